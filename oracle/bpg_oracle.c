@@ -1,0 +1,352 @@
+/*
+ * bpg_oracle.c -- CPU ORACLE (test infrastructure, see bpg_oracle.h).
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference).  Deliberately written the way the reference computes:
+ * float64 matrix, nested loops.  Do not "optimise" this file -- it is the
+ * checker, and bench.py times it only as the labelled cpu_baseline "port".
+ */
+#include "bpg_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* gym_blocks/envs/fetch_env.py:19-28 (evaluated in Python float64 order) */
+static double table_w(void) { double w = 0.25; w -= 0.05 / 2; return w; }
+static double table_h(void) { double h = 0.35; h -= 0.05 / 2; return h; }
+static double table_x(void) { return 1.05 + 0.25; }
+static double table_y(void) { return 0.40 + 0.35; }
+
+/* fetch_env.py:30-32 */
+int orc_out_of_table(double x, double y)
+{
+    return fabs(x - table_x()) > table_w() || fabs(y - table_y()) > table_h();
+}
+
+/* fetch_env.py:106-117 */
+int orc_geom2objid(const char *name)
+{
+    if (name != NULL) {
+        if (strstr(name, "finger") != NULL)
+            return 0;
+        else if (strcmp(name, "table") == 0)
+            return 1;
+        else if (strstr(name, "object") != NULL)
+            return atoi(name + 6) + 2;      /* int(name[6:]) + 2 */
+    }
+    return -1;
+}
+
+/* fetch_env.py:323-326 (GripperTouch), :360-363 (BlocksTouch), :434-441
+ * (Choose; shuffle commented out :438), :632-639 (Variation, max_num_blocks=4
+ * :523), :772-775 (ToppleTower). */
+int orc_sample_colors(int variant, int *c)
+{
+    switch (variant) {
+    case ORC_GRIPPER_TOUCH:
+        c[0] = ORC_BLUE; c[1] = ORC_GREY; c[2] = ORC_GREEN;
+        return 3;
+    case ORC_BLOCKS_TOUCH:
+    case ORC_BLOCKS_TOUCH_CURRICULUM:
+        c[0] = ORC_GREY; c[1] = ORC_GREY; c[2] = ORC_GREEN; c[3] = ORC_BLUE;
+        return 4;
+    case ORC_BLOCKS_TOUCH_CHOOSE:
+    case ORC_BLOCKS_TOUCH_CHOOSE_CURRICULUM:
+        c[0] = ORC_GREY; c[1] = ORC_GREY; c[2] = ORC_GREEN; c[3] = ORC_BLUE; c[4] = ORC_GREY;
+        return 5;
+    case ORC_BLOCKS_TOUCH_VARIATION:
+        c[0] = ORC_GREY; c[1] = ORC_GREY; c[2] = ORC_GREEN; c[3] = ORC_BLUE;
+        c[4] = ORC_GREY; c[5] = ORC_GREY;
+        return 6;
+    case ORC_TOPPLE_TOWER:
+        c[0] = ORC_RED; c[1] = ORC_GREEN; c[2] = ORC_GREY; c[3] = ORC_GREY;
+        c[4] = ORC_GREY; c[5] = ORC_BLUE;
+        return 6;
+    }
+    return 0;
+}
+
+/* fetch_env.py:260-273; Variation :682-695 always uses side 6 */
+void orc_sample_goal(const int *C, int side, long long *goal)
+{
+    int k = 0;
+    for (int i = 0; i < side; i++) {
+        for (int j = 0; j < side; j++) {
+            if ((C[i] == ORC_RED && C[j] == ORC_BLUE) || (C[i] == ORC_BLUE && C[j] == ORC_RED))
+                goal[k++] = -1;
+            else if ((C[i] == ORC_GREEN && C[j] == ORC_BLUE) || (C[i] == ORC_BLUE && C[j] == ORC_GREEN))
+                goal[k++] = 1;
+            else
+                goal[k++] = 0;
+        }
+    }
+}
+
+/* fetch_env.py:64-86 (constructor state) + robot_env.py:36 (goal sampled once
+ * in __init__); Variation keeps max_num_blocks + 2 = 6 (:523-527). */
+void orc_env_init(orc_env *e, int variant, int max_episode_steps)
+{
+    memset(e, 0, sizeof(*e));
+    e->variant = variant;
+    e->is_variation = (variant == ORC_BLOCKS_TOUCH_VARIATION);
+    e->num_objs = orc_sample_colors(variant, e->obj_colors);
+    e->side = e->num_objs;
+    for (int k = 0; k < ORC_MAX_G; k++)
+        e->achieved_goal[k] = -1.0;            /* :78 */
+    e->has_succeeded = 0;                      /* :80 */
+    orc_sample_goal(e->obj_colors, e->side, e->goal);
+    e->elapsed_steps = 0;
+    e->max_episode_steps = max_episode_steps;
+}
+
+/* robot_env.py:71-82 -> _reset_sim fetch_env.py:247-255: colours re-sampled
+ * (constant), has_succeeded cleared, achieved_goal untouched (Q1).
+ * Variation _reset_sim :646-679: num_grey = np_random.randint(3) (explicit
+ * input here), num_objs = 4 + num_grey, matrix re-created as -1 (6x6).
+ * Then goal = _sample_goal() (robot_env.py:80).  TimeLimit.reset zeroes the
+ * step counter (third-party). */
+void orc_env_reset(orc_env *e, int num_grey)
+{
+    if (e->is_variation) {
+        e->num_objs = 4 + num_grey;
+        e->side = 6;
+        for (int k = 0; k < ORC_MAX_G; k++)
+            e->achieved_goal[k] = -1.0;
+    }
+    orc_sample_colors(e->variant, e->obj_colors);
+    e->has_succeeded = 0;
+    orc_sample_goal(e->obj_colors, e->side, e->goal);
+    e->elapsed_steps = 0;
+}
+
+/* fetch_env.py:154-157: entries == 1 -> 0 for i,j < num_objs (row stride is
+ * the allocated side); :158-167: contacts with both geoms mapped set 1. */
+static void demote(orc_env *e)
+{
+    for (int i = 0; i < e->num_objs; i++)
+        for (int j = 0; j < e->num_objs; j++)
+            if (e->achieved_goal[i * e->side + j] == 1)
+                e->achieved_goal[i * e->side + j] = 0;
+}
+
+void orc_step_callback(orc_env *e, const int *id2obj, const int *contacts, int ncon)
+{
+    demote(e);
+    for (int i = 0; i < ncon; i++) {
+        int obj1 = id2obj[contacts[2 * i]];
+        int obj2 = id2obj[contacts[2 * i + 1]];
+        if (obj1 != -1 && obj2 != -1) {
+            e->achieved_goal[obj1 * e->side + obj2] = 1;
+            e->achieved_goal[obj2 * e->side + obj1] = 1;
+        }
+    }
+}
+
+int orc_pair_index(int i, int j)
+{
+    if (i > j) { int t = i; i = j; j = t; }
+    return i * ORC_MAX_OBJS - i * (i - 1) / 2 + (j - i);
+}
+
+uint32_t orc_contacts_to_mask(const int *id2obj, const int *contacts, int ncon)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < ncon; i++) {
+        int a = id2obj[contacts[2 * i]], b = id2obj[contacts[2 * i + 1]];
+        if (a != -1 && b != -1)
+            m |= 1u << orc_pair_index(a, b);
+    }
+    return m;
+}
+
+void orc_step_callback_mask(orc_env *e, uint32_t mask)
+{
+    demote(e);
+    for (int i = 0; i < e->side; i++)
+        for (int j = i; j < e->side; j++)
+            if (mask & (1u << orc_pair_index(i, j))) {
+                e->achieved_goal[i * e->side + j] = 1;
+                e->achieved_goal[j * e->side + i] = 1;
+            }
+}
+
+/* fetch_env.py:119-124 */
+int orc_check_goal(const orc_env *e)
+{
+    for (int i = 0; i < e->num_objs; i++)
+        for (int j = 0; j < e->num_objs; j++)
+            if (e->achieved_goal[i * e->side + j] != e->achieved_goal[j * e->side + i])
+                return 0;
+    return 1;
+}
+
+/* fetch_env.py:141-143: d = sum(ag*g); c = count_nonzero(g);
+ * -(d != c).astype(float32): -1.0f on mismatch, -0.0f on match (quirk Q2). */
+float orc_compute_reward(const double *ag, const double *g, int len)
+{
+    double d = 0.0;
+    long long c = 0;
+    for (int k = 0; k < len; k++) {
+        d += ag[k] * g[k];
+        if (g[k] != 0.0)
+            c++;
+    }
+    float ne = (d != (double)c) ? 1.0f : 0.0f;
+    return -ne;
+}
+
+void orc_compute_reward_batch(const double *ag, const double *g, int n, int len, float *out)
+{
+    for (int r = 0; r < n; r++)
+        out[r] = orc_compute_reward(ag + (size_t)r * len, g + (size_t)r * len, len);
+}
+
+/* fetch_env.py:220 / Variation :610-613 (padding to 36 is empty: side is 6) */
+void orc_get_achieved_goal(const orc_env *e, double *out)
+{
+    for (int k = 0; k < e->side * e->side; k++)
+        out[k] = e->achieved_goal[k];
+}
+
+static float reward_of_state(const orc_env *e)
+{
+    double g[ORC_MAX_G];
+    int len = e->side * e->side;
+    for (int k = 0; k < len; k++)
+        g[k] = (double)e->goal[k];
+    return orc_compute_reward(e->achieved_goal, g, len);
+}
+
+/* fetch_env.py:275-281: ignores its arguments, r == 0 (true for -0.0) latches */
+int orc_is_success(orc_env *e)
+{
+    float r = reward_of_state(e);
+    if (r == 0)
+        e->has_succeeded = 1;
+    return e->has_succeeded;
+}
+
+/* robot_env.py:57-69 after sim.step(): _step_callback, _get_obs (asserts
+ * _check_goal fetch_env.py:219), info['is_success'], reward; env done=False.
+ * gym TimeLimit (max_episode_steps=50, gym_blocks/__init__.py:10) ORs in
+ * elapsed_steps >= max (third-party behaviour). */
+static void finish_step(orc_env *e, float *reward, int *done, int *is_success)
+{
+    if (!orc_check_goal(e))
+        abort();
+    *is_success = orc_is_success(e);
+    *reward = reward_of_state(e);
+    e->elapsed_steps += 1;
+    *done = (e->elapsed_steps >= e->max_episode_steps) ? 1 : 0;
+}
+
+void orc_env_step(orc_env *e, const int *id2obj, const int *contacts, int ncon,
+                  float *reward, int *done, int *is_success)
+{
+    orc_step_callback(e, id2obj, contacts, ncon);
+    finish_step(e, reward, done, is_success);
+}
+
+void orc_env_step_mask(orc_env *e, uint32_t mask, float *reward, int *done, int *is_success)
+{
+    orc_step_callback_mask(e, mask);
+    finish_step(e, reward, done, is_success);
+}
+
+/* policy_gradient/rollout.py:255-258 -- at step t the reference appends r_t and
+ * then, for every earlier t_, does returns[t_] += gamma ** (t - t_) * r_t.
+ * So G[t_] accumulates r_t_ first, then the later terms in increasing t. */
+void orc_discounted_return(const double *r, int T, double gamma, double *G)
+{
+    for (int t = 0; t < T; t++) {
+        G[t] = r[t];
+        for (int t_ = 0; t_ < t; t_++)
+            G[t_] += pow(gamma, (double)(t - t_)) * r[t];
+    }
+}
+
+/* ---- build-defined synthetic contact source (no reference counterpart) ---- */
+uint32_t orc_hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+uint32_t orc_synth_mask(uint32_t seed, uint32_t env_id, uint32_t t, int num_objs)
+{
+    const uint32_t M21 = (1u << 21) - 1;
+    uint32_t key = orc_hash32(seed ^ orc_hash32(env_id + 0x9E3779B9U));
+    uint32_t w[4];
+    for (uint32_t i = 0; i < 4; i++)
+        w[i] = orc_hash32(key + (4u * t + i) * 0x9E3779B9U + 0x85EBCA6BU);
+    uint32_t f4 = ((w[0] >> 21) | ((w[1] >> 21) << 11)) & M21;
+    /* bit-sliced Bernoulli(5/32): 0.00101b, LSB first */
+    uint32_t acc = f4;
+    acc &= (w[3] & M21);
+    acc |= (w[2] & M21);
+    acc &= (w[1] & M21);
+    acc &= (w[0] & M21);
+    uint32_t valid = 0, forced = 0;
+    for (int i = 0; i < num_objs; i++)
+        for (int j = i + 1; j < num_objs; j++)
+            valid |= 1u << orc_pair_index(i, j);
+    for (int k = 2; k < num_objs; k++)
+        forced |= 1u << orc_pair_index(1, k);
+    return (acc & valid) | forced;
+}
+
+/* rollout.py:60-64 reset_all_rollouts, :75-172 generate_rollouts.  The policy
+ * and the physics are outside the boundary: the step's contacts arrive as
+ * masks[t*B+b].  float64 -> float32 stores as rollout.py:82-83,117-118,149-150.
+ * Episode arrays batch-major as convert_episode_to_batch_major (util.py:118-128). */
+double orc_generate_rollouts(orc_env *envs, int B, int T, const uint32_t *masks,
+                             const int *num_grey,
+                             float *ag, float *g, float *info_is_success, float *reward_tb)
+{
+    double succ_sum = 0.0;
+    for (int b = 0; b < B; b++) {
+        orc_env *e = &envs[b];
+        orc_env_reset(e, num_grey ? num_grey[b] : 0);
+        int dimg = e->side * e->side;
+        double cur[ORC_MAX_G];
+        orc_get_achieved_goal(e, cur);                        /* initial_ag */
+        int last_success = 0;
+        for (int t = 0; t < T; t++) {
+            float r; int done, succ;
+            for (int k = 0; k < dimg; k++) {
+                ag[((size_t)b * (T + 1) + t) * dimg + k] = (float)cur[k];
+                g[((size_t)b * T + t) * dimg + k] = (float)e->goal[k];
+            }
+            orc_env_step_mask(e, masks[(size_t)t * B + b], &r, &done, &succ);
+            orc_get_achieved_goal(e, cur);
+            info_is_success[(size_t)b * T + t] = (float)succ;
+            if (reward_tb)
+                reward_tb[(size_t)t * B + b] = r;
+            last_success = succ;
+        }
+        for (int k = 0; k < dimg; k++)
+            ag[((size_t)b * (T + 1) + T) * dimg + k] = (float)cur[k];
+        succ_sum += last_success;                            /* rollout.py:163-167 */
+    }
+    return succ_sum / B;
+}
+
+uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed)
+{
+    uint64_t sum = 0;
+    orc_env e;
+    for (int b = 0; b < B; b++) {
+        orc_env_init(&e, variant, T);
+        orc_env_reset(&e, 2);
+        for (int t = 0; t < T; t++) {
+            float r; int done, succ;
+            uint32_t m = orc_synth_mask(seed, (uint32_t)b, (uint32_t)t, e.num_objs);
+            orc_env_step_mask(&e, m, &r, &done, &succ);
+            sum += (uint64_t)(r == 0) + 2u * (uint64_t)succ + 4u * (uint64_t)done;
+        }
+    }
+    return sum;
+}

@@ -1,0 +1,143 @@
+/*
+ * bpg_oracle.h -- CPU ORACLE for the gym_blocks step()/reset() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C, scalar restatement of the
+ * reference's algorithm (matthew9671/BlockPuzzle-gym, paths relative to the
+ * reference root) in the SAME FORM the reference computes it: a float64
+ * N x N ternary "touch matrix" per env, Python-style loops, no bit packing.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product (blockpuzzle-gym_amd/) never links, imports or calls
+ * anything in oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * below against fixtures recorded from the reference's own code
+ * (tests/golden/make_golden.py; generated in the build container by importing
+ * /root/reference through inert stand-ins for gym / mujoco_py).  Not pinned,
+ * because the code lives in third-party packages absent from the reference
+ * tree (mujoco_py>=1.50 / MuJoCo 1.50, gym>=0.10 -- no version is pinned by
+ * setup.py:6): physics, observation floats, gym's seeding hash, TimeLimit
+ * (restated from SURVEY.md A.4, marked below).
+ */
+#ifndef BPG_ORACLE_H
+#define BPG_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_OBJS 6
+#define ORC_MAX_G    36
+
+/* colours, gym_blocks/envs/fetch_env.py:11-15 */
+enum { ORC_GREY = 0, ORC_RED = 1, ORC_GREEN = 2, ORC_BLUE = 3, ORC_NUM_COLORS = 4 };
+
+/* one per class registered in gym_blocks/__init__.py:6-53 */
+enum {
+    ORC_GRIPPER_TOUCH = 0,            /* GripperTouch-v0                 */
+    ORC_BLOCKS_TOUCH = 1,             /* BlocksTouch-v0                  */
+    ORC_TOPPLE_TOWER = 2,             /* ToppleTower-v0                  */
+    ORC_BLOCKS_TOUCH_CURRICULUM = 3,  /* BlocksTouchCurriculum-v0        */
+    ORC_BLOCKS_TOUCH_CHOOSE = 4,      /* BlocksTouchChoose-v0            */
+    ORC_BLOCKS_TOUCH_CHOOSE_CURRICULUM = 5,
+    ORC_BLOCKS_TOUCH_VARIATION = 6,   /* BlocksTouchVariation-v0         */
+    ORC_NUM_VARIANTS = 7
+};
+
+typedef struct {
+    int variant;
+    int num_objs;                 /* fetch_env.py:75; Variation per episode :649 */
+    int side;                     /* matrix side: num_objs, Variation always 6 (:663) */
+    int is_variation;
+    double achieved_goal[ORC_MAX_G];   /* fetch_env.py:78, row-major side x side */
+    long long goal[ORC_MAX_G];         /* fetch_env.py:260-273 / :682-695        */
+    int obj_colors[ORC_MAX_OBJS];
+    int has_succeeded;            /* fetch_env.py:80  */
+    int elapsed_steps;            /* gym TimeLimit (third-party) */
+    int max_episode_steps;        /* gym_blocks/__init__.py: 50 everywhere   */
+} orc_env;
+
+/* fetch_env.py:106-117: geom name -> object id, -1 for None. */
+int orc_geom2objid(const char *name);
+
+/* fetch_env.py:323-326,360-363,434-441,632-639,772-775: constant colourings.
+ * Returns the number of objects written. */
+int orc_sample_colors(int variant, int *colors);
+
+/* fetch_env.py:260-273 (Variation :682-695): colour table -> goal matrix. */
+void orc_sample_goal(const int *colors, int side, long long *goal);
+
+/* fetch_env.py:39-86 + tasks.py presets: fresh env, matrix all -1. */
+void orc_env_init(orc_env *e, int variant, int max_episode_steps);
+
+/* robot_env.py:71-82 + fetch_env.py:247-255 (Variation :646-679) + TimeLimit.
+ * num_grey is the explicit variate for np_random.randint(3) (:647); ignored
+ * for the other variants. Base classes do NOT clear achieved_goal (quirk Q1). */
+void orc_env_reset(orc_env *e, int num_grey);
+
+/* fetch_env.py:154-167 over a contact list of geom ids (contacts[2*i],
+ * contacts[2*i+1]); id2obj[g] == -1 means None. */
+void orc_step_callback(orc_env *e, const int *id2obj, const int *contacts, int ncon);
+
+/* Same update with the step's contact set given as a bit mask over the
+ * 21 unordered pairs (i<=j) of 6 objects, pair index orc_pair_index(i,j). */
+void orc_step_callback_mask(orc_env *e, uint32_t mask);
+
+/* fetch_env.py:119-124 */
+int orc_check_goal(const orc_env *e);
+
+/* fetch_env.py:135-143 for one row: -(sum(ag*g) != count_nonzero(g)) as float32. */
+float orc_compute_reward(const double *ag, const double *g, int len);
+/* vectorised over n rows of `len` (config.py:110-111 call shape). */
+void orc_compute_reward_batch(const double *ag, const double *g, int n, int len, float *out);
+
+/* fetch_env.py:275-281: recompute from own state, latch. */
+int orc_is_success(orc_env *e);
+
+/* robot_env.py:57-69 (+ TimeLimit done).  After the physics (not modelled) has
+ * produced the step's contact list.  Writes reward/done/is_success. */
+void orc_env_step(orc_env *e, const int *id2obj, const int *contacts, int ncon,
+                  float *reward, int *done, int *is_success);
+void orc_env_step_mask(orc_env *e, uint32_t mask, float *reward, int *done, int *is_success);
+
+/* achieved_goal as _get_obs returns it (fetch_env.py:220 / :610-613). */
+void orc_get_achieved_goal(const orc_env *e, double *out);
+
+/* pair index of unordered pair (i,j), i,j < 6: row-major upper triangle
+ * including the diagonal (build-defined packing, 21 pairs). */
+int orc_pair_index(int i, int j);
+/* contact list -> pair mask (build-defined helper). */
+uint32_t orc_contacts_to_mask(const int *id2obj, const int *contacts, int ncon);
+
+/* policy_gradient/rollout.py:255-258: returns[t_] += gamma**(t-t_) * r_new,
+ * evaluated in the reference's order, float64.  r: (T) rewards of one env. */
+void orc_discounted_return(const double *r, int T, double gamma, double *G);
+
+/* fetch_env.py:30-32 */
+int orc_out_of_table(double x, double y);
+
+/* ---- build-defined synthetic contact source (NO reference counterpart) ----
+ * Stand-in for the physics in throughput runs.  Counter-based:
+ * a pure function of (seed, env_id, t).  Table-block pairs (1,k) forced on,
+ * every other pair of the variant's objects Bernoulli(5/32).               */
+uint32_t orc_synth_mask(uint32_t seed, uint32_t env_id, uint32_t t, int num_objs);
+uint32_t orc_hash32(uint32_t x);
+
+/* rollout.py:75-172 for B envs and T steps with mask contacts (time-major
+ * masks[t*B+b]).  Outputs float32 episode arrays in batch-major layout:
+ * ag (B,T+1,dimg), g (B,T,dimg), info_is_success (B,T,1); optional per-step
+ * reward (T,B) float32.  Returns mean(successes[-1]). envs are reset first
+ * (num_grey[b] for Variation, may be NULL -> 0). */
+double orc_generate_rollouts(orc_env *envs, int B, int T, const uint32_t *masks,
+                             const int *num_grey,
+                             float *ag, float *g, float *info_is_success, float *reward_tb);
+
+/* cpu_baseline leg: B envs x T steps of the matrix-form step on synthetic
+ * masks, no episode buffers.  Returns a checksum so the work is not elided. */
+uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""ctypes loader for the CPU oracle (oracle/bpg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, '_build', 'libbpg_oracle.so')
+
+MAX_G = 36
+VARIANTS = {
+    'GripperTouch-v0': 0, 'BlocksTouch-v0': 1, 'ToppleTower-v0': 2,
+    'BlocksTouchCurriculum-v0': 3, 'BlocksTouchChoose-v0': 4,
+    'BlocksTouchChooseCurriculum-v0': 5, 'BlocksTouchVariation-v0': 6,
+}
+
+
+class Env(C.Structure):
+    _fields_ = [
+        ('variant', C.c_int), ('num_objs', C.c_int), ('side', C.c_int),
+        ('is_variation', C.c_int),
+        ('achieved_goal', C.c_double * MAX_G),
+        ('goal', C.c_longlong * MAX_G),
+        ('obj_colors', C.c_int * 6),
+        ('has_succeeded', C.c_int), ('elapsed_steps', C.c_int),
+        ('max_episode_steps', C.c_int),
+    ]
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src_m = max(os.path.getmtime(os.path.join(_HERE, f))
+                    for f in ('bpg_oracle.c', 'bpg_oracle.h'))
+        if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
+            build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.POINTER
+        L.orc_geom2objid.argtypes = [C.c_char_p]
+        L.orc_geom2objid.restype = C.c_int
+        L.orc_sample_colors.argtypes = [C.c_int, P(C.c_int)]
+        L.orc_sample_goal.argtypes = [P(C.c_int), C.c_int, P(C.c_longlong)]
+        L.orc_env_init.argtypes = [P(Env), C.c_int, C.c_int]
+        L.orc_env_reset.argtypes = [P(Env), C.c_int]
+        L.orc_step_callback.argtypes = [P(Env), P(C.c_int), P(C.c_int), C.c_int]
+        L.orc_step_callback_mask.argtypes = [P(Env), C.c_uint32]
+        L.orc_check_goal.argtypes = [P(Env)]
+        L.orc_compute_reward.argtypes = [P(C.c_double), P(C.c_double), C.c_int]
+        L.orc_compute_reward.restype = C.c_float
+        L.orc_compute_reward_batch.argtypes = [P(C.c_double), P(C.c_double), C.c_int, C.c_int, P(C.c_float)]
+        L.orc_is_success.argtypes = [P(Env)]
+        L.orc_env_step.argtypes = [P(Env), P(C.c_int), P(C.c_int), C.c_int,
+                                   P(C.c_float), P(C.c_int), P(C.c_int)]
+        L.orc_env_step_mask.argtypes = [P(Env), C.c_uint32, P(C.c_float), P(C.c_int), P(C.c_int)]
+        L.orc_get_achieved_goal.argtypes = [P(Env), P(C.c_double)]
+        L.orc_pair_index.argtypes = [C.c_int, C.c_int]
+        L.orc_contacts_to_mask.argtypes = [P(C.c_int), P(C.c_int), C.c_int]
+        L.orc_contacts_to_mask.restype = C.c_uint32
+        L.orc_discounted_return.argtypes = [P(C.c_double), C.c_int, C.c_double, P(C.c_double)]
+        L.orc_out_of_table.argtypes = [C.c_double, C.c_double]
+        L.orc_synth_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_synth_mask.restype = C.c_uint32
+        L.orc_hash32.argtypes = [C.c_uint32]
+        L.orc_hash32.restype = C.c_uint32
+        L.orc_generate_rollouts.argtypes = [P(Env), C.c_int, C.c_int, P(C.c_uint32), P(C.c_int),
+                                            P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]
+        L.orc_generate_rollouts.restype = C.c_double
+        L.orc_bench_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_bench_rollout.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OracleEnv:
+    """One reference-form env (matrix state) behind the contacts-in boundary."""
+
+    def __init__(self, env_id, max_episode_steps=50):
+        self.L = lib()
+        self.e = Env()
+        self.L.orc_env_init(C.byref(self.e), VARIANTS[env_id], max_episode_steps)
+
+    @property
+    def dimg(self):
+        return self.e.side * self.e.side
+
+    def reset(self, num_grey=0):
+        self.L.orc_env_reset(C.byref(self.e), int(num_grey))
+        return self.achieved_goal()
+
+    def achieved_goal(self):
+        out = np.zeros(self.dimg)
+        self.L.orc_get_achieved_goal(C.byref(self.e), _p(out, C.c_double))
+        return out
+
+    def goal(self):
+        return np.array(self.e.goal[:self.dimg], dtype=np.int64)
+
+    def step(self, id2obj, contacts):
+        """contacts: (ncon, 2) geom ids.  Returns (ag, reward f32, done, is_success)."""
+        id2obj = np.ascontiguousarray(id2obj, np.int32)
+        con = np.ascontiguousarray(contacts, np.int32).reshape(-1, 2)
+        r, d, s = C.c_float(), C.c_int(), C.c_int()
+        self.L.orc_env_step(C.byref(self.e), _p(id2obj, C.c_int), _p(con, C.c_int), len(con),
+                            C.byref(r), C.byref(d), C.byref(s))
+        return self.achieved_goal(), np.float32(r.value), bool(d.value), bool(s.value)
+
+    def step_mask(self, mask):
+        r, d, s = C.c_float(), C.c_int(), C.c_int()
+        self.L.orc_env_step_mask(C.byref(self.e), int(mask), C.byref(r), C.byref(d), C.byref(s))
+        return self.achieved_goal(), np.float32(r.value), bool(d.value), bool(s.value)
+
+
+def compute_reward(ag, g):
+    ag = np.ascontiguousarray(ag, np.float64)
+    g = np.ascontiguousarray(np.broadcast_to(g, ag.shape), np.float64)
+    n2 = ag.shape[-1]
+    out = np.zeros(ag.shape[:-1], np.float32)
+    lib().orc_compute_reward_batch(_p(ag, C.c_double), _p(g, C.c_double),
+                                   int(np.prod(ag.shape[:-1], dtype=np.int64)), n2,
+                                   _p(out, C.c_float))
+    return out
+
+
+def contacts_to_mask(id2obj, contacts):
+    id2obj = np.ascontiguousarray(id2obj, np.int32)
+    con = np.ascontiguousarray(contacts, np.int32).reshape(-1, 2)
+    return int(lib().orc_contacts_to_mask(_p(id2obj, C.c_int), _p(con, C.c_int), len(con)))
+
+
+def synth_masks(seed, env_ids, T, num_objs):
+    """(T, B) uint32 masks of the build-defined synthetic contact source."""
+    L = lib()
+    env_ids = np.asarray(env_ids, np.uint32)
+    num_objs = np.broadcast_to(np.asarray(num_objs, np.int32), env_ids.shape)
+    out = np.zeros((T, len(env_ids)), np.uint32)
+    for t in range(T):
+        for b, (eid, n) in enumerate(zip(env_ids, num_objs)):
+            out[t, b] = L.orc_synth_mask(seed, int(eid), t, int(n))
+    return out
+
+
+def discounted_return(r, gamma):
+    r = np.ascontiguousarray(r, np.float64)
+    G = np.zeros_like(r)
+    lib().orc_discounted_return(_p(r, C.c_double), len(r), float(gamma), _p(G, C.c_double))
+    return G
+
+
+def generate_rollouts(env_id, B, T, masks, num_grey=None, envs=None, want_reward=True):
+    """Batch rollout (rollout.py:75-172).  Returns dict + the env array so a
+    caller can chain rollouts (quirk Q1 persistence)."""
+    L = lib()
+    if envs is None:
+        envs = (Env * B)()
+        for b in range(B):
+            L.orc_env_init(C.byref(envs[b]), VARIANTS[env_id], T)
+    dimg = envs[0].side ** 2 if not envs[0].is_variation else 36
+    masks = np.ascontiguousarray(masks, np.uint32)
+    assert masks.shape == (T, B)
+    ag = np.zeros((B, T + 1, dimg), np.float32)
+    g = np.zeros((B, T, dimg), np.float32)
+    succ = np.zeros((B, T, 1), np.float32)
+    rew = np.zeros((T, B), np.float32)
+    ng = None if num_grey is None else np.ascontiguousarray(num_grey, np.int32)
+    rate = L.orc_generate_rollouts(envs, B, T, _p(masks, C.c_uint32),
+                                   None if ng is None else _p(ng, C.c_int),
+                                   _p(ag, C.c_float), _p(g, C.c_float), _p(succ, C.c_float),
+                                   _p(rew, C.c_float) if want_reward else None)
+    return dict(ag=ag, g=g, info_is_success=succ, reward=rew, success_rate=rate), envs

@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's gym_blocks package through the stand-in modules of
+_ref_harness.py, builds the real registered env classes
+(gym_blocks/envs/tasks.py) on a scripted fake sim, and records what the
+reference's own step()/reset()/compute_reward()/RolloutStudent produce for
+seeded scripted contact lists.  Outputs are DATA ONLY (json / npz); neither the
+reference nor this harness is needed to run the test-suite.
+
+Explicit inputs recorded alongside the outputs (because the third-party RNG /
+physics cannot be reproduced): the contact list of every step (geom id pairs),
+`num_objs` of every Variation episode, the actions of every rollout.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_harness as H  # noqa: E402
+
+MAXCON = H.FakeData.MAXCON
+ENV_IDS = ['GripperTouch-v0', 'BlocksTouch-v0', 'ToppleTower-v0',
+           'BlocksTouchCurriculum-v0', 'BlocksTouchChoose-v0',
+           'BlocksTouchChooseCurriculum-v0', 'BlocksTouchVariation-v0']
+
+
+def f32bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+def attach_scripts(env, seed, log, p_pair=0.15):
+    """Give every fake sim of `env` a seeded contact script writing to `log`."""
+    u = env.unwrapped
+    sims = getattr(u, 'sims', None) or [u.sim]
+    if u.sim not in sims:
+        sims = sims + [u.sim]
+    for k, sim in enumerate(sims):
+        script = H.ContactScript(sim.model, seed * 17 + k, p_pair=p_pair)
+
+        def run(script=script):
+            pairs = script()
+            log.append(pairs)
+            return pairs
+        sim.script = run
+
+
+def pad_contacts(pairs):
+    out = -np.ones((MAXCON, 2), np.int16)
+    for k, (a, b) in enumerate(pairs):
+        out[k] = (a, b)
+    return out
+
+
+def variant_info(env_id):
+    env = H.make(env_id)
+    u = env.unwrapped
+    np.random.seed(1)
+    env.seed(1)
+    obs = env.reset()
+    info = dict(
+        env_id=env_id,
+        dimo=int(obs['observation'].shape[0]),
+        dimg=int(obs['desired_goal'].shape[0]),
+        block_gripper=bool(u.block_gripper),
+        obj_colors=[int(c) for c in u.obj_colors],
+        goal=[int(v) for v in obs['desired_goal']],
+        desired_goal_dtype=str(obs['desired_goal'].dtype),
+        achieved_goal_dtype=str(obs['achieved_goal'].dtype),
+        observation_dtype=str(obs['observation'].dtype),
+        max_episode_steps=int(env._max_episode_steps),
+        action_shape=list(env.action_space.shape),
+    )
+    sims = getattr(u, 'sims', None) or [u.sim]
+    info['models'] = []
+    for sim in sims:
+        names = sim.model.geom_names
+        # the reference's own _geom2objid over the real geom names
+        u_sim_backup = u.sim
+        u.sim = sim
+        ids = [u._geom2objid(i) for i in range(sim.model.ngeom)]
+        u.sim = u_sim_backup
+        info['models'].append(dict(
+            xml=os.path.relpath(sim.model.path, H.ASSET_DIR),
+            geom_names=names,
+            id2obj=[-1 if v is None else int(v) for v in ids]))
+    # curriculum surface (fetch_env.py:93-101, 351-358, 419-432, 623-630)
+    for name in ['set_test', 'increase_difficulty']:
+        try:
+            getattr(u, name)()
+            info[name] = 'ok'
+        except NotImplementedError:
+            info[name] = 'NotImplementedError'
+        except AttributeError:
+            info[name] = 'AttributeError'
+    return info
+
+
+def difficulty_trace(env_id, n=12):
+    env = H.make(env_id)
+    u = env.unwrapped
+    rows = []
+    for _ in range(n):
+        try:
+            r = u.increase_difficulty()
+        except (NotImplementedError, AttributeError) as e:
+            return dict(error=type(e).__name__)
+        rows.append(dict(ret=bool(r), difficulty=int(u.get_difficulty()),
+                         obj_range=float(u.obj_range),
+                         wrong_obj_range=(float(u.wrong_obj_range) if hasattr(u, 'wrong_obj_range') else None)))
+    return dict(rows=rows)
+
+
+def step_trace(env_id, seed, lens, test_eps=()):
+    env = H.make(env_id)
+    u = env.unwrapped
+    log = []
+    attach_scripts(env, seed, log)
+    np.random.seed(seed)
+    env.seed(seed)
+    arng = np.random.RandomState(seed + 99)
+    E, Tmax = len(lens), max(lens)
+    dimg = len(env.reset()['desired_goal'])
+    out = dict(
+        lens=np.asarray(lens, np.int32),
+        contacts=-np.ones((E, Tmax, MAXCON, 2), np.int16),
+        ncon=np.zeros((E, Tmax), np.int32),
+        model_idx=np.zeros(E, np.int32),
+        num_objs=np.zeros(E, np.int32),
+        test_mode=np.zeros(E, np.uint8),
+        ag_reset=np.zeros((E, dimg)), g=np.zeros((E, dimg)),
+        ag=np.zeros((E, Tmax, dimg)),
+        reward_bits=np.zeros((E, Tmax), np.uint32),
+        success=np.zeros((E, Tmax), np.uint8),
+        done=np.zeros((E, Tmax), np.uint8),
+        actions=np.zeros((E, Tmax, 4), np.float32),
+    )
+    sims = getattr(u, 'sims', None)
+    for e, L in enumerate(lens):
+        obs = env.reset()
+        if e in test_eps:
+            obs = u.set_test()
+            out['test_mode'][e] = 1
+        out['ag_reset'][e] = obs['achieved_goal']
+        out['g'][e] = obs['desired_goal']
+        out['num_objs'][e] = u.num_objs
+        out['model_idx'][e] = sims.index(u.sim) if sims else 0
+        for t in range(L):
+            a = arng.uniform(-1.5, 1.5, size=4).astype(np.float32)  # exercises the clip
+            n0 = len(log)
+            o, r, d, info = env.step(a)
+            assert len(log) == n0 + 1
+            out['actions'][e, t] = a
+            out['contacts'][e, t] = pad_contacts(log[-1])
+            out['ncon'][e, t] = len(log[-1])
+            out['ag'][e, t] = o['achieved_goal']
+            assert (o['desired_goal'] == out['g'][e]).all()
+            assert r.dtype == np.float32
+            out['reward_bits'][e, t] = f32bits(r)
+            out['success'][e, t] = bool(info['is_success'])
+            out['done'][e, t] = bool(d)
+    return out
+
+
+def compute_reward_cases(rng):
+    """The reference's vectorised compute_reward on ternary inputs
+    (config.py:110-111 call shape: (batch, N^2) in, (batch,) float32 out)."""
+    out = {}
+    for env_id in ['GripperTouch-v0', 'BlocksTouch-v0', 'BlocksTouchChoose-v0',
+                   'ToppleTower-v0', 'BlocksTouchVariation-v0']:
+        env = H.make(env_id)
+        g = np.asarray(env.reset()['desired_goal'])
+        n2 = g.shape[0]
+        key = env_id.split('-')[0]
+        ag = rng.randint(-1, 2, size=(257, n2)).astype(np.float32)
+        # make a good share of rows succeed
+        nz = g != 0
+        ag[::3][:, nz] = g[nz]
+        out[key + '_ag'] = ag
+        out[key + '_g'] = np.broadcast_to(g, ag.shape).astype(np.float32).copy()
+        r = env.compute_reward(ag, out[key + '_g'], None)
+        assert r.dtype == np.float32 and r.shape == (257,)
+        out[key + '_rbits'] = f32bits(r)
+        # random ternary goals too (HER relabels g with achieved goals)
+        g2 = rng.randint(-1, 2, size=(257, n2)).astype(np.float32)
+        g2[::4] = ag[::4] * (rng.rand(*ag[::4].shape) < 0.3)
+        out[key + '_g2'] = g2
+        out[key + '_rbits2'] = f32bits(env.compute_reward(ag, g2, None))
+        # extra leading axis + float64 inputs
+        ag3 = ag[:240].reshape(4, 60, n2).astype(np.float64)
+        g3 = g2[:240].reshape(4, 60, n2).astype(np.float64)
+        r3 = env.compute_reward(ag3, g3, None)
+        assert r3.shape == (4, 60)
+        out[key + '_rbits3'] = f32bits(r3)
+    return out
+
+
+class RandomPolicy:
+    """Seeded random-action policy with the call signature rollout.py:92-97 uses."""
+
+    def __init__(self, seed, log):
+        self.rng = np.random.RandomState(seed)
+        self.log = log
+        self.kwargs = {}
+
+    def get_actions(self, o, ag, g, **kw):
+        u = self.rng.uniform(-1, 1, size=(o.shape[0], 4)).astype(np.float32)
+        self.log.append(u)
+        if 'exploit' in kw:      # policy_gradient/rollout.py:202-204
+            return u, u.copy(), np.zeros_like(u)
+        return u
+
+
+class NullLogger:
+    def warning(self, *a):
+        pass
+    info = warning
+
+
+def rollout_trace(env_id, seed, B, modes, pg=False):
+    """Reference RolloutStudent.generate_rollouts (rollout.py:75-172 or the
+    policy_gradient variant) over B scripted envs."""
+    H.install()
+    if pg:
+        from gym_blocks.policy_gradient.rollout import RolloutStudent
+    else:
+        from gym_blocks.rollout import RolloutStudent
+    logs = []
+
+    def make_env():
+        env = H.make(env_id)
+        log = []
+        attach_scripts(env, seed + 1000 * len(logs), log, p_pair=0.012)
+        logs.append(log)
+        return env
+
+    np.random.seed(seed)
+    probe = H.make(env_id)
+    o = probe.reset()
+    dims = dict(o=o['observation'].shape[0], u=4, g=o['desired_goal'].shape[0],
+                info_is_success=1)
+    T = probe._max_episode_steps
+    ulog = []
+    policy = RandomPolicy(seed, ulog)
+    kw = dict(make_env=make_env, policy=policy, dims=dims, logger=NullLogger(), T=T,
+              rollout_batch_size=B)
+    if pg:
+        kw.update(expert=None, gamma=1. - 1. / T)
+    worker = RolloutStudent(**kw)
+    worker.seed(seed)
+    out = dict(T=np.int32(T), B=np.int32(B), modes=np.asarray(modes, np.uint8))
+    for r, test in enumerate(modes):
+        for log in logs:
+            del log[:]
+        del ulog[:]
+        ep = worker.generate_rollouts(test=bool(test))
+        for k, v in ep.items():
+            out['r%d_%s' % (r, k)] = v
+        con = -np.ones((B, T, MAXCON, 2), np.int16)
+        ncon = np.zeros((B, T), np.int32)
+        for b, log in enumerate(logs):
+            assert len(log) == T, (len(log), T)
+            for t, pairs in enumerate(log):
+                con[b, t] = pad_contacts(pairs)
+                ncon[b, t] = len(pairs)
+        out['r%d_contacts' % r] = con
+        out['r%d_ncon' % r] = ncon
+        out['r%d_num_objs' % r] = np.asarray([e.unwrapped.num_objs for e in worker.envs], np.int32)
+        sims = getattr(worker.envs[0].unwrapped, 'sims', None)
+        out['r%d_model_idx' % r] = np.asarray(
+            [e.unwrapped.sims.index(e.unwrapped.sim) if sims else 0 for e in worker.envs], np.int32)
+        out['r%d_success_rate' % r] = np.float64(worker.success_history[-1])
+    out['n_episodes'] = np.int32(worker.n_episodes)
+    return out
+
+
+def main():
+    H.install()
+    from gym_blocks.envs import fetch_env
+    rng = np.random.RandomState(20261004)
+
+    registry = [dict(id=r['id'], entry_point=r['entry_point'], kwargs=r.get('kwargs', {}),
+                     max_episode_steps=r['max_episode_steps']) for r in H.REGISTRY]
+    variants = {eid: variant_info(eid) for eid in ENV_IDS}
+    for eid in ENV_IDS:
+        variants[eid]['num_objs'] = int(H.make(eid).unwrapped.num_objs)
+        variants[eid]['difficulty'] = difficulty_trace(eid)
+
+    pts = rng.uniform([0.9, 0.3], [1.7, 1.2], size=(200, 2))
+    # points exactly on / next to the table edge
+    edge = [[fetch_env.TABLE_X + s * fetch_env.TABLE_W, fetch_env.TABLE_Y] for s in (-1, 1)]
+    edge += [[fetch_env.TABLE_X, fetch_env.TABLE_Y + s * fetch_env.TABLE_H] for s in (-1, 1)]
+    edge += [[np.nextafter(e[0], 9), np.nextafter(e[1], 9)] for e in list(edge)]
+    pts = np.concatenate([pts, np.asarray(edge)])
+    misc = dict(
+        constants=dict(GREY=fetch_env.GREY, RED=fetch_env.RED, GREEN=fetch_env.GREEN,
+                       BLUE=fetch_env.BLUE, NUM_COLORS=fetch_env.NUM_COLORS,
+                       BLOCK_SIZE=fetch_env.BLOCK_SIZE, MIN_BLOCK_DIST=fetch_env.MIN_BLOCK_DIST,
+                       TABLE_W=fetch_env.TABLE_W, TABLE_H=fetch_env.TABLE_H,
+                       TABLE_X=fetch_env.TABLE_X, TABLE_Y=fetch_env.TABLE_Y),
+        out_of_table=dict(points=pts.tolist(),
+                          expected=[bool(fetch_env.out_of_table(p)) for p in pts]),
+        one_hot_color=[fetch_env.one_hot_color(c).tolist() for c in range(4)],
+    )
+    with open(os.path.join(HERE, 'registry.json'), 'w') as f:
+        json.dump(registry, f, indent=1)
+    with open(os.path.join(HERE, 'variants.json'), 'w') as f:
+        json.dump(variants, f, indent=1)
+    with open(os.path.join(HERE, 'misc.json'), 'w') as f:
+        json.dump(misc, f, indent=1)
+
+    lens = [50, 50, 7, 50, 1, 60, 50, 23]
+    for k, eid in enumerate(ENV_IDS):
+        can_test = variants[eid]['set_test'] == 'ok'
+        tr = step_trace(eid, seed=100 + k, lens=lens, test_eps=(3, 6) if can_test else ())
+        np.savez_compressed(os.path.join(HERE, 'trace_%s.npz' % eid.split('-')[0]), **tr)
+
+    np.savez_compressed(os.path.join(HERE, 'compute_reward.npz'), **compute_reward_cases(rng))
+
+    for k, eid in enumerate(ENV_IDS):
+        can_test = variants[eid]['set_test'] == 'ok'
+        modes = [0, 0, 1, 0] if can_test else [0, 0, 0]
+        ro = rollout_trace(eid, seed=500 + k, B=5, modes=modes)
+        np.savez_compressed(os.path.join(HERE, 'rollout_%s.npz' % eid.split('-')[0]), **ro)
+    for k, eid in enumerate(['BlocksTouch-v0', 'BlocksTouchVariation-v0']):
+        ro = rollout_trace(eid, seed=700 + k, B=4, modes=[0, 0], pg=True)
+        np.savez_compressed(os.path.join(HERE, 'pg_rollout_%s.npz' % eid.split('-')[0]), **ro)
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/bpg_oracle.c) against fixtures recorded from the
+reference's own code (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bpg_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+VARIANTS = json.load(open(os.path.join(G, 'variants.json')))
+ENV_IDS = list(VARIANTS)
+
+
+def short(env_id):
+    return env_id.split('-')[0]
+
+
+def test_registry_matches_reference():
+    # gym_blocks/__init__.py:6-53
+    reg = json.load(open(os.path.join(G, 'registry.json')))
+    assert [r['id'] for r in reg] == ENV_IDS
+    assert all(r['max_episode_steps'] == 50 for r in reg)
+    assert all(r['kwargs'] == {'reward_type': 'sparse'} for r in reg)
+    assert set(O.VARIANTS) == set(ENV_IDS)
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_geom2objid_and_goal(env_id):
+    v = VARIANTS[env_id]
+    L = O.lib()
+    for m in v['models']:
+        got = [L.orc_geom2objid(None if n is None else n.encode()) for n in m['geom_names']]
+        assert got == m['id2obj']
+    e = O.OracleEnv(env_id)
+    assert e.e.num_objs == v['num_objs']
+    assert list(e.e.obj_colors[:v['num_objs']]) == v['obj_colors']
+    e.reset()
+    assert e.dimg == v['dimg']
+    assert e.goal().tolist() == v['goal']
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_step_traces(env_id):
+    """Full reference env.step()/reset() sequences, incl. Q1 persistence across
+    resets, -0.0 rewards, the is_success latch and TimeLimit done."""
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(G, 'trace_%s.npz' % short(env_id)))
+    e = O.OracleEnv(env_id, v['max_episode_steps'])
+    id2objs = [m['id2obj'] for m in v['models']]
+    neg0 = 0
+    for ep, L in enumerate(d['lens']):
+        ag0 = e.reset(num_grey=int(d['num_objs'][ep]) - 4)
+        assert e.e.num_objs == d['num_objs'][ep]
+        np.testing.assert_array_equal(ag0, d['ag_reset'][ep])
+        np.testing.assert_array_equal(e.goal(), d['g'][ep])
+        id2obj = id2objs[int(d['model_idx'][ep])]
+        for t in range(L):
+            con = d['contacts'][ep, t, :d['ncon'][ep, t]]
+            ag, r, done, succ = e.step(id2obj, con)
+            np.testing.assert_array_equal(ag, d['ag'][ep, t])
+            assert np.float32(r).view(np.uint32) == d['reward_bits'][ep, t]
+            assert done == bool(d['done'][ep, t])
+            assert succ == bool(d['success'][ep, t])
+            neg0 += int(d['reward_bits'][ep, t] == 0x80000000)
+            # mask form of the same step gives the same matrix
+            assert O.contacts_to_mask(id2obj, con) < (1 << 21)
+    assert neg0 > 0, 'fixture must exercise the -0.0 success reward'
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_step_traces_mask_form(env_id):
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(G, 'trace_%s.npz' % short(env_id)))
+    e = O.OracleEnv(env_id, v['max_episode_steps'])
+    id2objs = [m['id2obj'] for m in v['models']]
+    for ep, L in enumerate(d['lens']):
+        e.reset(num_grey=int(d['num_objs'][ep]) - 4)
+        id2obj = id2objs[int(d['model_idx'][ep])]
+        for t in range(L):
+            m = O.contacts_to_mask(id2obj, d['contacts'][ep, t, :d['ncon'][ep, t]])
+            ag, r, done, succ = e.step_mask(m)
+            np.testing.assert_array_equal(ag, d['ag'][ep, t])
+            assert np.float32(r).view(np.uint32) == d['reward_bits'][ep, t]
+            assert (done, succ) == (bool(d['done'][ep, t]), bool(d['success'][ep, t]))
+
+
+def test_compute_reward_batched():
+    d = np.load(os.path.join(G, 'compute_reward.npz'))
+    keys = sorted({k.rsplit('_', 1)[0] for k in d.files})
+    assert len(keys) == 5
+    for k in keys:
+        ag, g, g2 = d[k + '_ag'], d[k + '_g'], d[k + '_g2']
+        np.testing.assert_array_equal(O.compute_reward(ag, g).view(np.uint32), d[k + '_rbits'])
+        np.testing.assert_array_equal(O.compute_reward(ag, g2).view(np.uint32), d[k + '_rbits2'])
+        n2 = ag.shape[1]
+        r3 = O.compute_reward(ag[:240].reshape(4, 60, n2), g2[:240].reshape(4, 60, n2))
+        np.testing.assert_array_equal(r3.view(np.uint32), d[k + '_rbits3'])
+        assert (d[k + '_rbits'] == 0x80000000).any() and (d[k + '_rbits'] == 0xbf800000).any()
+
+
+def test_out_of_table_and_constants():
+    m = json.load(open(os.path.join(G, 'misc.json')))
+    L = O.lib()
+    pts, exp = m['out_of_table']['points'], m['out_of_table']['expected']
+    assert [bool(L.orc_out_of_table(x, y)) for x, y in pts] == exp
+    assert any(exp) and not all(exp)
+    c = m['constants']
+    assert (c['GREY'], c['RED'], c['GREEN'], c['BLUE']) == (0, 1, 2, 3)
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_rollout_student_episodes(env_id):
+    """Reference RolloutStudent.generate_rollouts (rollout.py:75-172) episode
+    dicts over consecutive rollouts -- ag/g/info_is_success/success_rate."""
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(G, 'rollout_%s.npz' % short(env_id)))
+    B, T = int(d['B']), int(d['T'])
+    envs = None
+    for r in range(len(d['modes'])):
+        id2objs = [m['id2obj'] for m in v['models']]
+        masks = np.zeros((T, B), np.uint32)
+        for b in range(B):
+            id2obj = id2objs[int(d['r%d_model_idx' % r][b])]
+            for t in range(T):
+                masks[t, b] = O.contacts_to_mask(
+                    id2obj, d['r%d_contacts' % r][b, t, :d['r%d_ncon' % r][b, t]])
+        out, envs = O.generate_rollouts(env_id, B, T, masks,
+                                        num_grey=d['r%d_num_objs' % r] - 4, envs=envs)
+        np.testing.assert_array_equal(out['ag'], d['r%d_ag' % r])
+        np.testing.assert_array_equal(out['g'], d['r%d_g' % r])
+        np.testing.assert_array_equal(out['info_is_success'], d['r%d_info_is_success' % r])
+        assert out['success_rate'] == float(d['r%d_success_rate' % r])
+
+
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation'])
+def test_pg_discounted_return(name):
+    """policy_gradient/rollout.py:255-258 return accumulation, bit-exact f64."""
+    env_id = name + '-v0'
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(G, 'pg_rollout_%s.npz' % name))
+    B, T = int(d['B']), int(d['T'])
+    gamma = 1. - 1. / T                      # config.py:83
+    envs = None
+    for r in range(len(d['modes'])):
+        masks = np.zeros((T, B), np.uint32)
+        for b in range(B):
+            id2obj = v['models'][int(d['r%d_model_idx' % r][b])]['id2obj']
+            for t in range(T):
+                masks[t, b] = O.contacts_to_mask(
+                    id2obj, d['r%d_contacts' % r][b, t, :d['r%d_ncon' % r][b, t]])
+        out, envs = O.generate_rollouts(env_id, B, T, masks,
+                                        num_grey=d['r%d_num_objs' % r] - 4, envs=envs)
+        for b in range(B):
+            Gb = O.discounted_return(out['reward'][:, b].astype(np.float64), gamma)
+            np.testing.assert_array_equal(Gb.view(np.uint64), d['r%d_G' % r][b].view(np.uint64))
+
+
+def test_synth_mask_properties():
+    """Build-defined contact source: deterministic, table-block pairs forced,
+    no diagonal / out-of-range pairs, Bernoulli(5/32) elsewhere."""
+    L = O.lib()
+    m = O.synth_masks(7, np.arange(4096), 8, 6)
+    assert (m == O.synth_masks(7, np.arange(4096), 8, 6)).all()
+    forced = sum(1 << L.orc_pair_index(1, k) for k in range(2, 6))
+    assert ((m & forced) == forced).all()
+    diag = sum(1 << L.orc_pair_index(i, i) for i in range(6))
+    assert ((m & diag) == 0).all()
+    free = [L.orc_pair_index(i, j) for i in range(6) for j in range(i + 1, 6) if not (i == 1 and j >= 2)]
+    rate = np.mean([((m >> p) & 1).mean() for p in free])
+    assert abs(rate - 5 / 32) < 0.01
+    m4 = O.synth_masks(7, np.arange(512), 4, 4)
+    valid4 = sum(1 << L.orc_pair_index(i, j) for i in range(4) for j in range(i + 1, 4))
+    assert ((m4 & ~np.uint32(valid4)) == 0).all()
