@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched gym_blocks step()/reset() hot
+path at 1 048 576 envs per GPU (BASELINE.json metric), one JSON line on rank 0.
+
+A bench "step" = one rollout pass over the batch: reset of all envs, T=50 fused
+env steps in one launch (contacts read as packed masks resident in HBM -- the
+contacts-in boundary -- rewards + success/done flags written per env-step), and
+the success-count reduction; with N>1 GPUs one RCCL all-reduce of
+(successes, envs) per rollout.  Weak scaling: every GPU holds `--envs` envs.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ENV_ID = 'BlocksTouchVariation-v0'
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=100)
+    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU')
+    p.add_argument('--T', type=int, default=50)
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=12.0)
+    return p.parse_args()
+
+
+def cpu_baseline(T, seconds):
+    """The oracle (matrix-form C port of the reference algorithm) timed on ONE host
+    core on a bounded sample of the same workload (same variant, same synthetic
+    contact source, same T)."""
+    from oracle import bpg_oracle as O
+    L = O.lib()
+    variant = O.VARIANTS[ENV_ID]
+    t0 = time.perf_counter()
+    L.orc_bench_rollout(variant, 8192, T, 0)
+    dt = time.perf_counter() - t0
+    envs = int(max(8192, min(4 << 20, 8192 * seconds / max(dt, 1e-6))))
+    t0 = time.perf_counter()
+    L.orc_bench_rollout(variant, envs, T, 0)
+    dt = time.perf_counter() - t0
+    return dict(value=envs * T / dt, unit='env-steps/s', cores=1, kind='port',
+                sample='%d envs x %d steps of %s, synthetic contacts, %.1f s on 1 thread '
+                       '(oracle/bpg_oracle.c matrix-form port)' % (envs, T, ENV_ID, dt))
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import blockpuzzle_gym_amd as bpg
+    from blockpuzzle_gym_amd import _lib, distributed as D
+
+    rank, world, local = D.init_from_env()
+    assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    L = _lib.lib()
+    B, T = a.envs, a.T
+    total = B * world
+    env = D.make_sharded(ENV_ID, total, rank, world, device=dev, seed=a.seed)
+    assert env.num_envs == B
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    # inputs resident in HBM before the timed region: (T, B) contact masks from the
+    # synthetic source (global env index keyed), outputs preallocated
+    env.reset()
+    masks = torch.empty((T, B), dtype=torch.int32, device=dev)
+    _lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(masks.data_ptr()), stream))
+    reward = torch.empty((T, B), dtype=torch.float32, device=dev)
+    flags = torch.empty((T, B), dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    args = _lib.RolloutArgs(T=T, d_masks=masks.data_ptr(), d_reward_tb=reward.data_ptr(),
+                            d_flags_tb=flags.data_ptr(), d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    stats = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+
+    def one_rollout(k=None):
+        _lib.check(L.bpg_reset(env._h, None, None, stream))
+        if k is not None:
+            ev0[k].record()
+        _lib.check(L.bpg_rollout(env._h, C.byref(args), stream))
+        if k is not None:
+            ev1[k].record()
+        count.zero_()
+        _lib.check(L.bpg_success_count(env._h, C.c_void_p(count.data_ptr()), stream))
+        if world > 1:
+            stats[0] = count[0]
+            stats[1] = B
+            dist.all_reduce(stats)          # the one collective per rollout (RCCL over xGMI)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        one_rollout()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        one_rollout(k)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)) / a.steps
+    succ_rate = float(count.item()) / B
+
+    # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
+    # reward 4 B + flags 1 B out; per env packed state 8 B in + 8 B out
+    bytes_per_launch = B * (T * 9 + 16)
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tf):
+        t = json.load(open(tf)).get('k_rollout_vec4_masks')
+        if t and t.get('envs') == B and t.get('T') == T:
+            traffic = t['hbm_bytes_per_launch']
+
+    out = {
+        'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
+        'data': 'synthetic',
+        'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
+                               'resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
+                               'env-step' % (ENV_ID, B, T),
+                   'envs_per_gpu': B, 'total_envs': total, 'T': T, 'parallelism': 'env-shard x%d' % world,
+                   'success_rate': succ_rate},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_rollout_vec4<masks>', 'achieved': achieved,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
+                     'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms},
+    }
+
+    if rank == 0 and not a.no_extras:
+        out['extra'] = extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
+    """Secondary kernels of the same path, each with its own algorithmic-byte
+    roofline line (not part of `value`)."""
+    L = _lib.lib()
+    res = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    def line(ms, nbytes, env_steps):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {'ms': ms, 'GB/s': gbs, 'frac_hbm_peak': gbs / HBM_PEAK_GBS, 'bytes': nbytes,
+                'env_steps_per_sec': env_steps / (ms * 1e-3)}
+
+    # (1) one env.step launch: 12 B in (now, ever, mask) + 13 B out (now, ever, reward, flags) = 25 B/env-step
+    def step_once():
+        _lib.check(L.bpg_step_masks(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
+                                    C.c_void_p(flags.data_ptr()), stream))
+    res['step_masks_single_launch'] = line(timed(step_once, 200), 25 * B, B)
+
+    # (2) the same T steps as T launches replayed from a hipGraph
+    try:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            cs = C.c_void_p(s.cuda_stream)
+            with torch.cuda.graph(g, stream=s):
+                for t in range(T):
+                    _lib.check(L.bpg_step_masks(env._h, C.c_void_p(masks[t].data_ptr()),
+                                                C.c_void_p(reward[t].data_ptr()),
+                                                C.c_void_p(flags[t].data_ptr()), cs))
+        res['step_masks_graph_T_launches'] = line(timed(g.replay, 20), 25 * B * T, B * T)
+    except Exception as e:  # noqa: BLE001
+        res['step_masks_graph_T_launches'] = {'error': repr(e)[:200]}
+
+    # (3) fused rollout with in-kernel synthetic contacts: reward 4 + flags 1 per env-step + 16 B state
+    a2 = _lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr(),
+                          d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+
+    def synth():
+        _lib.check(L.bpg_reset(env._h, None, None, stream))
+        _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
+    res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 16), B * T)
+
+    # (4) episode writer: float32 episode['ag'] (B,T+1,36), ['g'] (B,T,36), ['info_is_success'] (B,T,1)
+    try:
+        dimg = env.dimg
+        ag = torch.empty((B, T + 1, dimg), dtype=torch.float32, device=dev)
+        gg = torch.empty((B, T, dimg), dtype=torch.float32, device=dev)
+        sc = torch.empty((B, T, 1), dtype=torch.float32, device=dev)
+        a3 = _lib.RolloutArgs(T=T, d_masks=masks.data_ptr(), d_reward_tb=None, d_flags_tb=None,
+                              d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(), d_ep_success=sc.data_ptr())
+
+        def episode():
+            _lib.check(L.bpg_reset(env._h, None, None, stream))
+            _lib.check(L.bpg_rollout(env._h, C.byref(a3), stream))
+        nbytes = B * (16 + T * 4 + 4 * ((T + 1) * dimg + T * dimg + T))
+        res['episode_writer_f32'] = line(timed(episode, 5), nbytes, B * T)
+        del ag, gg, sc
+    except Exception as e:  # noqa: BLE001
+        res['episode_writer_f32'] = {'error': repr(e)[:200]}
+    return res
+
+
+if __name__ == '__main__':
+    main()

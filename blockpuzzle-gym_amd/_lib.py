@@ -1,0 +1,109 @@
+"""ctypes binding of include/bpgym.h (the C-ABI drop-in boundary).
+
+The shared library is built in-tree by `build.build()` (hipcc, gfx950).  There
+is NO fallback: if the library is missing or a launch fails, the caller gets an
+exception -- nothing here (or anywhere in this package) routes to a CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libbpgym.so')
+
+OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ATTRIBUTE = 0, -1, -2, -3, -4
+MAX_OBJS, NUM_PAIRS, MAX_GEOMS, MAX_MODELS = 6, 21, 64, 3
+FLAG_SUCCESS, FLAG_DONE = 1, 2
+
+
+class VariantInfo(C.Structure):
+    _fields_ = [
+        ('variant', C.c_int32), ('num_objs', C.c_int32), ('side', C.c_int32),
+        ('dimg', C.c_int32), ('dimo', C.c_int32), ('dimu', C.c_int32),
+        ('block_gripper', C.c_int32), ('is_variation', C.c_int32),
+        ('max_episode_steps', C.c_int32), ('set_test_supported', C.c_int32),
+        ('increase_difficulty_status', C.c_int32), ('desired_goal_is_float', C.c_int32),
+        ('obj_colors', C.c_int32 * MAX_OBJS), ('goal', C.c_int32 * (MAX_OBJS * MAX_OBJS)),
+        ('want_touch', C.c_uint32), ('want_never', C.c_uint32), ('valid_pairs', C.c_uint32),
+        ('env_id', C.c_char * 48),
+    ]
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [
+        ('T', C.c_int32),
+        ('d_masks', C.c_void_p), ('d_reward_tb', C.c_void_p), ('d_flags_tb', C.c_void_p),
+        ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/bpgym.h declares
+SIGNATURES = {
+    'bpg_last_error': (C.c_char_p, []),
+    'bpg_version': (C.c_int, []),
+    'bpg_variant_from_id': (C.c_int, [C.c_char_p]),
+    'bpg_get_variant_info': (C.c_int, [C.c_int, C.POINTER(VariantInfo)]),
+    'bpg_geom2objid': (C.c_int, [C.c_char_p]),
+    'bpg_pair_index': (C.c_int, [C.c_int, C.c_int]),
+    'bpg_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_int,
+                             C.c_uint64, C.c_int64]),
+    'bpg_destroy': (C.c_int, [C.c_void_p]),
+    'bpg_num_envs': (C.c_int64, [C.c_void_p]),
+    'bpg_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'bpg_set_id2obj': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int8), C.c_int]),
+    'bpg_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_step_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_step_contacts': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_synth_masks': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'bpg_get_achieved_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_get_achieved_goal_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_get_desired_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_state_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'bpg_compute_reward_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_void_p]),
+    'bpg_compute_reward_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    'bpg_rollout': (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.c_void_p]),
+    'bpg_success_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_discounted_return': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p,
+                                        C.c_int, C.c_void_p]),
+}
+
+
+class BpgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('bpgym error %d: %s' % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libbpgym.so (raises if it has not been built -- no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'HIP extension %s is missing: run `python -c "import __graft_entry__ as g; '
+                'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise BpgError(rc, lib().bpg_last_error().decode())
+    return rc
+
+
+def variant_info(variant):
+    info = VariantInfo()
+    check(lib().bpg_get_variant_info(int(variant), C.byref(info)))
+    return info

@@ -1,0 +1,1245 @@
+// bpgym.hip -- hand-written HIP (gfx950 / CDNA4, wave64) implementation of the
+// batched gym_blocks step()/reset() hot path behind include/bpgym.h.
+//
+// Reference semantics implemented here (paths relative to the reference root):
+//   _step_callback   gym_blocks/envs/fetch_env.py:148-167
+//   compute_reward   fetch_env.py:135-143   (-1.0f / -0.0f)
+//   _is_success      fetch_env.py:275-281   (latched)
+//   _sample_goal     fetch_env.py:260-273, Variation :682-695
+//   _reset_sim       fetch_env.py:247-255,  Variation :646-679
+//   RobotEnv.step    gym_blocks/envs/robot_env.py:57-69 (+ gym TimeLimit done)
+//   generate_rollouts gym_blocks/rollout.py:75-172 (episode arrays, batch-major)
+//
+// Design: the symmetric ternary N x N touch matrix is stored as two
+// bit planes over the 21 unordered pairs of <=6 objects, 8 bytes per env in two
+// SoA uint32 arrays.  Everything is integer/bitmask streaming work: kernels are
+// HBM-bound, use 16-byte-per-lane coalesced accesses, keep state in registers
+// across fused steps, stage per-wave history tiles in LDS so that the float32
+// episode buffers are written as contiguous 1 KiB wave stores, and reduce
+// success counts with ballot/popcount.  No MFMA (nothing here is a contraction).
+//
+// This file never touches oracle/ and has no CPU fallback: without a GPU every
+// launch fails with BPG_ERR_HIP.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/bpgym.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(BPG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr uint32_t PAIR_BITS = (1u << BPG_NUM_PAIRS) - 1u;  // bits 0..20
+constexpr uint32_t ELAPSED_SHIFT = 21;
+constexpr uint32_t ELAPSED_MAX = 1023;                      // 10 bits, saturating
+constexpr uint32_t NOBJ_SHIFT = 21;                         // in `ever`
+constexpr uint32_t SUCC_BIT = 1u << 31;                     // in `ever`
+constexpr uint32_t RBITS_FAIL = 0xBF800000u;                // -1.0f
+constexpr uint32_t RBITS_OK = 0x80000000u;                  // -0.0f (quirk Q2)
+
+constexpr int host_pair_index(int i, int j)
+{
+    return i <= j ? i * BPG_MAX_OBJS - i * (i - 1) / 2 + (j - i)
+                  : j * BPG_MAX_OBJS - j * (j - 1) / 2 + (i - j);
+}
+
+// ---------------------------------------------------------------------------
+// variant table (host): tasks.py presets + constant colourings + goal planes
+// ---------------------------------------------------------------------------
+enum { GREY = 0, RED = 1, GREEN = 2, BLUE = 3 };   // fetch_env.py:11-14
+
+struct VariantDef {
+    const char *id;
+    int num_objs;
+    int colors[BPG_MAX_OBJS];
+    int block_gripper;       // tasks.py
+    int set_test;            // fetch_env.py:100-101 raises unless overridden
+    int incr_status;         // quirk Q6
+};
+
+const VariantDef kVariants[BPG_NUM_VARIANTS] = {
+    // fetch_env.py:323-326, tasks.py:4-20
+    {"GripperTouch-v0", 3, {BLUE, GREY, GREEN, 0, 0, 0}, 0, 0, BPG_ERR_UNSUPPORTED},
+    // fetch_env.py:360-363, tasks.py:22-40
+    {"BlocksTouch-v0", 4, {GREY, GREY, GREEN, BLUE, 0, 0}, 0, 1, BPG_OK},
+    // fetch_env.py:772-775, tasks.py:126-144
+    {"ToppleTower-v0", 6, {RED, GREEN, GREY, GREY, GREY, BLUE}, 0, 0, BPG_ERR_UNSUPPORTED},
+    // tasks.py:42-60 (curriculum=True, block_gripper=True)
+    {"BlocksTouchCurriculum-v0", 4, {GREY, GREY, GREEN, BLUE, 0, 0}, 1, 1, BPG_OK},
+    // fetch_env.py:434-441, tasks.py:62-81; curriculum=False lacks obj_range_step (:413-415)
+    {"BlocksTouchChoose-v0", 5, {GREY, GREY, GREEN, BLUE, GREY, 0}, 1, 1, BPG_ERR_ATTRIBUTE},
+    {"BlocksTouchChooseCurriculum-v0", 5, {GREY, GREY, GREEN, BLUE, GREY, 0}, 1, 1, BPG_OK},
+    // fetch_env.py:632-639 (max_num_blocks = 4, :523), tasks.py:104-124
+    {"BlocksTouchVariation-v0", 6, {GREY, GREY, GREEN, BLUE, GREY, GREY}, 1, 1, BPG_OK},
+};
+
+void fill_variant_info(int v, bpg_variant_info *o)
+{
+    const VariantDef &d = kVariants[v];
+    std::memset(o, 0, sizeof(*o));
+    o->variant = v;
+    o->num_objs = d.num_objs;
+    o->side = d.num_objs;
+    o->dimg = o->side * o->side;
+    o->is_variation = (v == BPG_BLOCKS_TOUCH_VARIATION);
+    // fetch_env.py:187-228: 10 env features + 15 per block; Variation :567-621:
+    // 1 + 10 + 4 * (15 + 4)
+    o->dimo = o->is_variation ? 87 : 10 + 15 * (d.num_objs - 2);
+    o->dimu = 4;
+    o->block_gripper = d.block_gripper;
+    o->max_episode_steps = 50;
+    o->set_test_supported = d.set_test;
+    o->increase_difficulty_status = d.incr_status;
+    o->desired_goal_is_float = o->is_variation;
+    std::snprintf(o->env_id, sizeof(o->env_id), "%s", d.id);
+    for (int i = 0; i < BPG_MAX_OBJS; i++)
+        o->obj_colors[i] = d.colors[i];
+    // _sample_goal, fetch_env.py:260-273
+    for (int i = 0; i < o->side; i++) {
+        for (int j = 0; j < o->side; j++) {
+            int ci = d.colors[i], cj = d.colors[j], g = 0;
+            if ((ci == RED && cj == BLUE) || (ci == BLUE && cj == RED))
+                g = -1;
+            else if ((ci == GREEN && cj == BLUE) || (ci == BLUE && cj == GREEN))
+                g = 1;
+            o->goal[i * o->side + j] = g;
+            uint32_t bit = 1u << host_pair_index(i, j);
+            if (g == 1) o->want_touch |= bit;
+            if (g == -1) o->want_never |= bit;
+            o->valid_pairs |= bit;
+        }
+    }
+}
+
+}  // namespace
+
+struct bpg_batch {
+    bpg_variant_info info;
+    int64_t n;
+    int device;
+    int max_steps;
+    uint64_t seed;
+    int64_t env_base;
+    uint64_t reset_counter;
+    uint32_t *now;
+    uint32_t *ever;
+    int8_t *d_id2obj;   // [BPG_MAX_MODELS][BPG_MAX_GEOMS]
+    int ngeom[BPG_MAX_MODELS];
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// device code
+// ---------------------------------------------------------------------------
+struct StepConst {
+    uint32_t valid;        // pairs of the variant's matrix
+    uint32_t want_touch;   // goal == +1 pairs
+    uint32_t want_never;   // goal == -1 pairs
+    uint32_t max_steps;    // TimeLimit
+};
+
+struct SynthConst {
+    uint32_t seed;         // folded 64 -> 32 on the host
+    uint32_t env_base;     // global id of env 0 (low 32 bits)
+    uint32_t valid_by_n[8];   // off-diagonal pairs among the first n objects
+    uint32_t forced_by_n[8];  // table-block pairs (1,k), k = 2..n-1
+};
+
+// One env step on the packed state.  fetch_env.py:154-157 demotes every 1 to 0
+// before the contacts are read (quirk Q4), so `now` is simply this step's
+// contact set and `ever` accumulates it; reward / success follow
+// fetch_env.py:141-143 and :275-281 on the two goal planes.
+__device__ __forceinline__ void step_core(uint32_t &now, uint32_t &ever, uint32_t mask,
+                                          const StepConst &c, uint32_t &rbits, uint32_t &flags)
+{
+    const uint32_t cm = mask & c.valid;
+    uint32_t elapsed = (now >> ELAPSED_SHIFT) & ELAPSED_MAX;
+    elapsed = elapsed < ELAPSED_MAX ? elapsed + 1 : ELAPSED_MAX;
+    const uint32_t ev = ever | cm;
+    const uint32_t bad = (c.want_touch & ~cm) | (c.want_never & ev);
+    const uint32_t ok = (bad == 0) ? 1u : 0u;
+    const uint32_t succ = (ev >> 31) | ok;
+    now = cm | (elapsed << ELAPSED_SHIFT);
+    ever = (ev & ~SUCC_BIT) | (succ << 31);
+    rbits = ok ? RBITS_OK : RBITS_FAIL;
+    flags = succ | ((elapsed >= c.max_steps) ? (uint32_t)BPG_FLAG_DONE : 0u);
+}
+
+// build-defined counter-based contact source (DESIGN.md "synthetic contacts"):
+// lowbias32 finaliser chained over (seed, env id, step); 5 x 21 random bits are
+// combined bit-sliced into 21 Bernoulli(5/32) bits (0.00101b, LSB first).
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t synth_key(uint32_t seed, uint32_t env_id)
+{
+    return hash32(seed ^ hash32(env_id + 0x9E3779B9U));
+}
+
+__device__ __forceinline__ uint32_t synth_mask(uint32_t key, uint32_t t, uint32_t valid, uint32_t forced)
+{
+    const uint32_t M21 = PAIR_BITS;
+    const uint32_t base = key + 0x85EBCA6BU + (4u * t) * 0x9E3779B9U;
+    const uint32_t w0 = hash32(base);
+    const uint32_t w1 = hash32(base + 0x9E3779B9U);
+    const uint32_t w2 = hash32(base + 2u * 0x9E3779B9U);
+    const uint32_t w3 = hash32(base + 3u * 0x9E3779B9U);
+    uint32_t acc = ((w0 >> 21) | ((w1 >> 21) << 11)) & M21;
+    acc &= w3;
+    acc |= (w2 & M21);
+    acc &= w1;
+    acc &= w0;
+    return (acc & valid) | forced;
+}
+
+__device__ __forceinline__ uint32_t nobj_of(uint32_t ever) { return (ever >> NOBJ_SHIFT) & 7u; }
+
+// ------------------------------ reset ---------------------------------------
+// fetch_env.py:247-255: has_succeeded = False, matrix kept (Q1);
+// Variation :646-679: matrix = -1, num_objs = 4 + num_grey.  TimeLimit: t = 0.
+__global__ void __launch_bounds__(256)
+k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, int is_variation,
+        uint32_t base_nobj, const int32_t *__restrict__ num_grey, const uint8_t *__restrict__ env_mask,
+        uint32_t seed, uint32_t env_base, uint32_t reset_counter)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (env_mask && env_mask[i] == 0) continue;
+        if (is_variation) {
+            uint32_t g;
+            if (num_grey) {
+                int32_t v = num_grey[i];
+                g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
+            } else {
+                // counter-based stand-in for np_random.randint(3), fetch_env.py:647
+                g = hash32(synth_key(seed ^ 0xA511E9B3U, env_base + (uint32_t)i) + reset_counter) % 3u;
+            }
+            now[i] = 0u;
+            ever[i] = (4u + g) << NOBJ_SHIFT;
+        } else {
+            now[i] = now[i] & PAIR_BITS;
+            ever[i] = (ever[i] & PAIR_BITS) | (base_nobj << NOBJ_SHIFT);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_init(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, uint32_t nobj)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        now[i] = 0u;                      // fetch_env.py:78 matrix all -1
+        ever[i] = nobj << NOBJ_SHIFT;     // :80 has_succeeded False
+    }
+}
+
+// ------------------------------ single step ---------------------------------
+enum { SRC_MASKS = 0, SRC_SYNTH = 1 };
+
+template <int SRC>
+__device__ __forceinline__ uint32_t fetch_mask(uint32_t m, uint32_t now, uint32_t ever, uint32_t key,
+                                               const SynthConst &s)
+{
+    if (SRC == SRC_MASKS) return m;
+    const uint32_t nobj = nobj_of(ever);
+    return synth_mask(key, (now >> ELAPSED_SHIFT) & ELAPSED_MAX, s.valid_by_n[nobj], s.forced_by_n[nobj]);
+}
+
+// 4 envs per lane: 16-byte coalesced loads/stores of now / ever / masks / reward,
+// one packed dword of 4 flag bytes.  Scalar tail for n % 4.
+template <int SRC>
+__global__ void __launch_bounds__(256)
+k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+            uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, int64_t n, StepConst c, SynthConst s)
+{
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t v = gtid; v < nvec; v += stride) {
+        uint4 a = reinterpret_cast<uint4 *>(now)[v];
+        uint4 e = reinterpret_cast<uint4 *>(ever)[v];
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if (SRC == SRC_MASKS) m = reinterpret_cast<const uint4 *>(masks)[v];
+        uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w}, mm[4] = {m.x, m.y, m.z, m.w};
+        uint32_t rb[4], fl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t key = 0;
+            if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)(4 * v + k));
+            const uint32_t mk = fetch_mask<SRC>(mm[k], an[k], ee[k], key, s);
+            step_core(an[k], ee[k], mk, c, rb[k], fl[k]);
+        }
+        reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
+        reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
+        if (reward) reinterpret_cast<uint4 *>(reward)[v] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+        if (flags)
+            reinterpret_cast<uint32_t *>(flags)[v] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+    }
+    const int64_t tail0 = nvec << 2;
+    if (gtid < n - tail0) {
+        const int64_t i = tail0 + gtid;
+        uint32_t a = now[i], e = ever[i], rb, fl;
+        uint32_t key = 0;
+        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        step_core(a, e, mk, c, rb, fl);
+        now[i] = a; ever[i] = e;
+        if (reward) reward[i] = rb;
+        if (flags) flags[i] = (uint8_t)fl;
+    }
+}
+
+// Unaligned-pointer fallback: one env per lane, 4-byte accesses.
+template <int SRC>
+__global__ void __launch_bounds__(256)
+k_step_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+              uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, int64_t n, StepConst c, SynthConst s)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t a = now[i], e = ever[i], rb, fl;
+        uint32_t key = 0;
+        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        step_core(a, e, mk, c, rb, fl);
+        now[i] = a; ever[i] = e;
+        if (reward) reward[i] = rb;
+        if (flags) flags[i] = (uint8_t)fl;
+    }
+}
+
+// Contacts as the reference reads them (fetch_env.py:158-167): per env a list
+// of geom-id pairs.  The id2obj tables live in LDS; one env per lane.
+__global__ void __launch_bounds__(256)
+k_step_contacts(uint32_t *__restrict__ now, uint32_t *__restrict__ ever,
+                const int16_t *__restrict__ contacts, const int32_t *__restrict__ ncon, int maxcon,
+                const int8_t *__restrict__ id2obj, int is_variation,
+                uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, int64_t n, StepConst c)
+{
+    __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
+    for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t a = now[i], e = ever[i], rb, fl;
+        int model = 0;
+        if (is_variation) {
+            model = (int)nobj_of(e) - 4;        // fetch_env.py:650-651
+            model = model < 0 ? 0 : (model > 2 ? 2 : model);
+        }
+        const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
+        int nc = ncon[i];
+        nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(contacts + (int64_t)i * maxcon * 2);
+        uint32_t m = 0;
+        for (int k = 0; k < nc; k++) {
+            const uint32_t pr = row[k];                  // geom1 | geom2 << 16
+            const uint32_t g1 = pr & 0xFFFFu, g2 = pr >> 16;
+            if (g1 < BPG_MAX_GEOMS && g2 < BPG_MAX_GEOMS) {
+                const int o1 = tab[g1], o2 = tab[g2];
+                if (o1 >= 0 && o2 >= 0) {                // both not None (:165)
+                    const int lo = o1 < o2 ? o1 : o2, hi = o1 < o2 ? o2 : o1;
+                    m |= 1u << (lo * BPG_MAX_OBJS - lo * (lo - 1) / 2 + (hi - lo));
+                }
+            }
+        }
+        step_core(a, e, m, c, rb, fl);
+        now[i] = a; ever[i] = e;
+        if (reward) reward[i] = rb;
+        if (flags) flags[i] = (uint8_t)fl;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint32_t *__restrict__ out,
+              SynthConst s)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t key = synth_key(s.seed, s.env_base + (uint32_t)i);
+        const uint32_t nobj = nobj_of(ever[i]);
+        const uint32_t valid = s.valid_by_n[nobj], forced = s.forced_by_n[nobj];
+        for (int t = 0; t < T; t++) {
+            uint32_t tt = (uint32_t)(t0 + t);
+            tt = tt > ELAPSED_MAX ? ELAPSED_MAX : tt;
+            out[(int64_t)t * n + i] = synth_mask(key, tt, valid, forced);
+        }
+    }
+}
+
+// ------------------------------ fused rollout -------------------------------
+// T steps in one launch, 4 envs per lane, state in registers.  Masks / rewards
+// are time-major (T, n) so every access is a 16-byte-per-lane coalesced stream.
+template <int SRC>
+__global__ void __launch_bounds__(256)
+k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+               uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
+               StepConst c, SynthConst s)
+{
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        uint4 a = reinterpret_cast<uint4 *>(now)[v];
+        uint4 e = reinterpret_cast<uint4 *>(ever)[v];
+        uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w};
+        uint32_t key[4] = {0, 0, 0, 0}, valid[4], forced[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (SRC == SRC_SYNTH) {
+                key[k] = synth_key(s.seed, s.env_base + (uint32_t)(4 * v + k));
+                valid[k] = s.valid_by_n[nobj_of(ee[k])];
+                forced[k] = s.forced_by_n[nobj_of(ee[k])];
+            }
+        }
+        const uint4 *mrow = reinterpret_cast<const uint4 *>(masks) + v;
+        uint4 *rrow = reinterpret_cast<uint4 *>(reward_tb) + v;
+        uint32_t *frow = reinterpret_cast<uint32_t *>(flags_tb) + v;
+#pragma unroll 5
+        for (int t = 0; t < T; t++) {
+            uint32_t mm[4] = {0, 0, 0, 0};
+            if (SRC == SRC_MASKS) {
+                const uint4 m = mrow[(int64_t)t * nvec];
+                mm[0] = m.x; mm[1] = m.y; mm[2] = m.z; mm[3] = m.w;
+            }
+            uint32_t rb[4], fl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (SRC == SRC_SYNTH)
+                    mm[k] = synth_mask(key[k], (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX, valid[k], forced[k]);
+                step_core(an[k], ee[k], mm[k], c, rb[k], fl[k]);
+            }
+            if (reward_tb) rrow[(int64_t)t * nvec] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+            if (flags_tb) frow[(int64_t)t * nvec] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+        }
+        reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
+        reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
+    }
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(256)
+k_rollout_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+                 uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
+                 StepConst c, SynthConst s)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t a = now[i], e = ever[i];
+        uint32_t key = 0, valid = 0, forced = 0;
+        if (SRC == SRC_SYNTH) {
+            key = synth_key(s.seed, s.env_base + (uint32_t)i);
+            valid = s.valid_by_n[nobj_of(e)];
+            forced = s.forced_by_n[nobj_of(e)];
+        }
+        for (int t = 0; t < T; t++) {
+            uint32_t m, rb, fl;
+            if (SRC == SRC_MASKS) m = masks[(int64_t)t * n + i];
+            else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
+            step_core(a, e, m, c, rb, fl);
+            if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
+            if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
+        }
+        now[i] = a; ever[i] = e;
+    }
+}
+
+// ------------------------------ float views ---------------------------------
+// flat index f of the SIDE x SIDE matrix -> pair index, packed 4 x 5 bits per
+// float4 chunk (even SIDE) or one byte per float (odd SIDE).
+struct PairTable {
+    uint32_t quad[9];     // chunk q covers flat 4q .. 4q+3
+    uint8_t flat[36];
+    float goal[36];       // desired_goal row as float32
+};
+
+__device__ __forceinline__ float tern(uint32_t now, uint32_t ever, uint32_t p)
+{
+    // achieved_goal entry: 1 touching now, 0 touched before, -1 never (fetch_env.py:129-134)
+    float v = ((ever >> p) & 1u) ? 0.0f : -1.0f;
+    return ((now >> p) & 1u) ? 1.0f : v;
+}
+
+// Writes `rows` consecutive matrices per env for the `nvalid` envs of one wave.
+// The wave's output region is contiguous, so lanes take consecutive float4
+// chunks (1 KiB per wave store); (env, row) is tracked incrementally.
+// hist[e * R + r] = (now, ever) of env e at row r, in LDS.
+template <int SIDE>
+__device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int nvalid, int rows,
+                                                    const uint2 *hist, int R, const PairTable *tab, int lane)
+{
+    constexpr int DIMG = SIDE * SIDE;
+    if (SIDE % 2 == 0) {
+        constexpr int QPR = DIMG / 4;
+        const int per_env = rows * QPR;
+        const int total = nvalid * per_env;
+        int e = 0, rem = lane;
+        while (rem >= per_env) { rem -= per_env; e++; }
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (int cidx = lane; cidx < total; cidx += 64) {
+            const int r = rem / QPR, q = rem - r * QPR;
+            const uint2 h = hist[e * R + r];
+            const uint32_t pw = tab->quad[q];
+            float4 v;
+            v.x = tern(h.x, h.y, pw & 31u);
+            v.y = tern(h.x, h.y, (pw >> 5) & 31u);
+            v.z = tern(h.x, h.y, (pw >> 10) & 31u);
+            v.w = tern(h.x, h.y, (pw >> 15) & 31u);
+            o4[cidx] = v;
+            rem += 64;
+            while (rem >= per_env) { rem -= per_env; e++; }
+        }
+    } else {
+        const int per_env = rows * DIMG;
+        const int total = nvalid * per_env;
+        int e = 0, rem = lane;
+        while (rem >= per_env) { rem -= per_env; e++; }
+        for (int f = lane; f < total; f += 64) {
+            const int r = rem / DIMG, k = rem - r * DIMG;
+            const uint2 h = hist[e * R + r];
+            out[f] = tern(h.x, h.y, tab->flat[k]);
+            rem += 64;
+            while (rem >= per_env) { rem -= per_env; e++; }
+        }
+    }
+}
+
+// obs['achieved_goal'] for the whole batch, float32 or float64; env e's matrix
+// goes to out + e * ld (ld == dimg: dense (n, dimg); ld > dimg: a row slot of a
+// batch-major episode buffer).  VEC4: 16-byte stores, needs ld % 4 == 0.
+template <int SIDE, typename OutT, bool VEC4>
+__global__ void __launch_bounds__(64)
+k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, int64_t n,
+         OutT *__restrict__ out, int64_t ld, PairTable tabv)
+{
+    constexpr int DIMG = SIDE * SIDE;
+    __shared__ uint2 hist[64];
+    __shared__ PairTable tab;
+    const int lane = threadIdx.x;
+    if (lane == 0) tab = tabv;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) hist[lane] = make_uint2(now[base + lane], ever[base + lane]);
+    __syncthreads();
+    OutT *o = out + base * ld;
+    if (VEC4) {
+        constexpr int QPR = DIMG / 4;
+        for (int cidx = lane; cidx < nvalid * QPR; cidx += 64) {
+            const int e = cidx / QPR, q = cidx - e * QPR;
+            const uint2 h = hist[e];
+            const uint32_t pw = tab.quad[q];
+            float4 v;
+            v.x = tern(h.x, h.y, pw & 31u);
+            v.y = tern(h.x, h.y, (pw >> 5) & 31u);
+            v.z = tern(h.x, h.y, (pw >> 10) & 31u);
+            v.w = tern(h.x, h.y, (pw >> 15) & 31u);
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + e * ld + 4 * q) = v;
+        }
+    } else {
+        for (int f = lane; f < nvalid * DIMG; f += 64) {
+            const int e = f / DIMG, k = f - e * DIMG;
+            const uint2 h = hist[e];
+            o[e * ld + k] = (OutT)tern(h.x, h.y, tab.flat[k]);
+        }
+    }
+}
+
+// ------------------------------ episode writer ------------------------------
+// rollout.py:100-172 for one wave = 64 consecutive envs per block.  Phase 1:
+// lane = env, T fused steps, packed (now, ever) history of every step kept in
+// LDS (row stride R odd -> conflict-free ds_write_b64).  Phase 2: the wave
+// streams its contiguous slices of episode['ag'] (B,T+1,dimg), episode['g']
+// (B,T,dimg) and episode['info_is_success'] (B,T,1) as float32.
+template <int SIDE, int SRC>
+__global__ void __launch_bounds__(64)
+k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+          uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
+          float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
+          int64_t n, int T, int R, StepConst c, SynthConst s, PairTable tabv)
+{
+    constexpr int DIMG = SIDE * SIDE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2 *hist = reinterpret_cast<uint2 *>(smem);                       // [64][R]
+    PairTable *tab = reinterpret_cast<PairTable *>(smem + (size_t)64 * R * sizeof(uint2));
+    const int lane = threadIdx.x;
+    if (lane == 0) *tab = tabv;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        const int64_t i = base + lane;
+        uint32_t a = now[i], e = ever[i];
+        uint32_t key = 0, valid = 0, forced = 0;
+        if (SRC == SRC_SYNTH) {
+            key = synth_key(s.seed, s.env_base + (uint32_t)i);
+            valid = s.valid_by_n[nobj_of(e)];
+            forced = s.forced_by_n[nobj_of(e)];
+        }
+        uint2 *my = hist + lane * R;
+        my[0] = make_uint2(a, e);                  // initial_ag (rollout.py:82-83)
+#pragma unroll 5
+        for (int t = 0; t < T; t++) {
+            uint32_t m, rb, fl;
+            if (SRC == SRC_MASKS) m = masks[(int64_t)t * n + i];
+            else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
+            step_core(a, e, m, c, rb, fl);
+            my[t + 1] = make_uint2(a, e);
+            if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
+            if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
+        }
+        now[i] = a; ever[i] = e;
+    }
+    __syncthreads();
+    if (ep_ag)
+        wave_write_matrices<SIDE>(ep_ag + base * (int64_t)(T + 1) * DIMG, nvalid, T + 1, hist, R, tab, lane);
+    if (ep_g) {
+        // episode['g']: T copies of the constant goal row per env (rollout.py:151)
+        float *o = ep_g + base * (int64_t)T * DIMG;
+        const int total = nvalid * T * DIMG;
+        if (SIDE % 2 == 0) {
+            constexpr int QPR = DIMG / 4;
+            float4 *o4 = reinterpret_cast<float4 *>(o);
+            for (int cidx = lane; cidx < total / 4; cidx += 64) {
+                const int q = cidx % QPR;
+                o4[cidx] = make_float4(tab->goal[4 * q], tab->goal[4 * q + 1], tab->goal[4 * q + 2],
+                                       tab->goal[4 * q + 3]);
+            }
+        } else {
+            for (int f = lane; f < total; f += 64) o[f] = tab->goal[f % DIMG];
+        }
+    }
+    if (ep_succ) {
+        // info['is_success'] after step t = latch in hist row t+1 (rollout.py:127-128,131)
+        float *o = ep_succ + base * (int64_t)T;
+        const int total = nvalid * T;
+        int e = 0, rem = lane;
+        while (rem >= T) { rem -= T; e++; }
+        for (int f = lane; f < total; f += 64) {
+            o[f] = (hist[e * R + rem + 1].y >> 31) ? 1.0f : 0.0f;
+            rem += 64;
+            while (rem >= T) { rem -= T; e++; }
+        }
+    }
+}
+
+// ------------------------------ compute_reward ------------------------------
+// fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
+// staged through LDS with coalesced loads (row stride padded odd).
+constexpr int CR_ROWS = 128;
+__global__ void __launch_bounds__(CR_ROWS)
+k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
+                     uint32_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *s_ag = reinterpret_cast<float *>(smem);
+    float *s_g = s_ag + CR_ROWS * ldp;
+    const int64_t row0 = (int64_t)blockIdx.x * CR_ROWS;
+    const int rows = (int)((n - row0) < CR_ROWS ? (n - row0) : CR_ROWS);
+    const int total = rows * len;
+    const float *pa = ag + row0 * len, *pg = g + row0 * len;
+    for (int f = threadIdx.x; f < total; f += CR_ROWS) {
+        const int r = f / len, k = f - r * len;
+        s_ag[r * ldp + k] = pa[f];
+        s_g[r * ldp + k] = pg[f];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+        const float *ra = s_ag + threadIdx.x * ldp, *rg = s_g + threadIdx.x * ldp;
+        float d = 0.0f;
+        int cnt = 0;
+        for (int k = 0; k < len; k++) {
+            d = __fadd_rn(d, __fmul_rn(ra[k], rg[k]));     // no fma contraction
+            cnt += (rg[k] != 0.0f) ? 1 : 0;
+        }
+        out[row0 + threadIdx.x] = (d != (float)cnt) ? RBITS_FAIL : RBITS_OK;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever,
+                        uint32_t want_touch, uint32_t want_never, int64_t n, uint32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t bad = (want_touch & ~now[i]) | (want_never & ever[i]);
+        out[i] = bad ? RBITS_FAIL : RBITS_OK;
+    }
+}
+
+// ------------------------------ success count -------------------------------
+// rollout.py:163-167: per-wave ballot + popcount, one atomic per wave.
+__global__ void __launch_bounds__(256)
+k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long *__restrict__ count)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    // every lane of a wave runs the same number of iterations (ballot needs the whole wave)
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t wave0 = i0 - (threadIdx.x & 63);
+    for (int64_t w = wave0; w < n; w += stride) {
+        const int64_t i = w + (threadIdx.x & 63);
+        const bool p = (i < n) && (ever[i] >> 31);
+        acc += (unsigned long long)__popcll(__ballot(p));
+    }
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(count, acc);
+}
+
+// ------------------------------ discounted return ---------------------------
+// policy_gradient/rollout.py:255-258.  One env per lane; G[t_] starts as r[t_]
+// and adds gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64,
+// unfused multiply/add so the rounding matches the reference's NumPy).  The
+// 64 x T tile of a wave is transposed through LDS so G (n, T) is written as
+// contiguous 8-byte-per-lane rows.
+__global__ void __launch_bounds__(64)
+k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R,
+                    const double *__restrict__ pw, double *__restrict__ G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tile = reinterpret_cast<double *>(smem);   // [64][R] : first r, then G
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        double *my = tile + lane * R;
+        for (int t = 0; t < T; t++) my[t] = (double)reward_tb[(int64_t)t * n + base + lane];
+        for (int t_ = 0; t_ < T; t_++) {
+            double acc = my[t_];
+            for (int t = t_ + 1; t < T; t++) acc = __dadd_rn(acc, __dmul_rn(pw[t - t_], my[t]));
+            my[t_] = acc;          // r[t_] is not needed by later (larger t_) rows
+        }
+    }
+    __syncthreads();
+    double *o = G + base * (int64_t)T;
+    const int total = nvalid * T;
+    int e = 0, rem = lane;
+    while (rem >= T) { rem -= T; e++; }
+    for (int f = lane; f < total; f += 64) {
+        o[f] = tile[e * R + rem];
+        rem += 64;
+        while (rem >= T) { rem -= T; e++; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_goal(float *__restrict__ out, int64_t total, int dimg, int64_t ld, PairTable tab)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += stride) {
+        const int64_t e = f / dimg;
+        const int k = (int)(f - e * dimg);
+        out[e * ld + k] = tab.goal[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------
+int grid_for(int64_t work_items, int block)
+{
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;      // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)g;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+StepConst step_const(const bpg_batch *b)
+{
+    StepConst c;
+    c.valid = b->info.valid_pairs;
+    c.want_touch = b->info.want_touch;
+    c.want_never = b->info.want_never;
+    c.max_steps = (uint32_t)b->max_steps;
+    return c;
+}
+
+SynthConst synth_const(const bpg_batch *b)
+{
+    SynthConst s;
+    s.seed = (uint32_t)(b->seed ^ (b->seed >> 32));
+    s.env_base = (uint32_t)b->env_base;
+    for (int n = 0; n < 8; n++) {
+        uint32_t valid = 0, forced = 0;
+        const int m = n > BPG_MAX_OBJS ? BPG_MAX_OBJS : n;
+        for (int i = 0; i < m; i++)
+            for (int j = i + 1; j < m; j++) valid |= 1u << host_pair_index(i, j);
+        for (int k = 2; k < m; k++) forced |= 1u << host_pair_index(1, k);
+        s.valid_by_n[n] = valid;
+        s.forced_by_n[n] = forced;
+    }
+    return s;
+}
+
+PairTable pair_table(const bpg_variant_info &info)
+{
+    PairTable t;
+    std::memset(&t, 0, sizeof(t));
+    const int side = info.side;
+    for (int f = 0; f < side * side; f++) {
+        t.flat[f] = (uint8_t)host_pair_index(f / side, f % side);
+        t.goal[f] = (float)info.goal[f];
+    }
+    for (int q = 0; q < 9; q++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) {
+            const int f = 4 * q + k;
+            if (f < side * side) w |= (uint32_t)t.flat[f] << (5 * k);
+        }
+        t.quad[q] = w;
+    }
+    return t;
+}
+
+template <typename F>
+int dispatch_side(int side, F &&f)
+{
+    switch (side) {
+    case 3: return f(std::integral_constant<int, 3>());
+    case 4: return f(std::integral_constant<int, 4>());
+    case 5: return f(std::integral_constant<int, 5>());
+    case 6: return f(std::integral_constant<int, 6>());
+    }
+    return fail(BPG_ERR_ARG, "unsupported matrix side");
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BPG_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return BPG_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *bpg_last_error(void) { return g_err.c_str(); }
+int bpg_version(void) { return 100; }
+
+int bpg_variant_from_id(const char *env_id)
+{
+    if (!env_id) return -1;
+    for (int v = 0; v < BPG_NUM_VARIANTS; v++)
+        if (std::strcmp(env_id, kVariants[v].id) == 0) return v;
+    return -1;
+}
+
+int bpg_get_variant_info(int variant, bpg_variant_info *out)
+{
+    if (variant < 0 || variant >= BPG_NUM_VARIANTS || !out) return fail(BPG_ERR_ARG, "bad variant");
+    fill_variant_info(variant, out);
+    return BPG_OK;
+}
+
+int bpg_geom2objid(const char *name)
+{
+    // fetch_env.py:106-117
+    if (name) {
+        if (std::strstr(name, "finger")) return 0;
+        if (std::strcmp(name, "table") == 0) return 1;
+        if (std::strstr(name, "object")) {
+            const char *p = name + (std::strlen(name) < 6 ? std::strlen(name) : 6);
+            return std::atoi(p) + 2;
+        }
+    }
+    return -1;
+}
+
+int bpg_pair_index(int i, int j)
+{
+    if (i < 0 || j < 0 || i >= BPG_MAX_OBJS || j >= BPG_MAX_OBJS) return -1;
+    return host_pair_index(i, j);
+}
+
+int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int max_episode_steps,
+               uint64_t seed, int64_t env_id_base)
+{
+    if (!out) return fail(BPG_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (variant < 0 || variant >= BPG_NUM_VARIANTS) return fail(BPG_ERR_ARG, "unknown variant");
+    if (n_envs < 1) return fail(BPG_ERR_ARG, "n_envs must be >= 1");
+    if (max_episode_steps < 1 || max_episode_steps > (int)ELAPSED_MAX)
+        return fail(BPG_ERR_ARG, "max_episode_steps must be in 1..1023");
+    DeviceGuard guard(device_id);
+    if (guard.err != hipSuccess)
+        return fail(BPG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    bpg_batch *b = new (std::nothrow) bpg_batch();
+    if (!b) return fail(BPG_ERR_ARG, "out of host memory");
+    fill_variant_info(variant, &b->info);
+    b->n = n_envs;
+    b->device = device_id;
+    b->max_steps = max_episode_steps;
+    b->info.max_episode_steps = max_episode_steps;
+    b->seed = seed;
+    b->env_base = env_id_base;
+    b->reset_counter = 0;
+    b->now = b->ever = nullptr;
+    b->d_id2obj = nullptr;
+    std::memset(b->ngeom, 0, sizeof(b->ngeom));
+    const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
+    hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
+    hipError_t e3 = hipMalloc(&b->d_id2obj, BPG_MAX_MODELS * BPG_MAX_GEOMS);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        bpg_destroy(b);
+        return fail(BPG_ERR_HIP, "hipMalloc failed for the packed state");
+    }
+    hipError_t e4 = hipMemset(b->d_id2obj, 0xFF, BPG_MAX_MODELS * BPG_MAX_GEOMS);
+    hipLaunchKernelGGL(k_init, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, b->now, b->ever, n_envs,
+                       (uint32_t)b->info.num_objs);
+    hipError_t e5 = hipDeviceSynchronize();
+    if (e4 != hipSuccess || e5 != hipSuccess) {
+        bpg_destroy(b);
+        return fail(BPG_ERR_HIP, "state initialisation failed");
+    }
+    *out = b;
+    return BPG_OK;
+}
+
+int bpg_destroy(bpg_batch *b)
+{
+    if (!b) return BPG_OK;
+    DeviceGuard guard(b->device);
+    if (b->now) (void)hipFree(b->now);
+    if (b->ever) (void)hipFree(b->ever);
+    if (b->d_id2obj) (void)hipFree(b->d_id2obj);
+    delete b;
+    return BPG_OK;
+}
+
+int64_t bpg_num_envs(const bpg_batch *b) { return b ? b->n : 0; }
+
+int bpg_seed(bpg_batch *b, uint64_t seed)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    b->seed = seed;
+    b->reset_counter = 0;
+    return BPG_OK;
+}
+
+int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
+{
+    if (!b || !id2obj) return fail(BPG_ERR_ARG, "NULL argument");
+    if (model_idx < 0 || model_idx >= BPG_MAX_MODELS) return fail(BPG_ERR_ARG, "model_idx out of range");
+    if (ngeom < 1 || ngeom > BPG_MAX_GEOMS) return fail(BPG_ERR_ARG, "ngeom must be in 1..64");
+    int8_t tab[BPG_MAX_GEOMS];
+    std::memset(tab, 0xFF, sizeof(tab));
+    for (int i = 0; i < ngeom; i++) {
+        if (id2obj[i] >= b->info.num_objs) return fail(BPG_ERR_ARG, "object id >= num_objs in id2obj");
+        tab[i] = id2obj[i] < 0 ? (int8_t)-1 : id2obj[i];
+    }
+    DeviceGuard guard(b->device);
+    HIP_TRY(hipMemcpy(b->d_id2obj + model_idx * BPG_MAX_GEOMS, tab, BPG_MAX_GEOMS, hipMemcpyHostToDevice));
+    b->ngeom[model_idx] = ngeom;
+    return BPG_OK;
+}
+
+int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    DeviceGuard guard(b->device);
+    const SynthConst s = synth_const(b);
+    hipLaunchKernelGGL(k_reset, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now, b->ever,
+                       b->n, b->info.is_variation, (uint32_t)b->info.num_objs, d_num_grey, d_env_mask, s.seed,
+                       s.env_base, (uint32_t)b->reset_counter);
+    b->reset_counter++;
+    return check_launch("k_reset");
+}
+
+static int launch_step(bpg_batch *b, int src, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
+                       void *stream)
+{
+    DeviceGuard guard(b->device);
+    const StepConst c = step_const(b);
+    const SynthConst s = synth_const(b);
+    uint32_t *rw = reinterpret_cast<uint32_t *>(d_reward);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = aligned16(d_masks) && aligned16(d_reward) && aligned4(d_flags);
+    if (vec) {
+        const dim3 grid(grid_for((b->n + 3) / 4, 256)), block(256);
+        if (src == SRC_MASKS)
+            hipLaunchKernelGGL(k_step_vec4<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags,
+                               b->n, c, s);
+        else
+            hipLaunchKernelGGL(k_step_vec4<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags,
+                               b->n, c, s);
+    } else {
+        const dim3 grid(grid_for(b->n, 256)), block(256);
+        if (src == SRC_MASKS)
+            hipLaunchKernelGGL(k_step_scalar<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, d_masks, rw,
+                               d_flags, b->n, c, s);
+        else
+            hipLaunchKernelGGL(k_step_scalar<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, d_masks, rw,
+                               d_flags, b->n, c, s);
+    }
+    return check_launch("k_step");
+}
+
+int bpg_step_masks(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, void *stream)
+{
+    if (!b || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
+    if (!aligned4(d_masks) || !aligned4(d_reward)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    return launch_step(b, SRC_MASKS, d_masks, d_reward, d_flags, stream);
+}
+
+int bpg_step_synth(bpg_batch *b, float *d_reward, uint8_t *d_flags, void *stream)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (!aligned4(d_reward)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    return launch_step(b, SRC_SYNTH, nullptr, d_reward, d_flags, stream);
+}
+
+int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
+                      float *d_reward, uint8_t *d_flags, void *stream)
+{
+    if (!b || !d_contacts || !d_ncon) return fail(BPG_ERR_ARG, "NULL argument");
+    if (maxcon < 1 || maxcon > 4096) return fail(BPG_ERR_ARG, "maxcon must be in 1..4096");
+    if (!aligned4(d_contacts) || !aligned4(d_reward)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
+    for (int m = 0; m < models; m++)
+        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_step_contacts, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now,
+                       b->ever, d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
+                       reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
+    return check_launch("k_step_contacts");
+}
+
+int bpg_synth_masks(bpg_batch *b, int t0, int T, uint32_t *d_masks, void *stream)
+{
+    if (!b || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
+    if (t0 < 0 || T < 1) return fail(BPG_ERR_ARG, "bad t0/T");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_synth_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever, b->n,
+                       t0, T, d_masks, synth_const(b));
+    return check_launch("k_synth_masks");
+}
+
+int bpg_get_achieved_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream)
+{
+    if (!b || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
+    if (!aligned4(d_out)) return fail(BPG_ERR_ARG, "d_out must be 4-byte aligned");
+    DeviceGuard guard(b->device);
+    const PairTable tab = pair_table(b->info);
+    const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+    const bool vec = (b->info.side % 2 == 0) && (ld % 4 == 0) && aligned16(d_out);
+    int rc = dispatch_side(b->info.side, [&](auto side) {
+        constexpr int S = decltype(side)::value;
+        if (vec)
+            hipLaunchKernelGGL((k_get_ag<S, float, (S % 2 == 0)>), grid, block, 0, (hipStream_t)stream, b->now,
+                               b->ever, b->n, d_out, ld, tab);
+        else
+            hipLaunchKernelGGL((k_get_ag<S, float, false>), grid, block, 0, (hipStream_t)stream, b->now, b->ever,
+                               b->n, d_out, ld, tab);
+        return BPG_OK;
+    });
+    return rc != BPG_OK ? rc : check_launch("k_get_ag");
+}
+
+int bpg_get_achieved_goal_f64(bpg_batch *b, double *d_out, int64_t ld, void *stream)
+{
+    if (!b || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
+    DeviceGuard guard(b->device);
+    const PairTable tab = pair_table(b->info);
+    const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+    int rc = dispatch_side(b->info.side, [&](auto side) {
+        hipLaunchKernelGGL((k_get_ag<decltype(side)::value, double, false>), grid, block, 0, (hipStream_t)stream,
+                           b->now, b->ever, b->n, d_out, ld, tab);
+        return BPG_OK;
+    });
+    return rc != BPG_OK ? rc : check_launch("k_get_ag");
+}
+
+int bpg_get_desired_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream)
+{
+    if (!b || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
+    DeviceGuard guard(b->device);
+    const int64_t total = b->n * b->info.dimg;
+    hipLaunchKernelGGL(k_fill_goal, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, d_out, total,
+                       b->info.dimg, ld, pair_table(b->info));
+    return check_launch("k_fill_goal");
+}
+
+int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (d_now) *d_now = b->now;
+    if (d_ever) *d_ever = b->ever;
+    return BPG_OK;
+}
+
+int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len, float *d_out, int device_id,
+                           void *stream)
+{
+    if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
+    if (n == 0) return BPG_OK;
+    DeviceGuard guard(device_id);
+    const int ldp = len | 1;
+    const size_t lds = (size_t)2 * CR_ROWS * ldp * sizeof(float);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_compute_reward_f32),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_compute_reward_f32, dim3((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), dim3(CR_ROWS), lds,
+                       (hipStream_t)stream, d_ag, d_g, n, len, ldp, reinterpret_cast<uint32_t *>(d_out));
+    return check_launch("k_compute_reward_f32");
+}
+
+int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever, uint32_t want_touch,
+                              uint32_t want_never, int64_t n, float *d_out, int device_id, void *stream)
+{
+    if (!d_now || !d_ever || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n <= 0) return n == 0 ? BPG_OK : fail(BPG_ERR_ARG, "n < 0");
+    DeviceGuard guard(device_id);
+    hipLaunchKernelGGL(k_compute_reward_packed, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_now,
+                       d_ever, want_touch & PAIR_BITS, want_never & PAIR_BITS, n,
+                       reinterpret_cast<uint32_t *>(d_out));
+    return check_launch("k_compute_reward_packed");
+}
+
+int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
+{
+    if (!b || !a) return fail(BPG_ERR_ARG, "NULL argument");
+    if (a->T < 1 || a->T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
+    DeviceGuard guard(b->device);
+    const StepConst c = step_const(b);
+    const SynthConst s = synth_const(b);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *rw = reinterpret_cast<uint32_t *>(a->d_reward_tb);
+    const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
+    if (!episode) {
+        const bool vec = (b->n % 4 == 0) && aligned16(a->d_masks) && aligned16(a->d_reward_tb) &&
+                         aligned4(a->d_flags_tb);
+        if (vec) {
+            const dim3 grid(grid_for(b->n / 4, 256)), block(256);
+            if (a->d_masks)
+                hipLaunchKernelGGL(k_rollout_vec4<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
+                                   a->d_flags_tb, b->n, a->T, c, s);
+            else
+                hipLaunchKernelGGL(k_rollout_vec4<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
+                                   a->d_flags_tb, b->n, a->T, c, s);
+        } else {
+            const dim3 grid(grid_for(b->n, 256)), block(256);
+            if (a->d_masks)
+                hipLaunchKernelGGL(k_rollout_scalar<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
+                                   a->d_flags_tb, b->n, a->T, c, s);
+            else
+                hipLaunchKernelGGL(k_rollout_scalar<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks,
+                                   rw, a->d_flags_tb, b->n, a->T, c, s);
+        }
+        return check_launch("k_rollout");
+    }
+    if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
+        (a->d_ep_success && !aligned4(a->d_ep_success)))
+        return fail(BPG_ERR_ARG, "episode buffers must be 16-byte aligned");
+    const int R = (a->T + 1) | 1;
+    const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
+    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS history tile");
+    const PairTable tab = pair_table(b->info);
+    const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+    const bool synth = (a->d_masks == nullptr);
+    int rc = dispatch_side(b->info.side, [&](auto side) {
+        constexpr int S = decltype(side)::value;
+        const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH>)
+                               : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS>);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        }
+        if (synth)
+            hipLaunchKernelGGL((k_episode<S, SRC_SYNTH>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                               a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab);
+        else
+            hipLaunchKernelGGL((k_episode<S, SRC_MASKS>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                               a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab);
+        return BPG_OK;
+    });
+    return rc != BPG_OK ? rc : check_launch("k_episode");
+}
+
+int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream)
+{
+    if (!b || !d_count) return fail(BPG_ERR_ARG, "NULL argument");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_success_count, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
+                       b->n, d_count);
+    return check_launch("k_success_count");
+}
+
+int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma, double *d_G, int device_id,
+                          void *stream)
+{
+    if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 1 || T < 1 || T > 1024) return fail(BPG_ERR_ARG, "bad n/T");
+    DeviceGuard guard(device_id);
+    // gamma ** k exactly as the reference's Python float pow (C pow)
+    std::vector<double> pw((size_t)T);
+    for (int k = 0; k < T; k++) pw[(size_t)k] = std::pow(gamma, (double)k);
+    double *d_pw = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_pw), sizeof(double) * (size_t)T, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(d_pw, pw.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // pw is a stack-lifetime host buffer
+    const int R = T | 1;
+    const size_t lds = (size_t)64 * R * sizeof(double);
+    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS tile");
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_discounted_return, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
+                       d_reward_tb, n, T, R, d_pw, d_G);
+    int rc = check_launch("k_discounted_return");
+    HIP_TRY(hipFreeAsync(d_pw, (hipStream_t)stream));
+    return rc;
+}
+
+}  // extern "C"

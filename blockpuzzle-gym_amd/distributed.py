@@ -1,0 +1,86 @@
+"""Multi-GPU sharding of the env batch: one process per GPU, no data-path
+collective.  Envs are independent (reference: separate objects rollout.py:33,
+separate MPI ranks train.py:113-119), so the global env index range is split
+into contiguous shards and each rank keeps its shard resident in its own HBM.
+The only exchange is one collective per rollout for the aggregated statistics,
+mirroring `success_rate = mean(successes[-1])` (rollout.py:163-167) and
+`mpi_average` (train.py:21-26): RCCL (`nccl` backend) over xGMI on GPUs, `gloo`
+on CPU for the tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs, rank, world_size):
+    """Contiguous [start, stop) of global env indices owned by `rank`; the first
+    `total % world` ranks get one extra env."""
+    if not (0 <= rank < world_size):
+        raise ValueError('rank out of range')
+    base, extra = divmod(int(total_envs), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (the
+    torchrun contract).  Returns (rank, world_size, local_rank); single-process
+    runs return (0, 1, 0) without creating a process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def make_sharded(env_id, total_envs, rank, world_size, device=None, seed=0, **kw):
+    """This rank's shard of a `total_envs`-env job.  The synthetic generator is
+    keyed by the GLOBAL env index (env_id_base), so results do not depend on
+    how the batch is sharded (mirrors seed + 1000*idx, rollout.py:209-210)."""
+    from .registration import make
+    start, stop = shard_range(total_envs, rank, world_size)
+    return make(env_id, num_envs=stop - start, device=device, seed=seed, env_id_base=start, **kw)
+
+
+def global_success_rate(local_success_count, local_num_envs):
+    """One all-reduce of (successes, envs) per rollout -> global success rate."""
+    t = torch.stack([torch.as_tensor(local_success_count).reshape(()).to(torch.float64),
+                     torch.as_tensor(float(local_num_envs), dtype=torch.float64,
+                                     device=torch.as_tensor(local_success_count).device)])
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0].item() / t[1].item())
+
+
+def all_gather_per_env(local_values, shard_sizes=None):
+    """All-gather of a per-env statistic (final is_success / episode return) into
+    global env order: one collective per rollout (4 B/env; 2 MB per GPU at
+    4 194 304 envs over 8 GPUs).  Ragged shards are padded to the largest."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return local_values
+    world = dist.get_world_size()
+    n_local = local_values.shape[0]
+    if shard_sizes is None:
+        sizes = torch.zeros(world, dtype=torch.int64, device=local_values.device)
+        sizes[dist.get_rank()] = n_local
+        dist.all_reduce(sizes)
+        shard_sizes = [int(s) for s in sizes.tolist()]
+    m = max(shard_sizes)
+    pad = torch.zeros((m,) + tuple(local_values.shape[1:]), dtype=local_values.dtype,
+                      device=local_values.device)
+    pad[:n_local] = local_values
+    out = torch.empty((world * m,) + tuple(local_values.shape[1:]), dtype=local_values.dtype,
+                      device=local_values.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m:r * m + shard_sizes[r]] for r in range(world)])

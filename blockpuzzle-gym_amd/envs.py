@@ -1,0 +1,448 @@
+"""Batched, GPU-resident mirror of the reference env surface.
+
+Mirrors (paths relative to the reference root):
+  gym_blocks/envs/robot_env.py  RobotEnv.step/reset/seed, action/observation spaces
+  gym_blocks/envs/fetch_env.py  BlocksEnv + the five variants: compute_reward,
+                                set_test, increase_difficulty, get_difficulty
+  gym TimeLimit                 `_max_episode_steps`, done after 50 steps
+                                (gym_blocks/__init__.py registers every id with 50)
+
+One `BatchedBlocksEnv` replaces the reference's `[make_env() for _ in range(B)]`
+(rollout.py:33): all B envs live packed in HBM behind one C-ABI handle and are
+stepped by one HIP kernel launch.
+
+Boundary: contacts-in.  MuJoCo (robot_env.py:60) is a closed third-party binary
+outside the reference tree; each step consumes the step's contact set, either
+  * packed pair masks           step(u, contact_masks=uint32[B])
+  * geom-id pair lists          step(u, contacts=(int16[B,maxcon,2], int32[B]))
+    (what fetch_env.py:158-167 reads from sim.data.contact), or
+  * the env's `contact_source`  (default: the build-defined synthetic source).
+`observation` has no physics behind it: it is zero except for the entries the
+reference fills without physics (Variation: obs[0] = num_blocks and the colour
+one-hots, fetch_env.py:579-600), unless the caller writes `env.observation`.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+ENV_FEATURES = 10          # actor_critic.py:4-7 / fetch_env.py:222
+BLOCK_BASE_FEATURES = 15
+COLOR_FEATURES = 4
+BLOCK_FEATURES = BLOCK_BASE_FEATURES + COLOR_FEATURES
+
+# scene file of each variant (tasks.py) -> default geom name list (assets/fetch_geoms.json)
+_MODEL_XML = {
+    'GripperTouch-v0': ['fetch/1block.xml'],
+    'BlocksTouch-v0': ['fetch/2blocks.xml'],
+    'BlocksTouchCurriculum-v0': ['fetch/2blocks.xml'],
+    'BlocksTouchChoose-v0': ['fetch/3blocks.xml'],
+    'BlocksTouchChooseCurriculum-v0': ['fetch/3blocks.xml'],
+    'ToppleTower-v0': ['fetch/4blocks.xml'],
+    # fetch_env.py:528-530: Variation builds one sim per block count
+    'BlocksTouchVariation-v0': ['fetch/2blocks.xml', 'fetch/3blocks.xml', 'fetch/4blocks.xml'],
+}
+
+
+def default_geom_names(env_id):
+    with open(os.path.join(_HERE, 'assets', 'fetch_geoms.json')) as f:
+        models = json.load(f)['models']
+    return [models[x] for x in _MODEL_XML[env_id]]
+
+
+def geom2objid(name):
+    """BlocksEnv._geom2objid (fetch_env.py:106-117); None for unmapped geoms."""
+    r = _lib.lib().bpg_geom2objid(None if name is None else name.encode())
+    return None if r < 0 else r
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency)."""
+
+    def __init__(self, low, high, shape, dtype='float32'):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.low = np.full(self.shape, low, dtype=self.dtype)
+        self.high = np.full(self.shape, high, dtype=self.dtype)
+        self._rng = np.random.RandomState()
+
+    def seed(self, seed=None):
+        self._rng = np.random.RandomState(seed)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return self._rng.uniform(lo, hi).astype(self.dtype)
+
+
+class DictSpace:
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+
+
+class _Spec:
+    def __init__(self, env_id, max_episode_steps):
+        self.id = env_id
+        self.max_episode_steps = max_episode_steps
+
+
+class _DevicePtr:
+    """Zero-copy torch view of a raw device pointer (CUDA array interface)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False),
+                                             version=3, strides=None)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class SyntheticContacts:
+    """Build-defined physics stand-in (no reference counterpart): contacts are a
+    counter-based pseudo-random function of (seed, global env id, step) evaluated
+    inside the step kernel; table-block pairs always touch, every other pair is
+    Bernoulli(5/32).  See DESIGN.md."""
+    kind = 'synthetic'
+
+    def next(self, env, actions):
+        return None
+
+
+class ScriptedContacts:
+    """Replays pre-recorded contacts: `masks` (T, B) uint32, or
+    `pairs` (T, B, maxcon, 2) int16 with `ncon` (T, B) int32."""
+
+    def __init__(self, masks=None, pairs=None, ncon=None):
+        self.masks, self.pairs, self.ncon = masks, pairs, ncon
+        self.t = 0
+
+    def next(self, env, actions):
+        t = self.t
+        self.t += 1
+        if self.masks is not None:
+            return ('masks', self.masks[t])
+        return ('pairs', self.pairs[t], self.ncon[t])
+
+
+class CallableContacts:
+    """Wraps a user physics backend: fn(env, clipped_actions) -> uint32 masks (B,)
+    or (int16 pairs (B,maxcon,2), int32 ncon (B,))."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def next(self, env, actions):
+        out = self.fn(env, actions)
+        if isinstance(out, (tuple, list)):
+            return ('pairs', out[0], out[1])
+        return ('masks', out)
+
+
+class BatchedBlocksEnv:
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 25}
+    reward_range = (-float('inf'), float('inf'))
+
+    def __init__(self, env_id, num_envs=1, device=None, seed=None, max_episode_steps=None,
+                 contact_source=None, env_id_base=0, scalar_api=False, reward_type='sparse'):
+        L = _lib.lib()
+        variant = L.bpg_variant_from_id(env_id.encode())
+        if variant < 0:
+            raise KeyError('No registered env with id: %s' % env_id)
+        if not torch.cuda.is_available():
+            raise RuntimeError('blockpuzzle-gym_amd needs a ROCm GPU; there is no CPU fallback')
+        self.env_id = env_id
+        self.info = _lib.variant_info(variant)
+        self.variant = variant
+        self.num_envs = int(num_envs)
+        self.scalar_api = bool(scalar_api)
+        if self.scalar_api and self.num_envs != 1:
+            raise ValueError('scalar_api needs num_envs == 1')
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.reward_type = reward_type
+        self._max_episode_steps = int(max_episode_steps or self.info.max_episode_steps)
+        self.spec = _Spec(env_id, self._max_episode_steps)
+        self.env_id_base = int(env_id_base)
+        self._seed_value = 0 if seed is None else int(seed)
+        h = C.c_void_p()
+        _lib.check(L.bpg_create(C.byref(h), variant, self.num_envs, self.device.index,
+                                self._max_episode_steps, C.c_uint64(self._seed_value & (2**64 - 1)),
+                                self.env_id_base))
+        self._h = h
+        self._L = L
+        # fetch_env.py:64-86 constructor state
+        i = self.info
+        self.num_objs = i.num_objs
+        self.side = i.side
+        self.dimg, self.dimo, self.dimu = i.dimg, i.dimo, i.dimu
+        self.block_gripper = bool(i.block_gripper)
+        self.obj_colors = list(i.obj_colors[:i.num_objs])
+        g = np.array(i.goal[:i.dimg], dtype=np.float64 if i.desired_goal_is_float else np.int64)
+        self.goal = g
+        self.difficulty = 0
+        self.obj_range = 0.15                      # tasks.py: every preset passes obj_range=0.15
+        self._init_curriculum()
+        self.contact_source = contact_source if contact_source is not None else SyntheticContacts()
+        B, dev = self.num_envs, self.device
+        self._reward = torch.empty(B, dtype=torch.float32, device=dev)
+        self._flags = torch.empty(B, dtype=torch.uint8, device=dev)
+        self._ag = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
+        self._g = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
+        self.observation = torch.zeros(B, self.dimo, dtype=torch.float32, device=dev)
+        _lib.check(L.bpg_get_desired_goal_f32(self._h, _ptr(self._g), self.dimg, _stream(dev)))
+        now, ever = C.c_void_p(), C.c_void_p()
+        _lib.check(L.bpg_state_ptrs(self._h, C.byref(now), C.byref(ever)))
+        self.state_now = torch.as_tensor(_DevicePtr(now.value, B, '<i4'), device=dev)
+        self.state_ever = torch.as_tensor(_DevicePtr(ever.value, B, '<i4'), device=dev)
+        self.set_geom_names(default_geom_names(env_id))
+        # robot_env.py:38-44
+        self.action_space = Box(-1., 1., shape=(self.dimu,), dtype='float32')
+        self.observation_space = DictSpace(dict(
+            desired_goal=Box(-np.inf, np.inf, shape=(self.dimg,), dtype='float32'),
+            achieved_goal=Box(-np.inf, np.inf, shape=(self.dimg,), dtype='float32'),
+            observation=Box(-np.inf, np.inf, shape=(self.dimo,), dtype='float32')))
+        self._fill_static_observation()
+
+    # ------------------------------------------------------------------ misc
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                self._L.bpg_destroy(h)
+            except Exception:
+                pass
+
+    close = __del__
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def render(self, mode='human'):
+        raise NotImplementedError('rendering needs the MuJoCo viewer (robot_env.py:89-105): out of scope')
+
+    def with_num_envs(self, num_envs, **kw):
+        """A fresh env of the same id/config with another batch size."""
+        args = dict(device=self.device, seed=self._seed_value, max_episode_steps=self._max_episode_steps,
+                    env_id_base=self.env_id_base, contact_source=self.contact_source)
+        args.update(kw)
+        return BatchedBlocksEnv(self.env_id, num_envs=num_envs, **args)
+
+    def _init_curriculum(self):
+        # fetch_env.py:340-348 (BlocksTouch), :404-417 (Choose), :561-563 (Variation)
+        v = self.env_id
+        if v in ('BlocksTouch-v0', 'BlocksTouchCurriculum-v0'):
+            if v == 'BlocksTouchCurriculum-v0':
+                self.obj_range, self.obj_range_step, self.max_obj_range = 0.08, 0.025, 0.2
+            else:
+                self.max_obj_range, self.obj_range_step = self.obj_range, 0
+        elif v in ('BlocksTouchChoose-v0', 'BlocksTouchChooseCurriculum-v0'):
+            if v == 'BlocksTouchChooseCurriculum-v0':
+                self.obj_range, self.obj_range_step = 0.08, 0.025
+                self.wrong_obj_range, self.wrong_obj_range_step = 0.2, 0.02
+                self.max_obj_range = 0.3
+            else:
+                self.wrong_obj_range, self.max_obj_range = 0, 0.2
+            self.challenge = False
+        elif v == 'BlocksTouchVariation-v0':
+            self.max_num_blocks = 4
+            self.obj_range, self.obj_range_step, self.max_obj_range = 0.08, 0.025, 0.2
+
+    # ----------------------------------------------------- curriculum surface
+    def get_difficulty(self):
+        return self.difficulty                     # fetch_env.py:96-97
+
+    def increase_difficulty(self):
+        v = self.env_id
+        if v in ('GripperTouch-v0', 'ToppleTower-v0'):
+            raise NotImplementedError()             # fetch_env.py:93-94
+        if v in ('BlocksTouchChoose-v0', 'BlocksTouchChooseCurriculum-v0'):
+            # fetch_env.py:419-432; the non-curriculum preset lacks *_step (quirk Q6)
+            self.obj_range += self.obj_range_step
+            self.wrong_obj_range -= self.wrong_obj_range_step
+            if self.obj_range > self.max_obj_range:
+                self.obj_range = self.max_obj_range
+                if self.wrong_obj_range < 0:
+                    self.wrong_obj_range = 0
+                    return True
+            else:
+                if self.wrong_obj_range < 0:
+                    self.wrong_obj_range = 0
+            self.difficulty += 1
+            return False
+        # fetch_env.py:351-358 (BlocksTouch) / :623-630 (Variation)
+        self.obj_range += self.obj_range_step
+        if self.obj_range > self.max_obj_range:
+            self.obj_range = self.max_obj_range
+            return True
+        self.difficulty += 1
+        return False
+
+    def set_test(self):
+        if not self.info.set_test_supported:
+            raise NotImplementedError()             # fetch_env.py:100-101
+        # fetch_env.py:365-368 / :443-446 re-randomise the cubes at max range (physics side,
+        # outside the boundary) and return _get_obs(); Variation :641-644 only returns it.
+        return self._get_obs()
+
+    # ------------------------------------------------------------ id2obj
+    def set_geom_names(self, models):
+        """models: one geom-name list per scene (3 for Variation).  Builds the
+        id2obj tables exactly as fetch_env.py:284 / :651 do."""
+        if models and (models[0] is None or isinstance(models[0], str)):
+            models = [models]
+        self.id2obj = []
+        for k, names in enumerate(models):
+            ids = [geom2objid(n) for n in names]
+            self.id2obj.append(ids)
+            arr = np.array([-1 if v is None else v for v in ids], dtype=np.int8)
+            _lib.check(self._L.bpg_set_id2obj(self._h, k, arr.ctypes.data_as(C.POINTER(C.c_int8)), len(arr)))
+
+    # ------------------------------------------------------------ gym API
+    def seed(self, seed=None):
+        """robot_env.py:53-55 (returns [seed]); re-keys the counter-based generator."""
+        self._seed_value = 0 if seed is None else int(seed)
+        _lib.check(self._L.bpg_seed(self._h, C.c_uint64(self._seed_value & (2**64 - 1))))
+        self.action_space.seed(seed)
+        return [seed]
+
+    def _to_dev(self, x, dtype):
+        if x is None:
+            return None
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.ascontiguousarray(x))
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+    def reset(self, num_grey=None, env_mask=None):
+        """robot_env.py:71-82.  num_grey: optional explicit (B,) draws for Variation's
+        np_random.randint(3) (fetch_env.py:647); env_mask: optional (B,) partial reset."""
+        ng = self._to_dev(num_grey, torch.int32)
+        em = self._to_dev(env_mask, torch.uint8)
+        _lib.check(self._L.bpg_reset(self._h, _ptr(ng), _ptr(em), _stream(self.device)))
+        if self.info.is_variation:
+            self._fill_static_observation()
+        return self._get_obs()
+
+    def step(self, action, contact_masks=None, contacts=None):
+        """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info)."""
+        a = self._to_dev(action, torch.float32)
+        if a is not None:
+            a = a.reshape(self.num_envs, self.dimu)
+            a = torch.clamp(a, -1.0, 1.0)            # robot_env.py:58
+        self.last_action = a
+        if contact_masks is None and contacts is None:
+            nxt = self.contact_source.next(self, a)
+            if nxt is not None:
+                if nxt[0] == 'masks':
+                    contact_masks = nxt[1]
+                else:
+                    contacts = (nxt[1], nxt[2])
+        st = _stream(self.device)
+        if contact_masks is not None:
+            m = self._to_dev(contact_masks, torch.int32) if not (
+                torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
+            ) else contact_masks.to(self.device).contiguous()
+            assert m.numel() == self.num_envs
+            _lib.check(self._L.bpg_step_masks(self._h, _ptr(m), _ptr(self._reward), _ptr(self._flags), st))
+        elif contacts is not None:
+            pairs = self._to_dev(contacts[0], torch.int16)
+            ncon = self._to_dev(contacts[1], torch.int32)
+            assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
+            _lib.check(self._L.bpg_step_contacts(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]),
+                                                 _ptr(self._reward), _ptr(self._flags), st))
+        else:
+            _lib.check(self._L.bpg_step_synth(self._h, _ptr(self._reward), _ptr(self._flags), st))
+        obs = self._get_obs()
+        done = (self._flags & _lib.FLAG_DONE) != 0
+        succ = (self._flags & _lib.FLAG_SUCCESS) != 0
+        if self.scalar_api:
+            return obs, np.float32(self._reward[0].item()), bool(done[0].item()), {'is_success': bool(succ[0].item())}
+        return obs, self._reward, done, {'is_success': succ}
+
+    def _get_obs(self):
+        """fetch_env.py:219-228 (achieved_goal / desired_goal parts)."""
+        _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(self._ag), self.dimg, _stream(self.device)))
+        if self.scalar_api:
+            # reference dtypes (quirk Q9): float64 obs/ag, int64 goal (Variation float64)
+            return {'observation': self.observation[0].double().cpu().numpy(),
+                    'achieved_goal': self._ag[0].double().cpu().numpy(),
+                    'desired_goal': self.goal.copy()}
+        return {'observation': self.observation, 'achieved_goal': self._ag, 'desired_goal': self._g}
+
+    def achieved_goal_f64(self):
+        out = torch.empty(self.num_envs, self.dimg, dtype=torch.float64, device=self.device)
+        _lib.check(self._L.bpg_get_achieved_goal_f64(self._h, _ptr(out), self.dimg, _stream(self.device)))
+        return out
+
+    def _fill_static_observation(self):
+        """The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607):
+        obs[0] = num_blocks, colour one-hot of every present block, zero padding."""
+        if not self.info.is_variation:
+            return
+        nobj = (self.state_ever >> 21) & 7
+        nblocks = (nobj - 2).to(torch.float32)
+        self.observation[:, 0] = nblocks
+        for i in range(self.max_num_blocks):
+            off = 1 + ENV_FEATURES + BLOCK_FEATURES * i
+            present = (nobj - 2 > i).to(torch.float32)
+            self.observation[:, off:off + BLOCK_FEATURES] *= present[:, None]
+            onehot = torch.zeros(COLOR_FEATURES, device=self.device)
+            onehot[self.info.obj_colors[i + 2]] = 1.0
+            self.observation[:, off + BLOCK_BASE_FEATURES:off + BLOCK_FEATURES] = onehot[None, :] * present[:, None]
+
+    def num_objs_per_env(self):
+        return (self.state_ever >> 21) & 7
+
+    # ------------------------------------------------------------ reward
+    def compute_reward(self, achieved_goal, goal=None, info=None, desired_goal=None):
+        """fetch_env.py:135-143, vectorised over leading axes; accepts the `goal`
+        (definition) and `desired_goal` (config.py:110-111 call site) spellings."""
+        if goal is None:
+            goal = desired_goal
+        return compute_reward(achieved_goal, goal, device=self.device)
+
+    def success_count(self):
+        """Number of envs whose has_succeeded latch is set (rollout.py:163-167)."""
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.check(self._L.bpg_success_count(self._h, _ptr(cnt), _stream(self.device)))
+        return cnt
+
+    # ------------------------------------------------------------ state I/O
+    def state_dict(self):
+        return {'now': self.state_now.clone(), 'ever': self.state_ever.clone()}
+
+    def load_state_dict(self, sd):
+        self.state_now.copy_(sd['now'])
+        self.state_ever.copy_(sd['ever'])
+
+
+def compute_reward(achieved_goal, goal, device=None):
+    """Stateless BlocksEnv.compute_reward on the GPU.  numpy in -> numpy float32 out,
+    torch in -> torch float32 out (on `device`)."""
+    L = _lib.lib()
+    np_in = not torch.is_tensor(achieved_goal)
+    dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+    ag = torch.as_tensor(np.asarray(achieved_goal) if np_in else achieved_goal).to(dev, torch.float32)
+    g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal).to(dev, torch.float32)
+    g = g.expand_as(ag).contiguous()
+    ag = ag.contiguous()
+    lead = ag.shape[:-1]
+    n = int(np.prod(lead, dtype=np.int64)) if len(lead) else 1
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        _lib.check(L.bpg_compute_reward_f32(_ptr(ag), _ptr(g), n, int(ag.shape[-1]), _ptr(out),
+                                            dev.index, _stream(dev)))
+    out = out.reshape(lead)
+    return out.cpu().numpy() if np_in else out

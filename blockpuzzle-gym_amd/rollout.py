@@ -1,0 +1,288 @@
+"""Batched rollout workers with the reference's call signatures.
+
+  RolloutStudent    mirrors gym_blocks/rollout.py:9-210
+  PGRolloutStudent  mirrors gym_blocks/policy_gradient/rollout.py (keeps the
+                    reward and returns the discounted return `G`, :217-231,255-258)
+
+The reference steps `rollout_batch_size` Python envs one by one
+(rollout.py:121-137); here the whole batch is one HIP launch per step, or -- when
+no policy has to look at the observations between steps -- ONE launch for the
+whole T-step rollout (`generate_rollouts_fused`) that also writes the
+batch-major float32 episode arrays the reference returns (rollout.py:155-172).
+"""
+import ctypes as C
+import pickle
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import _lib
+from .envs import _ptr, _stream
+
+
+def configure_dims(env):
+    """config.py:159-183: one probe reset+step to read the dimensions."""
+    env.reset()
+    obs, _, _, info = env.step(env.action_space.sample()
+                               if env.scalar_api else np.stack([env.action_space.sample()
+                                                                for _ in range(env.num_envs)]))
+    last = (lambda x: x.shape[-1])
+    dims = {'o': last(obs['observation']), 'u': env.action_space.shape[0], 'g': last(obs['desired_goal'])}
+    for key, value in info.items():
+        value = np.array(value.cpu() if torch.is_tensor(value) else value)
+        if value.ndim == 0 or not env.scalar_api:
+            dims['info_{}'.format(key)] = 1
+        else:
+            dims['info_{}'.format(key)] = value.shape[0]
+    return dims
+
+
+def discounted_return(reward_tb, gamma, out=None):
+    """policy_gradient/rollout.py:255-258 on the GPU.  reward_tb: (T, B) float32
+    (time-major) torch tensor; returns G (B, T) float64, bit-identical to the
+    reference's in-order float64 accumulation."""
+    assert reward_tb.dim() == 2 and reward_tb.dtype == torch.float32 and reward_tb.is_cuda
+    reward_tb = reward_tb.contiguous()
+    T, B = reward_tb.shape
+    if out is None:
+        out = torch.empty(B, T, dtype=torch.float64, device=reward_tb.device)
+    _lib.check(_lib.lib().bpg_discounted_return(_ptr(reward_tb), B, T, float(gamma), _ptr(out),
+                                                reward_tb.device.index, _stream(reward_tb.device)))
+    return out
+
+
+class RolloutStudent:
+
+    def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1,
+                 exploit=False, use_target_net=False, compute_Q=False, noise_eps=0,
+                 random_eps=0, history_len=100, render=False, output=None, **kwargs):
+        """Same arguments as the reference (rollout.py:11-14).  `make_env` may
+        return a batched env directly (called as make_env(num_envs=B) when it
+        accepts that) or a single env, which is re-created with B envs."""
+        self.make_env, self.policy, self.dims, self.logger, self.T = make_env, policy, dims, logger, T
+        self.rollout_batch_size = rollout_batch_size
+        self.exploit, self.use_target_net, self.compute_Q = exploit, use_target_net, compute_Q
+        self.noise_eps, self.random_eps, self.history_len, self.render = noise_eps, random_eps, history_len, render
+        self.kwargs = kwargs
+        B = rollout_batch_size
+        try:
+            env = make_env(num_envs=B)
+        except TypeError:
+            env = make_env()
+        if getattr(env, 'num_envs', None) != B or getattr(env, 'scalar_api', False):
+            env = env.with_num_envs(B)
+        self.env = env
+        self.envs = [env]                    # the reference keeps a list (rollout.py:33)
+        assert self.T > 0
+        self.device = env.device
+        self.output = output or ('torch' if getattr(policy, 'device_tensors', False) else 'numpy')
+        self.info_keys = [key.replace('info_', '') for key in dims.keys() if key.startswith('info_')]
+        self.success_history = deque(maxlen=history_len)
+        self.Q_history = deque(maxlen=history_len)
+        self.n_episodes = 0
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.g = torch.empty((B, dims['g']), **f32)
+        self.initial_o = torch.empty((B, dims['o']), **f32)
+        self.initial_ag = torch.empty((B, dims['g']), **f32)
+        self.reset_all_rollouts()
+        self.clear_history()
+
+    # -- rollout.py:47-64 -------------------------------------------------
+    def reset_all_rollouts(self, test=False, num_grey=None):
+        obs = self.env.reset(num_grey=num_grey)
+        if test:
+            obs = self.env.unwrapped.set_test()      # maximum difficulty (rollout.py:53-55)
+        self.initial_o.copy_(obs['observation'])
+        self.initial_ag.copy_(obs['achieved_goal'])
+        self.g.copy_(obs['desired_goal'])
+
+    def reset_rollout(self, i, test=False):
+        mask = torch.zeros(self.rollout_batch_size, dtype=torch.uint8, device=self.device)
+        mask[i] = 1
+        obs = self.env.reset(env_mask=mask)
+        if test:
+            obs = self.env.unwrapped.set_test()
+        self.initial_o[i] = obs['observation'][i]
+        self.initial_ag[i] = obs['achieved_goal'][i]
+        self.g[i] = obs['desired_goal'][i]
+
+    def increase_difficulty(self):
+        # rollout.py:66-73
+        max_level = False
+        for env in self.envs:
+            max_level = env.unwrapped.increase_difficulty()
+        if not max_level:
+            return self.envs[0].unwrapped.get_difficulty()
+        return None
+
+    # -- rollout.py:75-172 ------------------------------------------------
+    def _policy_in(self, *ts):
+        if self.output == 'torch':
+            return ts
+        return tuple(t.cpu().numpy() for t in ts)
+
+    def _alloc_episode(self):
+        B, T, d = self.rollout_batch_size, self.T, self.dims
+        f32 = dict(dtype=torch.float32, device=self.device)
+        return dict(o=torch.zeros((B, T + 1, d['o']), **f32), u=torch.zeros((B, T, d['u']), **f32),
+                    g=torch.empty((B, T, d['g']), **f32), ag=torch.empty((B, T + 1, d['g']), **f32),
+                    info_is_success=torch.empty((B, T, 1), **f32))
+
+    def _finish(self, episode, Qs=()):
+        succ_last = episode['info_is_success'][:, -1, 0]
+        success_rate = float(succ_last.mean().item())           # rollout.py:163-167
+        self.success_history.append(success_rate)
+        if self.compute_Q and len(Qs):
+            self.Q_history.append(np.mean(Qs))
+        self.n_episodes += self.rollout_batch_size
+        if 'is_success' not in self.info_keys:       # only keys named in dims (rollout.py:35,160-161)
+            episode = {k: v for k, v in episode.items() if k != 'info_is_success'}
+        if self.output == 'numpy':
+            return {k: v.cpu().numpy() for k, v in episode.items()}
+        return episode
+
+    def generate_rollouts(self, render=False, test=False, compute_Attention=False, num_grey=None):
+        """rollout.py:75-172 with the policy in the loop: one HIP step launch
+        for the whole batch per time step.  Returns the batch-major episode."""
+        env, B, T = self.env, self.rollout_batch_size, self.T
+        self.reset_all_rollouts(test, num_grey=num_grey)
+        ep = self._alloc_episode()
+        o, ag = self.initial_o.clone(), self.initial_ag.clone()
+        ld = (T + 1) * self.dims['g']
+        Qs = []
+        for t in range(T):
+            policy_output = self.policy.get_actions(
+                *self._policy_in(o, ag, self.g),
+                compute_Q=self.compute_Q,
+                noise_eps=self.noise_eps if not self.exploit else 0.,
+                random_eps=self.random_eps if not self.exploit else 0.,
+                use_target_net=self.use_target_net)
+            if self.compute_Q:
+                u, Q = policy_output[0], policy_output[1]
+                Qs.append(float(np.mean(Q.cpu().numpy() if torch.is_tensor(Q) else Q)))
+            else:
+                u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
+            u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
+            ep['o'][:, t] = o
+            ep['ag'][:, t] = ag
+            ep['u'][:, t] = u
+            ep['g'][:, t] = self.g
+            obs, _, _, info = env.step(u)        # reward ignored: recomputed for HER (rollout.py:123-125)
+            ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
+            o = obs['observation'].clone()
+            # next achieved_goal straight into its episode slot when it is the last one
+            ag = obs['achieved_goal'].clone()
+        ep['o'][:, T] = o
+        ep['ag'][:, T] = ag
+        self.initial_o.copy_(o)
+        return self._finish(ep, Qs)
+
+    def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
+                                want_reward=False):
+        """Whole rollout in ONE kernel launch (no policy between steps): contacts
+        come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
+        source when None.  Same episode dict as generate_rollouts; `o` is the
+        env's physics-less observation repeated, `u` = `actions` or zeros."""
+        env, B, T = self.env, self.rollout_batch_size, self.T
+        self.reset_all_rollouts(test, num_grey=num_grey)
+        ep = self._alloc_episode()
+        ep['o'][:] = self.initial_o[:, None, :]
+        if actions is not None:
+            ep['u'].copy_(torch.as_tensor(actions).to(self.device).clamp(-1, 1))
+        reward = torch.empty((T, B), dtype=torch.float32, device=self.device) if want_reward else None
+        args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
+                                d_reward_tb=None if reward is None else reward.data_ptr(), d_flags_tb=None,
+                                d_ep_ag=ep['ag'].data_ptr(), d_ep_g=ep['g'].data_ptr(),
+                                d_ep_success=ep['info_is_success'].data_ptr())
+        if masks is not None:
+            assert masks.shape == (T, B) and masks.is_contiguous() and masks.element_size() == 4
+        _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
+        out = self._finish(ep)
+        if want_reward:
+            out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
+        return out
+
+    # -- rollout.py:174-210 -----------------------------------------------
+    def clear_history(self):
+        self.success_history.clear()
+        self.Q_history.clear()
+
+    def current_success_rate(self):
+        return np.mean(self.success_history)
+
+    def current_mean_Q(self):
+        return np.mean(self.Q_history)
+
+    def save_policy(self, path):
+        with open(path, 'wb') as f:
+            pickle.dump(self.policy, f)
+
+    def logs(self, prefix='worker'):
+        logs = [('success_rate', np.mean(self.success_history))]
+        if self.compute_Q:
+            logs += [('mean_Q', np.mean(self.Q_history))]
+        logs += [('episode', self.n_episodes)]
+        if prefix != '' and not prefix.endswith('/'):
+            return [(prefix + '/' + key, val) for key, val in logs]
+        return logs
+
+    def seed(self, seed):
+        """rollout.py:206-210 seeds env idx with seed + 1000*idx; the batched
+        generator is keyed by (seed, global env index) instead."""
+        for env in self.envs:
+            env.seed(seed)
+
+
+class PGRolloutStudent(RolloutStudent):
+    """policy_gradient/rollout.py: keeps the step reward and returns the
+    discounted return G (B, T) float64 and sigma (B, T, dimu)."""
+
+    def __init__(self, make_env, policy, expert, dims, logger, T, rollout_batch_size=1,
+                 exploit=False, use_target_net=False, compute_Q=False, noise_eps=0,
+                 random_eps=0, history_len=100, render=False, gamma=None,
+                 beta_final=None, annealing_coeff=None, **kwargs):
+        super().__init__(make_env, policy, dims, logger, T, rollout_batch_size=rollout_batch_size,
+                         exploit=exploit, use_target_net=use_target_net, compute_Q=compute_Q,
+                         noise_eps=noise_eps, random_eps=random_eps, history_len=history_len,
+                         render=render, **kwargs)
+        self.gamma, self.time = gamma, 0.0
+        self.beta_final, self.annealing_coeff, self.expert = beta_final, annealing_coeff, expert
+
+    def beta(self):
+        return (1.0 - self.beta_final) * np.exp(-self.time / self.annealing_coeff) + self.beta_final
+
+    def anneal(self):
+        self.time += 1.0
+
+    def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None):
+        env, B, T = self.env, self.rollout_batch_size, self.T
+        self.reset_all_rollouts(test, num_grey=num_grey)
+        beta = self.beta() if self.expert is not None else 0
+        ep = self._alloc_episode()
+        ep['sigma'] = torch.zeros((B, T, self.dims['u']), dtype=torch.float32, device=self.device)
+        reward = torch.empty((T, B), dtype=torch.float32, device=self.device)
+        o, ag = self.initial_o.clone(), self.initial_ag.clone()
+        for t in range(T):
+            if np.random.rand() < beta:
+                if o.shape[-1] != self.expert.dimo:
+                    raise NotImplementedError('expert observation trimming (policy_gradient/rollout.py:105-171)')
+                u, raw = self.expert.get_actions(*self._policy_in(o, ag, self.g), compute_raw=True)
+                sigma = None
+            else:
+                u, raw, sigma = self.policy.get_actions(*self._policy_in(o, ag, self.g), exploit=exploit)
+            if self.expert is not None:
+                sigma = None
+            u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
+            raw = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
+            ep['o'][:, t], ep['ag'][:, t], ep['u'][:, t], ep['g'][:, t] = o, ag, raw, self.g
+            if sigma is not None:
+                ep['sigma'][:, t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
+            obs, r, _, info = env.step(u)
+            reward[t] = r
+            ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
+            o, ag = obs['observation'].clone(), obs['achieved_goal'].clone()
+        ep['o'][:, T], ep['ag'][:, T] = o, ag
+        self.initial_o.copy_(o)
+        ep['G'] = discounted_return(reward, self.gamma)
+        return self._finish(ep)

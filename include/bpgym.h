@@ -1,0 +1,198 @@
+/*
+ * bpgym.h -- C ABI of the MI355X-native batched gym_blocks step()/reset() path.
+ *
+ * The reference (matthew9671/BlockPuzzle-gym) has no FFI: its env boundary is
+ * the Python gym.Env duck type.  This header is what a ctypes
+ * binding of that boundary calls; every entry point cites the reference
+ * interface it replaces (paths relative to the reference root).  Plain C types
+ * only, `int` return codes (0 = BPG_OK, negative = error, text via
+ * bpg_last_error()), no exceptions, no hidden host syncs in step/reset/rollout
+ * (they only enqueue work on `stream`), one caller thread per handle.
+ *
+ * The boundary is "contacts-in": the closed-source physics the reference calls
+ * (mujoco_py MjSim.step, robot_env.py:60) is outside; each step takes the set
+ * of object pairs in contact, which is exactly what the reference extracts from
+ * sim.data.contact (fetch_env.py:158-167).
+ *
+ * All `d_` pointers are DEVICE pointers (hipMalloc / torch tensors on the
+ * handle's device).  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).
+ *
+ * Packed per-env state (8 bytes, two SoA uint32 arrays):
+ *   now  : bits 0..20  pair (i<=j) touching this step   (achieved_goal == 1)
+ *          bits 21..30 elapsed steps since reset, saturating (gym TimeLimit)
+ *   ever : bits 0..20  pair has ever touched            (achieved_goal != -1)
+ *          bits 21..23 num_objs of the episode (Variation: 4..6)
+ *          bit  31     has_succeeded latch (fetch_env.py:80, :275-281)
+ *   pair index of (i,j), i<=j<6:  i*6 - i*(i-1)/2 + (j-i)   (bpg_pair_index)
+ * flags byte written per env-step: bit0 = info['is_success'], bit1 = done.
+ */
+#ifndef BPGYM_H
+#define BPGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPG_OK               0
+#define BPG_ERR_ARG         -1
+#define BPG_ERR_HIP         -2
+#define BPG_ERR_UNSUPPORTED -3   /* mirrors the reference's NotImplementedError  */
+#define BPG_ERR_ATTRIBUTE   -4   /* mirrors the reference's AttributeError (Q6)  */
+
+#define BPG_MAX_OBJS   6
+#define BPG_NUM_PAIRS  21
+#define BPG_MAX_GEOMS  64
+#define BPG_MAX_MODELS 3
+#define BPG_FLAG_SUCCESS 1
+#define BPG_FLAG_DONE    2
+
+/* env ids registered by gym_blocks/__init__.py:6-53, in registration order */
+enum {
+    BPG_GRIPPER_TOUCH = 0,
+    BPG_BLOCKS_TOUCH = 1,
+    BPG_TOPPLE_TOWER = 2,
+    BPG_BLOCKS_TOUCH_CURRICULUM = 3,
+    BPG_BLOCKS_TOUCH_CHOOSE = 4,
+    BPG_BLOCKS_TOUCH_CHOOSE_CURRICULUM = 5,
+    BPG_BLOCKS_TOUCH_VARIATION = 6,
+    BPG_NUM_VARIANTS = 7
+};
+
+typedef struct bpg_batch bpg_batch;     /* opaque: one batch of envs on one GPU */
+
+/* Static facts about a variant (tasks.py presets + fetch_env.py class consts). */
+typedef struct {
+    int32_t variant;
+    int32_t num_objs;        /* fetch_env.py:75 (Variation: max, 6)            */
+    int32_t side;            /* achieved_goal matrix side (Variation always 6) */
+    int32_t dimg;            /* side*side                                      */
+    int32_t dimo;            /* 10 + 15*(num_objs-2); Variation 87 (:567-621)  */
+    int32_t dimu;            /* 4 (robot_env.py:39)                            */
+    int32_t block_gripper;   /* tasks.py presets                               */
+    int32_t is_variation;
+    int32_t max_episode_steps;        /* 50 for every id (__init__.py)         */
+    int32_t set_test_supported;       /* fetch_env.py:100-101 vs :365,:443,:641 */
+    int32_t increase_difficulty_status; /* BPG_OK / _UNSUPPORTED / _ATTRIBUTE (Q6) */
+    int32_t desired_goal_is_float;    /* Q9: Variation float64, others int64   */
+    int32_t obj_colors[BPG_MAX_OBJS]; /* _sample_colors, constant per variant  */
+    int32_t goal[BPG_MAX_OBJS * BPG_MAX_OBJS]; /* _sample_goal :260-273/:682-695 */
+    uint32_t want_touch;     /* packed goal planes: pairs with goal +1 / -1    */
+    uint32_t want_never;
+    uint32_t valid_pairs;    /* all pairs i<=j<side                            */
+    char env_id[48];
+} bpg_variant_info;
+
+const char *bpg_last_error(void);
+int bpg_version(void);
+
+/* gym.make(id) name lookup (gym_blocks/__init__.py:6-53). -1 if not registered. */
+int bpg_variant_from_id(const char *env_id);
+int bpg_get_variant_info(int variant, bpg_variant_info *out);
+
+/* BlocksEnv._geom2objid (fetch_env.py:106-117): geom name -> object id, -1 = None. */
+int bpg_geom2objid(const char *name);
+/* pair index used by every packed mask. */
+int bpg_pair_index(int i, int j);
+
+/* rollout.py:33 `[make_env() for _ in range(B)]` -> one handle for n_envs envs
+ * on `device_id`.  env_id_base offsets the global env index of env 0 (multi-GPU
+ * shards, mirrors seed + 1000*idx of rollout.py:209-210).  State starts as the
+ * constructor leaves it (fetch_env.py:78-80): matrix all -1, not succeeded. */
+int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id,
+               int max_episode_steps, uint64_t seed, int64_t env_id_base);
+int bpg_destroy(bpg_batch *b);
+int64_t bpg_num_envs(const bpg_batch *b);
+
+/* RobotEnv.seed (robot_env.py:53-55) / RolloutStudent.seed (rollout.py:206-210):
+ * re-keys the counter-based generator (synthetic contacts, num_grey draw). */
+int bpg_seed(bpg_batch *b, uint64_t seed);
+
+/* id2obj table of one model (fetch_env.py:284, Variation :651): host array of
+ * `ngeom` object ids (-1 = None).  model_idx 0 except Variation (0..2 =
+ * 2/3/4-block models, chosen per episode by num_objs-4). */
+int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom);
+
+/* RobotEnv.reset (robot_env.py:71-82) + _reset_sim (fetch_env.py:247-255;
+ * Variation :646-679) + TimeLimit.reset for every env with d_env_mask[b] != 0
+ * (NULL = all).  Base variants keep the touch matrix (quirk Q1); Variation
+ * clears it and takes num_objs = 4 + num_grey, with num_grey from
+ * d_num_grey[b] (explicit variate for np_random.randint(3), :647) or, when
+ * NULL, from the handle's counter-based generator. */
+int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream);
+
+/* RobotEnv.step (robot_env.py:57-69) after the physics: _step_callback
+ * (fetch_env.py:154-167) + _is_success latch (:275-281) + compute_reward
+ * (:135-143) + TimeLimit done, fused in one kernel.  The step's contacts are
+ * given as packed pair masks d_masks[n_envs].  d_reward (float32, -1.0f /
+ * -0.0f) and d_flags (uint8) may each be NULL. */
+int bpg_step_masks(bpg_batch *b, const uint32_t *d_masks, float *d_reward,
+                   uint8_t *d_flags, void *stream);
+
+/* Same step with the contacts as the reference reads them: per env a list of
+ * geom-id pairs (sim.data.contact[i].geom1/geom2, fetch_env.py:159-162),
+ * d_contacts[n_envs][maxcon][2] int16, d_ncon[n_envs] valid entries each;
+ * geoms are mapped through the id2obj table of the env's current model. */
+int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon,
+                      int maxcon, float *d_reward, uint8_t *d_flags, void *stream);
+
+/* One step whose contacts come from the build-defined counter-based synthetic
+ * source keyed (seed, global env id, elapsed step) -- physics stand-in for
+ * throughput runs, no reference counterpart. */
+int bpg_step_synth(bpg_batch *b, float *d_reward, uint8_t *d_flags, void *stream);
+
+/* Fills d_masks[T][n_envs] (time-major) with that synthetic source for steps
+ * t0 .. t0+T-1 of the current episode. */
+int bpg_synth_masks(bpg_batch *b, int t0, int T, uint32_t *d_masks, void *stream);
+
+/* obs['achieved_goal'] / obs['desired_goal'] of _get_obs (fetch_env.py:219-228,
+ * Variation :609-621) for the whole batch: env e's dimg values are written at
+ * d_out + e*ld (ld = dimg for a dense (n_envs, dimg) array; a larger ld writes
+ * straight into the time slot of a batch-major episode buffer, rollout.py:149-150). */
+int bpg_get_achieved_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream);
+int bpg_get_achieved_goal_f64(bpg_batch *b, double *d_out, int64_t ld, void *stream);
+int bpg_get_desired_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream);
+
+/* Raw packed state, device pointers owned by the handle (zero-copy views). */
+int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);
+
+/* BlocksEnv.compute_reward (fetch_env.py:135-143), stateless and vectorised as
+ * HER calls it (config.py:110-111): n rows of `len` floats each. */
+int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len,
+                           float *d_out, int device_id, void *stream);
+/* Same on packed states against packed goal planes. */
+int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,
+                              uint32_t want_touch, uint32_t want_never, int64_t n,
+                              float *d_out, int device_id, void *stream);
+
+/* RolloutStudent.generate_rollouts inner loop (rollout.py:100-153) for T steps
+ * in ONE launch: state stays in registers, every array below is optional
+ * (NULL = not produced).  Does not reset (call bpg_reset first, as
+ * rollout.py:79 does). */
+typedef struct {
+    int32_t T;
+    const uint32_t *d_masks;   /* (T, n_envs) time-major contact masks; NULL = synthetic source */
+    float *d_reward_tb;        /* (T, n_envs) float32 step rewards                */
+    uint8_t *d_flags_tb;       /* (T, n_envs) flags bytes                         */
+    float *d_ep_ag;            /* (n_envs, T+1, dimg) episode['ag'] batch-major   */
+    float *d_ep_g;             /* (n_envs, T, dimg)   episode['g']                */
+    float *d_ep_success;       /* (n_envs, T, 1)      episode['info_is_success']  */
+} bpg_rollout_args;
+int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
+
+/* rollout.py:163-167 `successful = successes[-1]`: number of envs whose
+ * has_succeeded latch is set, added to *d_count (uint64, caller zeroes it). */
+int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream);
+
+/* policy_gradient/rollout.py:255-258: G[b][t_] = r[t_] + sum_{t>t_}
+ * gamma**(t-t_) * r[t], float64, accumulated in the reference's order.
+ * d_reward_tb (T, n) float32 time-major in, d_G (n, T) float64 batch-major out. */
+int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma,
+                          double *d_G, int device_id, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

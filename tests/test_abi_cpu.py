@@ -1,0 +1,119 @@
+"""CPU-only checks of the C-ABI library and the host logic: the library loads,
+exports every symbol include/bpgym.h declares, and its host-side tables match
+the reference-derived fixtures.  No kernel is launched here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import blockpuzzle_gym_amd as bpg
+from blockpuzzle_gym_amd import _lib
+from util import GOLDEN, VARIANTS, ENV_IDS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'bpgym.h')).read()
+    declared = sorted(set(re.findall(r'\b(bpg_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 25
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_lib.SIGNATURES) == declared, 'ctypes binding and header disagree'
+
+
+def test_registry_mirrors_reference():
+    reg = json.load(open(os.path.join(GOLDEN, 'registry.json')))
+    assert list(bpg.registry) == [r['id'] for r in reg]
+    for r in reg:
+        spec = bpg.registry[r['id']]
+        assert spec.max_episode_steps == r['max_episode_steps'] == 50
+        assert spec.kwargs == r['kwargs']
+        assert spec.entry_point == r['entry_point']
+    L = _lib.lib()
+    assert L.bpg_variant_from_id(b'haha-v0') == -1        # README.md:21 id is never registered
+    with pytest.raises(KeyError):
+        bpg.make('haha-v0')
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_variant_tables_match_reference(env_id):
+    v = VARIANTS[env_id]
+    L = _lib.lib()
+    info = _lib.variant_info(L.bpg_variant_from_id(env_id.encode()))
+    assert info.env_id.decode() == env_id
+    assert (info.num_objs, info.dimo, info.dimg, info.dimu) == (v['num_objs'], v['dimo'], v['dimg'], 4)
+    assert bool(info.block_gripper) == v['block_gripper']
+    assert list(info.obj_colors[:info.num_objs]) == v['obj_colors']
+    assert list(info.goal[:info.dimg]) == v['goal']
+    assert bool(info.desired_goal_is_float) == (v['desired_goal_dtype'] == 'float64')
+    assert bool(info.set_test_supported) == (v['set_test'] == 'ok')
+    status = {'ok': _lib.OK, 'NotImplementedError': _lib.ERR_UNSUPPORTED, 'AttributeError': _lib.ERR_ATTRIBUTE}
+    assert info.increase_difficulty_status == status[v['increase_difficulty']]
+    # packed goal planes agree with the goal matrix
+    side = info.side
+    for i in range(side):
+        for j in range(side):
+            bit = 1 << L.bpg_pair_index(i, j)
+            g = v['goal'][i * side + j]
+            assert bool(info.want_touch & bit) == (g == 1)
+            assert bool(info.want_never & bit) == (g == -1)
+            assert info.valid_pairs & bit
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_geom2objid_over_real_geom_names(env_id):
+    names = bpg.default_geom_names(env_id)
+    for k, m in enumerate(VARIANTS[env_id]['models']):
+        assert names[k] == m['geom_names']
+        got = [bpg.geom2objid(n) for n in names[k]]
+        assert [-1 if g is None else g for g in got] == m['id2obj']
+
+
+def test_pair_index_is_a_bijection():
+    L = _lib.lib()
+    seen = {}
+    for i in range(6):
+        for j in range(6):
+            p = L.bpg_pair_index(i, j)
+            assert 0 <= p < 21 and p == L.bpg_pair_index(j, i)
+            seen.setdefault(p, (min(i, j), max(i, j)))
+            assert seen[p] == (min(i, j), max(i, j))
+    assert len(seen) == 21
+    assert L.bpg_pair_index(6, 0) == -1
+
+
+def test_error_reporting_without_gpu_calls():
+    L = _lib.lib()
+    info = _lib.VariantInfo()
+    assert L.bpg_get_variant_info(99, C.byref(info)) == _lib.ERR_ARG
+    assert b'variant' in L.bpg_last_error()
+    h = C.c_void_p()
+    assert L.bpg_create(C.byref(h), 99, 4, 0, 50, 0, 0) == _lib.ERR_ARG
+    assert L.bpg_create(C.byref(h), 0, 0, 0, 50, 0, 0) == _lib.ERR_ARG
+    assert L.bpg_create(C.byref(h), 0, 4, 0, 5000, 0, 0) == _lib.ERR_ARG
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'blockpuzzle-gym_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, f
+                assert 'bpg_oracle' not in text, f
+
+
+def test_shard_ranges_cover_the_batch():
+    from blockpuzzle_gym_amd.distributed import shard_range
+    for total, world in [(4194304, 8), (1048576, 4), (10, 3), (7, 8), (1, 1)]:
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

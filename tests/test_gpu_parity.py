@@ -1,0 +1,424 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs, against the golden fixtures recorded from the reference, and
+-- at BASELINE.json's full size -- through size-independent properties.
+Everything here is bit-exact (integer / bitmask work; rewards compared as bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import blockpuzzle_gym_amd as bpg
+from oracle import bpg_oracle as O
+from util import GOLDEN, VARIANTS, ENV_IDS, short, legal_masks, fixture_masks
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def i32(a):
+    return torch.as_tensor(np.ascontiguousarray(a).view(np.int32), device=DEV)
+
+
+def bits(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+def dims_of(env_id):
+    v = VARIANTS[env_id]
+    return dict(o=v['dimo'], u=4, g=v['dimg'], info_is_success=1)
+
+
+# --------------------------------------------------------------------------
+# golden fixtures recorded from the reference
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_golden_step_traces_scalar_api(env_id):
+    """Reference env.step()/reset() traces replayed through the drop-in single-env
+    API with the contacts exactly as the reference read them (geom-id pairs)."""
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(GOLDEN, 'trace_%s.npz' % short(env_id)))
+    env = bpg.make(env_id, device=DEV)
+    assert env._max_episode_steps == 50
+    for ep, L in enumerate(d['lens']):
+        obs = env.reset(num_grey=[int(d['num_objs'][ep]) - 4])
+        if d['test_mode'][ep]:
+            obs = env.unwrapped.set_test()
+        assert obs['observation'].shape == (v['dimo'],) and obs['observation'].dtype == np.float64
+        assert obs['achieved_goal'].dtype == np.float64
+        assert str(obs['desired_goal'].dtype) == v['desired_goal_dtype']
+        np.testing.assert_array_equal(obs['achieved_goal'], d['ag_reset'][ep])
+        np.testing.assert_array_equal(obs['desired_goal'], d['g'][ep])
+        for t in range(L):
+            nc = int(d['ncon'][ep, t])
+            pairs = d['contacts'][ep, t][None].copy()
+            pairs[pairs < 0] = 0
+            obs, r, done, info = env.step(d['actions'][ep, t], contacts=(pairs, np.array([nc], np.int32)))
+            np.testing.assert_array_equal(obs['achieved_goal'], d['ag'][ep, t])
+            assert isinstance(r, np.float32) and r.view(np.uint32) == d['reward_bits'][ep, t]
+            assert done is bool(d['done'][ep, t])
+            assert info['is_success'] is bool(d['success'][ep, t])
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_golden_rollout_student(env_id):
+    """Reference RolloutStudent.generate_rollouts episodes (rollout.py:75-172)
+    over consecutive rollouts, policy in the loop, contacts as geom-id pairs."""
+    d = np.load(os.path.join(GOLDEN, 'rollout_%s.npz' % short(env_id)))
+    B, T = int(d['B']), int(d['T'])
+
+    class Replay:
+        def __init__(self):
+            self.u, self.t = None, 0
+
+        def get_actions(self, o, ag, g, **kw):
+            assert o.shape == (B, VARIANTS[env_id]['dimo']) and o.dtype == np.float32
+            assert set(kw) == {'compute_Q', 'noise_eps', 'random_eps', 'use_target_net'}
+            u = self.u[:, self.t]
+            self.t += 1
+            return u
+
+    policy = Replay()
+    src = bpg.ScriptedContacts()
+    worker = bpg.RolloutStudent(lambda: bpg.make(env_id, device=DEV, contact_source=src), policy,
+                                dims_of(env_id), None, T, rollout_batch_size=B)
+    worker.env.contact_source = src
+    worker.seed(123)
+    for r, test in enumerate(d['modes']):
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        src.pairs = np.ascontiguousarray(con.transpose(1, 0, 2, 3))       # (T, B, maxcon, 2)
+        src.ncon = np.ascontiguousarray(d['r%d_ncon' % r].T)
+        src.masks, src.t = None, 0
+        policy.u, policy.t = d['r%d_u' % r], 0
+        ep = worker.generate_rollouts(test=bool(test), num_grey=d['r%d_num_objs' % r] - 4)
+        for k in ('ag', 'g', 'u', 'info_is_success'):
+            assert ep[k].dtype == np.float32
+            np.testing.assert_array_equal(ep[k], d['r%d_%s' % (r, k)], err_msg=k)
+        assert ep['o'].shape == d['r%d_o' % r].shape
+        assert worker.success_history[-1] == pytest.approx(float(d['r%d_success_rate' % r]), abs=1e-7)
+    assert worker.n_episodes == int(d['n_episodes'])
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_golden_rollout_fused(env_id):
+    """Same reference episodes through the single-launch fused rollout kernel."""
+    d = np.load(os.path.join(GOLDEN, 'rollout_%s.npz' % short(env_id)))
+    B, T = int(d['B']), int(d['T'])
+    worker = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
+                                dims_of(env_id), None, T, rollout_batch_size=B)
+    for r, test in enumerate(d['modes']):
+        masks = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
+        ep = worker.generate_rollouts_fused(test=bool(test), masks=i32(masks),
+                                            num_grey=d['r%d_num_objs' % r] - 4)
+        for k in ('ag', 'g', 'info_is_success'):
+            np.testing.assert_array_equal(ep[k], d['r%d_%s' % (r, k)], err_msg=k)
+        assert worker.success_history[-1] == pytest.approx(float(d['r%d_success_rate' % r]), abs=1e-7)
+
+
+def test_golden_compute_reward():
+    d = np.load(os.path.join(GOLDEN, 'compute_reward.npz'))
+    keys = sorted({k.rsplit('_', 1)[0] for k in d.files})
+    env = bpg.make('BlocksTouch-v0', device=DEV)
+    for k in keys:
+        ag, g, g2 = d[k + '_ag'], d[k + '_g'], d[k + '_g2']
+        r = env.compute_reward(ag, g, None)
+        assert r.dtype == np.float32 and r.shape == (257,)
+        np.testing.assert_array_equal(r.view(np.uint32), d[k + '_rbits'])
+        # config.py:110-111 keyword spelling
+        r2 = env.compute_reward(achieved_goal=ag, desired_goal=g2, info=None)
+        np.testing.assert_array_equal(r2.view(np.uint32), d[k + '_rbits2'])
+        n2 = ag.shape[1]
+        r3 = env.compute_reward(ag[:240].reshape(4, 60, n2).astype(np.float64),
+                                g2[:240].reshape(4, 60, n2).astype(np.float64), None)
+        assert r3.shape == (4, 60)
+        np.testing.assert_array_equal(r3.view(np.uint32), d[k + '_rbits3'])
+
+
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation'])
+def test_golden_pg_rollout_return(name):
+    """policy_gradient/rollout.py: reference G (float64) bit-for-bit."""
+    env_id = name + '-v0'
+    d = np.load(os.path.join(GOLDEN, 'pg_rollout_%s.npz' % name))
+    B, T = int(d['B']), int(d['T'])
+
+    class Replay:
+        kwargs = {}
+
+        def get_actions(self, o, ag, g, exploit=False):
+            u = self.u[:, self.t]
+            self.t += 1
+            return u, u.copy(), np.zeros_like(u)
+
+    policy = Replay()
+    src = bpg.ScriptedContacts()
+    worker = bpg.PGRolloutStudent(lambda: bpg.make(env_id, device=DEV), policy, None, dims_of(env_id), None, T,
+                                  rollout_batch_size=B, gamma=1. - 1. / T)
+    worker.env.contact_source = src
+    for r in range(len(d['modes'])):
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        src.pairs = np.ascontiguousarray(con.transpose(1, 0, 2, 3))
+        src.ncon = np.ascontiguousarray(d['r%d_ncon' % r].T)
+        src.t = 0
+        policy.u, policy.t = d['r%d_u' % r], 0
+        ep = worker.generate_rollouts(num_grey=d['r%d_num_objs' % r] - 4)
+        assert ep['G'].dtype == np.float64
+        np.testing.assert_array_equal(ep['G'].view(np.uint64), d['r%d_G' % r].view(np.uint64))
+        np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
+        np.testing.assert_array_equal(ep['info_is_success'], d['r%d_info_is_success' % r])
+
+
+# --------------------------------------------------------------------------
+# oracle on the same seeded inputs
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('env_id', ENV_IDS)
+@pytest.mark.parametrize('B', [4096, 1003, 1])
+def test_fused_rollout_vs_oracle(env_id, B):
+    """Random legal contact masks, two consecutive rollouts (quirk Q1 carries the
+    matrix over for the base variants), vector (B%4==0) and scalar kernels."""
+    T = 50
+    rng = np.random.RandomState(B)
+    worker = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
+                                dims_of(env_id), None, T, rollout_batch_size=B)
+    envs = None
+    for r in range(2):
+        num_grey = rng.randint(3, size=B).astype(np.int32)
+        nobj = 4 + num_grey if 'Variation' in env_id else VARIANTS[env_id]['num_objs']
+        masks = legal_masks(rng, T, B, nobj, density=2 + r)
+        ep = worker.generate_rollouts_fused(masks=i32(masks), num_grey=num_grey, want_reward=True)
+        ref, envs = O.generate_rollouts(env_id, B, T, masks, num_grey=num_grey, envs=envs)
+        np.testing.assert_array_equal(ep['ag'], ref['ag'])
+        np.testing.assert_array_equal(ep['g'], ref['g'])
+        np.testing.assert_array_equal(ep['info_is_success'], ref['info_is_success'])
+        np.testing.assert_array_equal(ep['reward_tb'].view(np.uint32), ref['reward'].view(np.uint32))
+        assert worker.success_history[-1] == pytest.approx(ref['success_rate'], abs=1e-6)
+
+
+@pytest.mark.parametrize('env_id', ['GripperTouch-v0', 'BlocksTouchChoose-v0', 'BlocksTouchVariation-v0',
+                                    'ToppleTower-v0'])
+@pytest.mark.parametrize('B', [2048, 777])
+def test_packed_rollout_and_steps_vs_oracle(env_id, B):
+    """The packed fused rollout (no episode buffers), the per-step mask kernel
+    and the contact-list kernel all agree with the oracle: reward bits, flags
+    (is_success | done<<1) and the final touch matrix.  T=60 crosses the
+    TimeLimit (done stays set)."""
+    T = 60
+    rng = np.random.RandomState(7 * B)
+    v = VARIANTS[env_id]
+    num_grey = rng.randint(3, size=B).astype(np.int32)
+    nobj = 4 + num_grey if 'Variation' in env_id else np.full(B, v['num_objs'])
+    masks = legal_masks(rng, T, B, nobj)
+    # oracle
+    oenvs = [O.OracleEnv(env_id) for _ in range(B)]
+    exp_r = np.zeros((T, B), np.uint32)
+    exp_f = np.zeros((T, B), np.uint8)
+    for b, e in enumerate(oenvs):
+        e.reset(num_grey=int(num_grey[b]))
+        for t in range(T):
+            _, r, done, succ = e.step_mask(int(masks[t, b]))
+            exp_r[t, b] = np.float32(r).view(np.uint32)
+            exp_f[t, b] = int(succ) | (int(done) << 1)
+    exp_ag = np.stack([e.achieved_goal() for e in oenvs])
+
+    L = bpg._lib.lib()
+    import ctypes as C
+    # (1) per-step mask kernel through the gym-style API
+    env = bpg.make(env_id, num_envs=B, device=DEV)
+    env.reset(num_grey=num_grey)
+    dm = i32(masks)
+    for t in range(T):
+        obs, r, done, info = env.step(None, contact_masks=dm[t])
+        np.testing.assert_array_equal(bits(r), exp_r[t])
+        f = info['is_success'].cpu().numpy().astype(np.uint8) | (done.cpu().numpy().astype(np.uint8) << 1)
+        np.testing.assert_array_equal(f, exp_f[t])
+    np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), exp_ag.astype(np.float32))
+    np.testing.assert_array_equal(env.achieved_goal_f64().cpu().numpy(), exp_ag)
+    assert int(env.success_count().item()) == int((exp_f[-1] & 1).sum())
+    # (2) packed fused rollout
+    env2 = bpg.make(env_id, num_envs=B, device=DEV)
+    env2.reset(num_grey=num_grey)
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(),
+                                d_flags_tb=flg.data_ptr(), d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    bpg._lib.check(L.bpg_rollout(env2._h, C.byref(args), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(bits(rew), exp_r)
+    np.testing.assert_array_equal(flg.cpu().numpy(), exp_f)
+    assert torch.equal(env2.state_now, env.state_now) and torch.equal(env2.state_ever, env.state_ever)
+    # (3) contact-list kernel: rebuild geom-id lists from the masks
+    env3 = bpg.make(env_id, num_envs=B, device=DEV)
+    env3.reset(num_grey=num_grey)
+    maxcon = 24
+    pair_of = {L.bpg_pair_index(i, j): (i, j) for i in range(6) for j in range(i, 6)}
+    geom_of = []                                   # per model: object id -> a geom id
+    for m in v['models']:
+        geom_of.append({o: g for g, o in enumerate(m['id2obj']) if o >= 0})
+    none_geom = [m['id2obj'].index(-1) for m in v['models']]
+    for t in range(0, T, 7):
+        pairs = np.zeros((B, maxcon, 2), np.int16)
+        ncon = np.zeros(B, np.int32)
+        for b in range(B):
+            mi = int(num_grey[b]) if 'Variation' in env_id else 0
+            lst = [(none_geom[mi], geom_of[mi][1])]                 # a None-mapped contact is ignored
+            for p in range(21):
+                if masks[t, b] >> p & 1:
+                    i, j = pair_of[p]
+                    lst.append((geom_of[mi][j], geom_of[mi][i]) if (p + b) % 2 else (geom_of[mi][i], geom_of[mi][j]))
+            lst.append(lst[-1])                                      # duplicates are harmless
+            pairs[b, :len(lst)] = lst
+            ncon[b] = len(lst)
+        env3.load_state_dict(env.state_dict())
+        e_ref = bpg.make(env_id, num_envs=B, device=DEV)
+        e_ref.load_state_dict(env.state_dict())
+        _, r_a, d_a, i_a = env3.step(None, contacts=(pairs, ncon))
+        _, r_b, d_b, i_b = e_ref.step(None, contact_masks=dm[t])
+        assert torch.equal(r_a.view(torch.int32), r_b.view(torch.int32))
+        assert torch.equal(env3.state_now, e_ref.state_now) and torch.equal(env3.state_ever, e_ref.state_ever)
+
+
+def test_synthetic_source_matches_oracle_spec():
+    """bpg_synth_masks / in-kernel synthetic contacts == the oracle's statement of
+    the (build-defined) generator, including the global env index offset."""
+    import ctypes as C
+    B, T, base, seed = 3000, 12, 123456, 99
+    for env_id in ['BlocksTouchVariation-v0', 'BlocksTouch-v0']:
+        env = bpg.make(env_id, num_envs=B, device=DEV, seed=seed, env_id_base=base)
+        rng = np.random.RandomState(5)
+        num_grey = rng.randint(3, size=B).astype(np.int32)
+        env.reset(num_grey=num_grey)
+        nobj = env.num_objs_per_env().cpu().numpy()
+        out = torch.empty((T, B), dtype=torch.int32, device=DEV)
+        bpg._lib.check(bpg._lib.lib().bpg_synth_masks(env._h, 0, T, C.c_void_p(out.data_ptr()), None))
+        exp = O.synth_masks(seed, base + np.arange(B), T, nobj)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), exp)
+        # stepping with the in-kernel source == stepping with those masks
+        env_b = bpg.make(env_id, num_envs=B, device=DEV, seed=seed, env_id_base=base)
+        env_b.reset(num_grey=num_grey)
+        for t in range(T):
+            _, r1, d1, i1 = env.step(None)
+            _, r2, d2, i2 = env_b.step(None, contact_masks=out[t])
+            assert torch.equal(r1.view(torch.int32), r2.view(torch.int32))
+        assert torch.equal(env.state_now, env_b.state_now) and torch.equal(env.state_ever, env_b.state_ever)
+
+
+def test_compute_reward_random_vs_oracle():
+    rng = np.random.RandomState(3)
+    for n, ln in [(1, 36), (127, 9), (128, 16), (1000, 25), (5000, 36), (300, 7)]:
+        ag = rng.randint(-1, 2, size=(n, ln)).astype(np.float32)
+        g = rng.randint(-1, 2, size=(n, ln)).astype(np.float32) * (rng.rand(n, ln) < 0.2)
+        ag[::2] = np.where(g[::2] != 0, g[::2], ag[::2])
+        got = bpg.compute_reward(torch.as_tensor(ag, device=DEV), torch.as_tensor(g.astype(np.float32), device=DEV))
+        np.testing.assert_array_equal(bits(got), O.compute_reward(ag, g).view(np.uint32))
+    assert bpg.compute_reward(np.zeros((0, 36), np.float32), np.zeros((0, 36), np.float32)).shape == (0,)
+
+
+def test_discounted_return_random_vs_oracle():
+    rng = np.random.RandomState(11)
+    for T, B in [(50, 130), (7, 64), (1, 3), (100, 65)]:
+        r = np.where(rng.rand(T, B) < 0.7, -1.0, -0.0).astype(np.float32)
+        G = bpg.discounted_return(torch.as_tensor(r, device=DEV), 1. - 1. / 50).cpu().numpy()
+        for b in range(0, B, 9):
+            np.testing.assert_array_equal(G[b].view(np.uint64),
+                                          O.discounted_return(r[:, b].astype(np.float64), 1. - 1. / 50).view(np.uint64))
+
+
+def test_partial_reset_and_curriculum_surface():
+    env = bpg.make('BlocksTouch-v0', num_envs=8, device=DEV)
+    env.reset()
+    m = np.full(8, 1 << bpg._lib.lib().bpg_pair_index(2, 3), np.uint32)
+    _, r, done, info = env.step(None, contact_masks=m.view(np.int32))
+    assert info['is_success'].all() and (bits(r) == 0x80000000).all()
+    mask = np.array([1, 0, 0, 0, 1, 0, 0, 0], np.uint8)
+    obs = env.reset(env_mask=mask)
+    _, r, done, info = env.step(None, contact_masks=np.zeros(8, np.int32))
+    # reset envs lost the latch, the others keep it; the matrix itself persists (Q1)
+    np.testing.assert_array_equal(info['is_success'].cpu().numpy(), mask == 0)
+    assert (obs['achieved_goal'][:, 2 * 4 + 3] == 1).all()
+    # curriculum surface (quirk Q6), golden difficulty traces
+    for env_id, v in VARIANTS.items():
+        e = bpg.make(env_id, num_envs=2, device=DEV)
+        if 'error' in v['difficulty']:
+            with pytest.raises({'NotImplementedError': NotImplementedError,
+                                'AttributeError': AttributeError}[v['difficulty']['error']]):
+                e.unwrapped.increase_difficulty()
+        else:
+            for row in v['difficulty']['rows']:
+                assert e.unwrapped.increase_difficulty() is row['ret']
+                assert e.unwrapped.get_difficulty() == row['difficulty']
+                assert e.obj_range == row['obj_range']
+                if row['wrong_obj_range'] is not None:
+                    assert e.wrong_obj_range == row['wrong_obj_range']
+        if v['set_test'] != 'ok':
+            with pytest.raises(NotImplementedError):
+                e.unwrapped.set_test()
+
+
+def test_configure_dims_probe():
+    """config.py:159-183 probe on the drop-in single env."""
+    for env_id, v in VARIANTS.items():
+        env = bpg.make(env_id, device=DEV)
+        assert bpg.configure_dims(env) == dict(o=v['dimo'], u=4, g=v['dimg'], info_is_success=1)
+        assert env.seed(5) == [5]
+
+
+# --------------------------------------------------------------------------
+# BASELINE.json full size: size-independent properties
+# --------------------------------------------------------------------------
+def test_full_size_properties():
+    """1 048 576 envs: (a) the fused T-step launch equals T single-step launches,
+    (b) sharding invariance: two half-size handles with env_id_base offsets equal
+    the full batch, (c) success count == popcount of the final flags, (d) rewards
+    are only -1.0f / -0.0f and success implies a -0.0 at some step, (e) the
+    episode writer's ag rows equal the float view of the packed state."""
+    import ctypes as C
+    B, T, seed = 1 << 20, 50, 2026
+    env_id = 'BlocksTouchVariation-v0'
+    L = bpg._lib.lib()
+    full = bpg.make(env_id, num_envs=B, device=DEV, seed=seed)
+    full.reset()
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
+                                d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    bpg._lib.check(L.bpg_rollout(full._h, C.byref(args), None))
+    # (a)
+    step = bpg.make(env_id, num_envs=B, device=DEV, seed=seed)
+    step.reset()
+    for t in range(T):
+        _, r, done, info = step.step(None)
+        assert torch.equal(r.view(torch.int32), rew[t].view(torch.int32))
+        f = info['is_success'].to(torch.uint8) | (done.to(torch.uint8) << 1)
+        assert torch.equal(f, flg[t])
+    assert torch.equal(step.state_now, full.state_now) and torch.equal(step.state_ever, full.state_ever)
+    # (b)
+    halves = [bpg.make(env_id, num_envs=B // 2, device=DEV, seed=seed, env_id_base=k * (B // 2)) for k in range(2)]
+    for k, h in enumerate(halves):
+        h.reset()
+        rw = torch.empty((T, B // 2), dtype=torch.float32, device=DEV)
+        a = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rw.data_ptr(), d_flags_tb=None,
+                                 d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+        bpg._lib.check(L.bpg_rollout(h._h, C.byref(a), None))
+        sl = slice(k * (B // 2), (k + 1) * (B // 2))
+        assert torch.equal(rw.view(torch.int32), rew[:, sl].view(torch.int32))
+        assert torch.equal(h.state_ever, full.state_ever[sl])
+    # (c)
+    assert int(full.success_count().item()) == int((flg[-1] & 1).sum().item())
+    assert (flg[-1] & 2).all() and not (flg[-2] & 2).any()          # done exactly at step 50
+    # (d)
+    rb = rew.view(torch.int32)
+    ok = rb == -2147483648
+    assert (ok | (rb == -1082130432)).all()
+    assert torch.equal(ok.any(dim=0), (flg[-1] & 1).bool())
+    # (e) episode writer on a smaller batch
+    Bs = 1 << 16
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=seed), None,
+                           dims_of(env_id), None, T, rollout_batch_size=Bs, output='torch')
+    ep = w.generate_rollouts_fused(want_reward=True)
+    assert torch.equal(ep['reward_tb'].view(torch.int32), rew[:, :Bs].view(torch.int32))
+    assert torch.equal(ep['ag'][:, T], w.env._get_obs()['achieved_goal'])
+    assert torch.equal(ep['info_is_success'][:, :, 0].T.to(torch.uint8), flg[:, :Bs] & 1)
+    assert (ep['ag'][:, 0] == -1).all()
+    g = torch.as_tensor(np.asarray(VARIANTS[env_id]['goal'], np.float32), device=DEV)
+    assert (ep['g'] == g).all()
