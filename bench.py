@@ -2,10 +2,10 @@
 """Headline benchmark: env-steps/s of the batched gym_blocks step()/reset() hot
 path at 1 048 576 envs per GPU (BASELINE.json metric), one JSON line on rank 0.
 
-A bench "step" = one rollout pass over the batch: reset of all envs, T=50 fused
-env steps in one launch (contacts read as packed masks resident in HBM -- the
-contacts-in boundary -- rewards + success/done flags written per env-step), and
-the success-count reduction; with N>1 GPUs one RCCL all-reduce of
+A bench "step" = one rollout pass over the batch in ONE kernel launch: reset of
+all envs, T=50 fused env steps (contacts read as packed masks resident in HBM --
+the contacts-in boundary -- rewards + success/done flags written per env-step)
+and the success-count reduction; with N>1 GPUs one RCCL all-reduce of
 (successes, envs) per rollout.  Weak scaling: every GPU holds `--envs` envs.
 
     python bench.py [--gpus N --steps K --warmup W]
@@ -80,31 +80,38 @@ def main():
 
     # inputs resident in HBM before the timed region: (T, B) contact masks from the
     # synthetic source (global env index keyed), outputs preallocated
-    env.reset()
+    # Variation draws num_grey per episode (fetch_env.py:647); fixed explicit draws keep every
+    # rollout's episode consistent with the pre-generated contact masks
+    num_grey = (torch.arange(B, device=dev, dtype=torch.int32) * 7 + rank) % 3
+    env.reset(num_grey=num_grey)
     masks = torch.empty((T, B), dtype=torch.int32, device=dev)
     _lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(masks.data_ptr()), stream))
     reward = torch.empty((T, B), dtype=torch.float32, device=dev)
     flags = torch.empty((T, B), dtype=torch.uint8, device=dev)
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
-    args = _lib.RolloutArgs(T=T, d_masks=masks.data_ptr(), d_reward_tb=reward.data_ptr(),
-                            d_flags_tb=flags.data_ptr(), d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)      # ping-pong success counters
+    cptr = [counts.data_ptr(), counts.data_ptr() + 8]
+    # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167)
+    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks.data_ptr(),
+                             d_reward_tb=reward.data_ptr(),
+                             d_flags_tb=flags.data_ptr(), d_success_count=cptr[k], d_zero_count=cptr[1 - k])
+            for k in range(2)]
     stats = torch.zeros(2, dtype=torch.float64, device=dev)
+    stats[1] = B
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    it = [0]
 
     def one_rollout(k=None):
-        _lib.check(L.bpg_reset(env._h, None, None, stream))
+        cur = it[0] & 1
+        it[0] += 1
         if k is not None:
             ev0[k].record()
-        _lib.check(L.bpg_rollout(env._h, C.byref(args), stream))
+        _lib.check(L.bpg_rollout(env._h, C.byref(args[cur]), stream))
         if k is not None:
             ev1[k].record()
-        count.zero_()
-        _lib.check(L.bpg_success_count(env._h, C.c_void_p(count.data_ptr()), stream))
         if world > 1:
-            stats[0] = count[0]
-            stats[1] = B
+            stats[0] = counts[cur]
             dist.all_reduce(stats)          # the one collective per rollout (RCCL over xGMI)
 
     def fence():
@@ -126,7 +133,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)) / a.steps
-    succ_rate = float(count.item()) / B
+    succ_rate = float(counts[(it[0] - 1) & 1].item()) / B
 
     # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env packed state 8 B in + 8 B out
@@ -211,11 +218,10 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         res['step_masks_graph_T_launches'] = {'error': repr(e)[:200]}
 
     # (3) fused rollout with in-kernel synthetic contacts: reward 4 + flags 1 per env-step + 16 B state
-    a2 = _lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr(),
-                          d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    a2 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=None, d_reward_tb=reward.data_ptr(),
+                          d_flags_tb=flags.data_ptr())
 
     def synth():
-        _lib.check(L.bpg_reset(env._h, None, None, stream))
         _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
     res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 16), B * T)
 
@@ -225,11 +231,10 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         ag = torch.empty((B, T + 1, dimg), dtype=torch.float32, device=dev)
         gg = torch.empty((B, T, dimg), dtype=torch.float32, device=dev)
         sc = torch.empty((B, T, 1), dtype=torch.float32, device=dev)
-        a3 = _lib.RolloutArgs(T=T, d_masks=masks.data_ptr(), d_reward_tb=None, d_flags_tb=None,
+        a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(),
                               d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(), d_ep_success=sc.data_ptr())
 
         def episode():
-            _lib.check(L.bpg_reset(env._h, None, None, stream))
             _lib.check(L.bpg_rollout(env._h, C.byref(a3), stream))
         nbytes = B * (16 + T * 4 + 4 * ((T + 1) * dimg + T * dimg + T))
         res['episode_writer_f32'] = line(timed(episode, 5), nbytes, B * T)

@@ -30,9 +30,10 @@ class VariantInfo(C.Structure):
 
 class RolloutArgs(C.Structure):
     _fields_ = [
-        ('T', C.c_int32),
+        ('T', C.c_int32), ('reset_first', C.c_int32), ('d_num_grey', C.c_void_p),
         ('d_masks', C.c_void_p), ('d_reward_tb', C.c_void_p), ('d_flags_tb', C.c_void_p),
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
+        ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
     ]
 
 

@@ -148,7 +148,7 @@ struct bpg_batch {
     int ngeom[BPG_MAX_MODELS];
 };
 
-namespace {
+namespace bpgk {   // kernels + launch helpers (named so profiles read bpgk::k_*)
 
 struct DeviceGuard {
     int prev = -1;
@@ -242,29 +242,44 @@ __device__ __forceinline__ uint32_t nobj_of(uint32_t ever) { return (ever >> NOB
 // ------------------------------ reset ---------------------------------------
 // fetch_env.py:247-255: has_succeeded = False, matrix kept (Q1);
 // Variation :646-679: matrix = -1, num_objs = 4 + num_grey.  TimeLimit: t = 0.
+struct ResetConst {
+    int32_t enabled;        // apply the reset before step 0 (fused rollouts)
+    int32_t is_variation;
+    uint32_t base_nobj;
+    uint32_t seed, env_base, reset_counter;
+    const int32_t *num_grey;   // explicit variates for np_random.randint(3) (:647) or NULL
+};
+
+__device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_t i, const ResetConst &rc)
+{
+    if (rc.is_variation) {
+        uint32_t g;
+        if (rc.num_grey) {
+            const int32_t v = rc.num_grey[i];
+            g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
+        } else {
+            // counter-based stand-in for np_random.randint(3)
+            g = hash32(synth_key(rc.seed ^ 0xA511E9B3U, rc.env_base + (uint32_t)i) + rc.reset_counter) % 3u;
+        }
+        now = 0u;
+        ever = (4u + g) << NOBJ_SHIFT;
+    } else {
+        now = now & PAIR_BITS;
+        ever = (ever & PAIR_BITS) | (rc.base_nobj << NOBJ_SHIFT);
+    }
+}
+
 __global__ void __launch_bounds__(256)
-k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, int is_variation,
-        uint32_t base_nobj, const int32_t *__restrict__ num_grey, const uint8_t *__restrict__ env_mask,
-        uint32_t seed, uint32_t env_base, uint32_t reset_counter)
+k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, ResetConst rc,
+        const uint8_t *__restrict__ env_mask)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (env_mask && env_mask[i] == 0) continue;
-        if (is_variation) {
-            uint32_t g;
-            if (num_grey) {
-                int32_t v = num_grey[i];
-                g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
-            } else {
-                // counter-based stand-in for np_random.randint(3), fetch_env.py:647
-                g = hash32(synth_key(seed ^ 0xA511E9B3U, env_base + (uint32_t)i) + reset_counter) % 3u;
-            }
-            now[i] = 0u;
-            ever[i] = (4u + g) << NOBJ_SHIFT;
-        } else {
-            now[i] = now[i] & PAIR_BITS;
-            ever[i] = (ever[i] & PAIR_BITS) | (base_nobj << NOBJ_SHIFT);
-        }
+        uint32_t a = now[i], e = ever[i];
+        reset_core(a, e, i, rc);
+        now[i] = a;
+        ever[i] = e;
     }
 }
 
@@ -413,16 +428,39 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
 }
 
 // ------------------------------ fused rollout -------------------------------
+// rollout.py:163-167 inside a kernel: per-wave ballot + popcount, LDS sum over
+// the block's waves, ONE atomic per block (a same-address atomic costs ~12 ns
+// at the memory side, so the grid is kept at <= 256 fat blocks).
+__device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned long long *count)
+{
+    __shared__ uint32_t s_part[16];
+    uint32_t c = lane_count;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_part[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < nw; w++) tot += s_part[w];
+        if (tot) atomicAdd(count, tot);
+    }
+}
+
 // T steps in one launch, 4 envs per lane, state in registers.  Masks / rewards
 // are time-major (T, n) so every access is a 16-byte-per-lane coalesced stream.
+// Optionally resets first (rollout.py:79) and counts the final successes.
 template <int SRC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
                uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
-               StepConst c, SynthConst s)
+               StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
+               unsigned long long *__restrict__ zero_next)
 {
     const int64_t nvec = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t nsucc = 0;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint4 a = reinterpret_cast<uint4 *>(now)[v];
         uint4 e = reinterpret_cast<uint4 *>(ever)[v];
@@ -430,6 +468,7 @@ k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const ui
         uint32_t key[4] = {0, 0, 0, 0}, valid[4], forced[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            if (rc.enabled) reset_core(an[k], ee[k], 4 * v + k, rc);
             if (SRC == SRC_SYNTH) {
                 key[k] = synth_key(s.seed, s.env_base + (uint32_t)(4 * v + k));
                 valid[k] = s.valid_by_n[nobj_of(ee[k])];
@@ -458,18 +497,24 @@ k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const ui
         }
         reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
         reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
+        nsucc += (ee[0] >> 31) + (ee[1] >> 31) + (ee[2] >> 31) + (ee[3] >> 31);
     }
+    if (count) block_count_add(nsucc, count);
 }
 
 template <int SRC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_rollout_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
                  uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
-                 StepConst c, SynthConst s)
+                 StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
+                 unsigned long long *__restrict__ zero_next)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t nsucc = 0;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t a = now[i], e = ever[i];
+        if (rc.enabled) reset_core(a, e, i, rc);
         uint32_t key = 0, valid = 0, forced = 0;
         if (SRC == SRC_SYNTH) {
             key = synth_key(s.seed, s.env_base + (uint32_t)i);
@@ -485,7 +530,9 @@ k_rollout_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const 
             if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
         }
         now[i] = a; ever[i] = e;
+        nsucc += e >> 31;
     }
+    if (count) block_count_add(nsucc, count);
 }
 
 // ------------------------------ float views ---------------------------------
@@ -599,7 +646,8 @@ __global__ void __launch_bounds__(64)
 k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
-          int64_t n, int T, int R, StepConst c, SynthConst s, PairTable tabv)
+          int64_t n, int T, int R, StepConst c, SynthConst s, PairTable tabv, ResetConst rc,
+          unsigned long long *__restrict__ count, unsigned long long *__restrict__ zero_next)
 {
     constexpr int DIMG = SIDE * SIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -607,11 +655,14 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     PairTable *tab = reinterpret_cast<PairTable *>(smem + (size_t)64 * R * sizeof(uint2));
     const int lane = threadIdx.x;
     if (lane == 0) *tab = tabv;
+    if (zero_next && blockIdx.x == 0 && lane == 0) *zero_next = 0ull;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    bool succ_final = false;
     if (lane < nvalid) {
         const int64_t i = base + lane;
         uint32_t a = now[i], e = ever[i];
+        if (rc.enabled) reset_core(a, e, i, rc);
         uint32_t key = 0, valid = 0, forced = 0;
         if (SRC == SRC_SYNTH) {
             key = synth_key(s.seed, s.env_base + (uint32_t)i);
@@ -631,6 +682,11 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
         }
         now[i] = a; ever[i] = e;
+        succ_final = (e >> 31) != 0;
+    }
+    if (count) {
+        const unsigned long long nb = (unsigned long long)__popcll(__ballot(succ_final));
+        if (lane == 0 && nb) atomicAdd(count, nb);
     }
     __syncthreads();
     if (ep_ag)
@@ -710,21 +766,21 @@ k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__rest
 }
 
 // ------------------------------ success count -------------------------------
-// rollout.py:163-167: per-wave ballot + popcount, one atomic per wave.
-__global__ void __launch_bounds__(256)
+// rollout.py:163-167 as its own launch: <= 256 blocks of 1024 lanes, 16-byte
+// loads, block reduction, one atomic per block.
+__global__ void __launch_bounds__(1024)
 k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long *__restrict__ count)
 {
+    const int64_t nvec = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    unsigned long long acc = 0;
-    // every lane of a wave runs the same number of iterations (ballot needs the whole wave)
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t wave0 = i0 - (threadIdx.x & 63);
-    for (int64_t w = wave0; w < n; w += stride) {
-        const int64_t i = w + (threadIdx.x & 63);
-        const bool p = (i < n) && (ever[i] >> 31);
-        acc += (unsigned long long)__popcll(__ballot(p));
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    for (int64_t v = gtid; v < nvec; v += stride) {
+        const uint4 e = reinterpret_cast<const uint4 *>(ever)[v];
+        c += (e.x >> 31) + (e.y >> 31) + (e.z >> 31) + (e.w >> 31);
     }
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(count, acc);
+    if (gtid < n - (nvec << 2)) c += ever[(nvec << 2) + gtid] >> 31;
+    block_count_add(c, count);
 }
 
 // ------------------------------ discounted return ---------------------------
@@ -815,6 +871,28 @@ SynthConst synth_const(const bpg_batch *b)
     return s;
 }
 
+ResetConst reset_const(const bpg_batch *b, int enabled, const int32_t *d_num_grey)
+{
+    ResetConst rc;
+    const SynthConst s = synth_const(b);
+    rc.enabled = enabled;
+    rc.is_variation = b->info.is_variation;
+    rc.base_nobj = (uint32_t)b->info.num_objs;
+    rc.seed = s.seed;
+    rc.env_base = s.env_base;
+    rc.reset_counter = (uint32_t)b->reset_counter;
+    rc.num_grey = d_num_grey;
+    return rc;
+}
+
+int fat_grid(int64_t work_items)
+{
+    int64_t g = (work_items + 1023) / 1024;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;        // one 1024-lane block per CU; <= 256 counter atomics per launch
+    return (int)g;
+}
+
 PairTable pair_table(const bpg_variant_info &info)
 {
     PairTable t;
@@ -854,7 +932,8 @@ int check_launch(const char *what)
     return BPG_OK;
 }
 
-}  // namespace
+}  // namespace bpgk
+using namespace bpgk;
 
 // ---------------------------------------------------------------------------
 // C ABI
@@ -985,10 +1064,8 @@ int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
     DeviceGuard guard(b->device);
-    const SynthConst s = synth_const(b);
     hipLaunchKernelGGL(k_reset, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now, b->ever,
-                       b->n, b->info.is_variation, (uint32_t)b->info.num_objs, d_num_grey, d_env_mask, s.seed,
-                       s.env_base, (uint32_t)b->reset_counter);
+                       b->n, reset_const(b, 1, d_num_grey), d_env_mask);
     b->reset_counter++;
     return check_launch("k_reset");
 }
@@ -1151,68 +1228,82 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
 {
     if (!b || !a) return fail(BPG_ERR_ARG, "NULL argument");
     if (a->T < 1 || a->T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
+    if ((a->d_success_count && ((uintptr_t)a->d_success_count & 7u)) ||
+        (a->d_zero_count && ((uintptr_t)a->d_zero_count & 7u)))
+        return fail(BPG_ERR_ARG, "counters must be 8-byte aligned");
+    if (a->d_success_count && a->d_success_count == a->d_zero_count)
+        return fail(BPG_ERR_ARG, "d_zero_count must differ from d_success_count");
     DeviceGuard guard(b->device);
     const StepConst c = step_const(b);
     const SynthConst s = synth_const(b);
+    const ResetConst rc = reset_const(b, a->reset_first ? 1 : 0, a->d_num_grey);
     hipStream_t st = (hipStream_t)stream;
     uint32_t *rw = reinterpret_cast<uint32_t *>(a->d_reward_tb);
+    unsigned long long *cnt = a->d_success_count, *znext = a->d_zero_count;
     const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
+    int rcode = BPG_OK;
     if (!episode) {
         const bool vec = (b->n % 4 == 0) && aligned16(a->d_masks) && aligned16(a->d_reward_tb) &&
                          aligned4(a->d_flags_tb);
         if (vec) {
-            const dim3 grid(grid_for(b->n / 4, 256)), block(256);
+            const dim3 grid(fat_grid(b->n / 4)), block(1024);
             if (a->d_masks)
                 hipLaunchKernelGGL(k_rollout_vec4<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s);
+                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
             else
                 hipLaunchKernelGGL(k_rollout_vec4<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s);
+                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
         } else {
-            const dim3 grid(grid_for(b->n, 256)), block(256);
+            const dim3 grid(fat_grid(b->n)), block(1024);
             if (a->d_masks)
                 hipLaunchKernelGGL(k_rollout_scalar<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s);
+                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
             else
                 hipLaunchKernelGGL(k_rollout_scalar<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks,
-                                   rw, a->d_flags_tb, b->n, a->T, c, s);
+                                   rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
         }
-        return check_launch("k_rollout");
+        rcode = check_launch("k_rollout");
+    } else {
+        if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
+            (a->d_ep_success && !aligned4(a->d_ep_success)))
+            return fail(BPG_ERR_ARG, "episode buffers must be 16-byte aligned");
+        const int R = (a->T + 1) | 1;
+        const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
+        if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS history tile");
+        const PairTable tab = pair_table(b->info);
+        const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+        const bool synth = (a->d_masks == nullptr);
+        rcode = dispatch_side(b->info.side, [&](auto side) {
+            constexpr int S = decltype(side)::value;
+            const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH>)
+                                   : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS>);
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess)
+                    return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            }
+            if (synth)
+                hipLaunchKernelGGL((k_episode<S, SRC_SYNTH>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
+                                   rc, cnt, znext);
+            else
+                hipLaunchKernelGGL((k_episode<S, SRC_MASKS>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
+                                   rc, cnt, znext);
+            return BPG_OK;
+        });
+        if (rcode == BPG_OK) rcode = check_launch("k_episode");
     }
-    if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
-        (a->d_ep_success && !aligned4(a->d_ep_success)))
-        return fail(BPG_ERR_ARG, "episode buffers must be 16-byte aligned");
-    const int R = (a->T + 1) | 1;
-    const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
-    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS history tile");
-    const PairTable tab = pair_table(b->info);
-    const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
-    const bool synth = (a->d_masks == nullptr);
-    int rc = dispatch_side(b->info.side, [&](auto side) {
-        constexpr int S = decltype(side)::value;
-        const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH>)
-                               : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS>);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-        }
-        if (synth)
-            hipLaunchKernelGGL((k_episode<S, SRC_SYNTH>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                               a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab);
-        else
-            hipLaunchKernelGGL((k_episode<S, SRC_MASKS>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                               a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab);
-        return BPG_OK;
-    });
-    return rc != BPG_OK ? rc : check_launch("k_episode");
+    if (rcode == BPG_OK && a->reset_first) b->reset_counter++;
+    return rcode;
 }
 
 int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream)
 {
     if (!b || !d_count) return fail(BPG_ERR_ARG, "NULL argument");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_success_count, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
-                       b->n, d_count);
+    hipLaunchKernelGGL(k_success_count, dim3(fat_grid((b->n + 3) / 4)), dim3(1024), 0, (hipStream_t)stream,
+                       b->ever, b->n, d_count);
     return check_launch("k_success_count");
 }
 

@@ -196,9 +196,6 @@ class BatchedBlocksEnv:
         self._init_curriculum()
         self.contact_source = contact_source if contact_source is not None else SyntheticContacts()
         B, dev = self.num_envs, self.device
-        self._reward = torch.empty(B, dtype=torch.float32, device=dev)
-        self._flags = torch.empty(B, dtype=torch.uint8, device=dev)
-        self._ag = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
         self._g = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
         self.observation = torch.zeros(B, self.dimo, dtype=torch.float32, device=dev)
         _lib.check(L.bpg_get_desired_goal_f32(self._h, _ptr(self._g), self.dimg, _stream(dev)))
@@ -350,36 +347,42 @@ class BatchedBlocksEnv:
                 else:
                     contacts = (nxt[1], nxt[2])
         st = _stream(self.device)
+        # fresh output tensors every call (the reference returns copies, fetch_env.py:225-227);
+        # the kernels write straight into them, so this costs an allocation, not a copy
+        reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         if contact_masks is not None:
             m = self._to_dev(contact_masks, torch.int32) if not (
                 torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
             ) else contact_masks.to(self.device).contiguous()
             assert m.numel() == self.num_envs
-            _lib.check(self._L.bpg_step_masks(self._h, _ptr(m), _ptr(self._reward), _ptr(self._flags), st))
+            _lib.check(self._L.bpg_step_masks(self._h, _ptr(m), _ptr(reward), _ptr(flags), st))
         elif contacts is not None:
             pairs = self._to_dev(contacts[0], torch.int16)
             ncon = self._to_dev(contacts[1], torch.int32)
             assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
             _lib.check(self._L.bpg_step_contacts(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]),
-                                                 _ptr(self._reward), _ptr(self._flags), st))
+                                                 _ptr(reward), _ptr(flags), st))
         else:
-            _lib.check(self._L.bpg_step_synth(self._h, _ptr(self._reward), _ptr(self._flags), st))
+            _lib.check(self._L.bpg_step_synth(self._h, _ptr(reward), _ptr(flags), st))
         obs = self._get_obs()
-        done = (self._flags & _lib.FLAG_DONE) != 0
-        succ = (self._flags & _lib.FLAG_SUCCESS) != 0
+        done = (flags & _lib.FLAG_DONE) != 0
+        succ = (flags & _lib.FLAG_SUCCESS) != 0
         if self.scalar_api:
-            return obs, np.float32(self._reward[0].item()), bool(done[0].item()), {'is_success': bool(succ[0].item())}
-        return obs, self._reward, done, {'is_success': succ}
+            return obs, np.float32(reward[0].item()), bool(done[0].item()), {'is_success': bool(succ[0].item())}
+        return obs, reward, done, {'is_success': succ}
 
     def _get_obs(self):
         """fetch_env.py:219-228 (achieved_goal / desired_goal parts)."""
-        _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(self._ag), self.dimg, _stream(self.device)))
+        ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
+        _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), self.dimg, _stream(self.device)))
         if self.scalar_api:
             # reference dtypes (quirk Q9): float64 obs/ag, int64 goal (Variation float64)
             return {'observation': self.observation[0].double().cpu().numpy(),
-                    'achieved_goal': self._ag[0].double().cpu().numpy(),
+                    'achieved_goal': ag[0].double().cpu().numpy(),
                     'desired_goal': self.goal.copy()}
-        return {'observation': self.observation, 'achieved_goal': self._ag, 'desired_goal': self._g}
+        # achieved_goal is a fresh tensor; observation / desired_goal are the env's shared buffers
+        return {'observation': self.observation, 'achieved_goal': ag, 'desired_goal': self._g}
 
     def achieved_goal_f64(self):
         out = torch.empty(self.num_envs, self.dimg, dtype=torch.float64, device=self.device)

@@ -149,7 +149,6 @@ class RolloutStudent:
         self.reset_all_rollouts(test, num_grey=num_grey)
         ep = self._alloc_episode()
         o, ag = self.initial_o.clone(), self.initial_ag.clone()
-        ld = (T + 1) * self.dims['g']
         Qs = []
         for t in range(T):
             policy_output = self.policy.get_actions(
@@ -170,9 +169,7 @@ class RolloutStudent:
             ep['g'][:, t] = self.g
             obs, _, _, info = env.step(u)        # reward ignored: recomputed for HER (rollout.py:123-125)
             ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
-            o = obs['observation'].clone()
-            # next achieved_goal straight into its episode slot when it is the last one
-            ag = obs['achieved_goal'].clone()
+            o, ag = obs['observation'], obs['achieved_goal']
         ep['o'][:, T] = o
         ep['ag'][:, T] = ag
         self.initial_o.copy_(o)
@@ -192,7 +189,7 @@ class RolloutStudent:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device).clamp(-1, 1))
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device) if want_reward else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
-                                d_reward_tb=None if reward is None else reward.data_ptr(), d_flags_tb=None,
+                                d_reward_tb=None if reward is None else reward.data_ptr(),
                                 d_ep_ag=ep['ag'].data_ptr(), d_ep_g=ep['g'].data_ptr(),
                                 d_ep_success=ep['info_is_success'].data_ptr())
         if masks is not None:
@@ -281,7 +278,7 @@ class PGRolloutStudent(RolloutStudent):
             obs, r, _, info = env.step(u)
             reward[t] = r
             ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
-            o, ag = obs['observation'].clone(), obs['achieved_goal'].clone()
+            o, ag = obs['observation'], obs['achieved_goal']
         ep['o'][:, T], ep['ag'][:, T] = o, ag
         self.initial_o.copy_(o)
         ep['G'] = discounted_return(reward, self.gamma)

@@ -169,16 +169,20 @@ int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,
 
 /* RolloutStudent.generate_rollouts inner loop (rollout.py:100-153) for T steps
  * in ONE launch: state stays in registers, every array below is optional
- * (NULL = not produced).  Does not reset (call bpg_reset first, as
- * rollout.py:79 does). */
+ * (NULL = not produced).  With reset_first the launch also performs the
+ * reset_all_rollouts of rollout.py:79; otherwise call bpg_reset first. */
 typedef struct {
     int32_t T;
+    int32_t reset_first;       /* 1: reset every env (bpg_reset semantics) inside the launch, before step 0 */
+    const int32_t *d_num_grey; /* reset_first on Variation: explicit num_grey draws, NULL = generator */
     const uint32_t *d_masks;   /* (T, n_envs) time-major contact masks; NULL = synthetic source */
     float *d_reward_tb;        /* (T, n_envs) float32 step rewards                */
     uint8_t *d_flags_tb;       /* (T, n_envs) flags bytes                         */
     float *d_ep_ag;            /* (n_envs, T+1, dimg) episode['ag'] batch-major   */
     float *d_ep_g;             /* (n_envs, T, dimg)   episode['g']                */
     float *d_ep_success;       /* (n_envs, T, 1)      episode['info_is_success']  */
+    unsigned long long *d_success_count; /* += #envs with has_succeeded after step T (rollout.py:163-167) */
+    unsigned long long *d_zero_count;    /* optional second counter the launch sets to 0 (ping-pong) */
 } bpg_rollout_args;
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 

@@ -240,8 +240,7 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
     env2.reset(num_grey=num_grey)
     rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
     flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
-    args = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(),
-                                d_flags_tb=flg.data_ptr(), d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    args = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr())
     bpg._lib.check(L.bpg_rollout(env2._h, C.byref(args), None))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(bits(rew), exp_r)
@@ -276,6 +275,48 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
         _, r_b, d_b, i_b = e_ref.step(None, contact_masks=dm[t])
         assert torch.equal(r_a.view(torch.int32), r_b.view(torch.int32))
         assert torch.equal(env3.state_now, e_ref.state_now) and torch.equal(env3.state_ever, e_ref.state_ever)
+
+
+@pytest.mark.parametrize('env_id', ['BlocksTouchVariation-v0', 'BlocksTouch-v0'])
+@pytest.mark.parametrize('B', [8192, 1001])
+def test_single_launch_rollout_reset_and_count(env_id, B):
+    """reset_first + d_success_count inside the rollout launch == bpg_reset, then
+    bpg_rollout, then bpg_success_count; ping-pong counter zeroing."""
+    import ctypes as C
+    T = 50
+    L = bpg._lib.lib()
+    rng = np.random.RandomState(B)
+    num_grey = torch.as_tensor(rng.randint(3, size=B).astype(np.int32), device=DEV)
+    nobj = 4 + num_grey.cpu().numpy() if 'Variation' in env_id else VARIANTS[env_id]['num_objs']
+    a, b = [bpg.make(env_id, num_envs=B, device=DEV, seed=3) for _ in range(2)]
+    counts = torch.tensor([0, 12345], dtype=torch.int64, device=DEV)
+    for r in range(3):
+        dm = i32(legal_masks(rng, T, B, nobj, density=4))
+        rew_a = torch.empty((T, B), dtype=torch.float32, device=DEV)
+        rew_b = torch.empty_like(rew_a)
+        cur = r & 1
+        args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=dm.data_ptr(),
+                                    d_reward_tb=rew_a.data_ptr(),
+                                    d_success_count=counts.data_ptr() + 8 * cur,
+                                    d_zero_count=counts.data_ptr() + 8 * (1 - cur))
+        bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+        b.reset(num_grey=num_grey)
+        args_b = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew_b.data_ptr())
+        bpg._lib.check(L.bpg_rollout(b._h, C.byref(args_b), None))
+        assert torch.equal(rew_a.view(torch.int32), rew_b.view(torch.int32))
+        assert torch.equal(a.state_now, b.state_now) and torch.equal(a.state_ever, b.state_ever)
+        assert int(counts[cur].item()) == int(b.success_count().item()) == int((b.state_ever < 0).sum().item())
+        assert int(counts[1 - cur].item()) == 0
+    # the episode-writer kernel takes the same fused reset / count path
+    ag = torch.empty((B, T + 1, a.dimg), dtype=torch.float32, device=DEV)
+    counts.zero_()
+    args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=dm.data_ptr(),
+                                d_ep_ag=ag.data_ptr(), d_success_count=counts.data_ptr())
+    bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+    b.reset(num_grey=num_grey)
+    bpg._lib.check(L.bpg_rollout(b._h, C.byref(args_b), None))
+    assert torch.equal(a.state_ever, b.state_ever) and int(counts[0].item()) == int(b.success_count().item())
+    assert torch.equal(ag[:, T], b._get_obs()['achieved_goal'])
 
 
 def test_synthetic_source_matches_oracle_spec():
@@ -380,8 +421,7 @@ def test_full_size_properties():
     full.reset()
     rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
     flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
-    args = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
-                                d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+    args = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr())
     bpg._lib.check(L.bpg_rollout(full._h, C.byref(args), None))
     # (a)
     step = bpg.make(env_id, num_envs=B, device=DEV, seed=seed)
@@ -397,8 +437,7 @@ def test_full_size_properties():
     for k, h in enumerate(halves):
         h.reset()
         rw = torch.empty((T, B // 2), dtype=torch.float32, device=DEV)
-        a = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rw.data_ptr(), d_flags_tb=None,
-                                 d_ep_ag=None, d_ep_g=None, d_ep_success=None)
+        a = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rw.data_ptr())
         bpg._lib.check(L.bpg_rollout(h._h, C.byref(a), None))
         sl = slice(k * (B // 2), (k + 1) * (B // 2))
         assert torch.equal(rw.view(torch.int32), rew[:, sl].view(torch.int32))
