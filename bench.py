@@ -34,6 +34,7 @@ def parse():
     p.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU')
     p.add_argument('--T', type=int, default=50)
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--buffers', type=int, default=4, help='independent mask/output buffer sets used round-robin')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -84,17 +85,25 @@ def main():
     # rollout's episode consistent with the pre-generated contact masks
     num_grey = (torch.arange(B, device=dev, dtype=torch.int32) * 7 + rank) % 3
     env.reset(num_grey=num_grey)
-    masks = torch.empty((T, B), dtype=torch.int32, device=dev)
-    _lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(masks.data_ptr()), stream))
-    reward = torch.empty((T, B), dtype=torch.float32, device=dev)
-    flags = torch.empty((T, B), dtype=torch.uint8, device=dev)
+    # NBUF independent input/output buffer sets, used round-robin, so that no launch finds its
+    # contact masks in the 256 MiB Infinity Cache from a previous launch: inputs come from HBM
+    NBUF = a.buffers
+    masks, reward, flags = [], [], []
+    for k in range(NBUF):
+        env.seed(a.seed + k)
+        m = torch.empty((T, B), dtype=torch.int32, device=dev)
+        _lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(m.data_ptr()), stream))
+        masks.append(m)
+        reward.append(torch.empty((T, B), dtype=torch.float32, device=dev))
+        flags.append(torch.empty((T, B), dtype=torch.uint8, device=dev))
+    env.seed(a.seed)
     counts = torch.zeros(2, dtype=torch.int64, device=dev)      # ping-pong success counters
     cptr = [counts.data_ptr(), counts.data_ptr() + 8]
     # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167)
-    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks.data_ptr(),
-                             d_reward_tb=reward.data_ptr(),
-                             d_flags_tb=flags.data_ptr(), d_success_count=cptr[k], d_zero_count=cptr[1 - k])
-            for k in range(2)]
+    args = [[_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[j].data_ptr(),
+                              d_reward_tb=reward[j].data_ptr(), d_flags_tb=flags[j].data_ptr(),
+                              d_success_count=cptr[k], d_zero_count=cptr[1 - k])
+             for k in range(2)] for j in range(NBUF)]
     stats = torch.zeros(2, dtype=torch.float64, device=dev)
     stats[1] = B
 
@@ -107,7 +116,7 @@ def main():
         it[0] += 1
         if k is not None:
             ev0[k].record()
-        _lib.check(L.bpg_rollout(env._h, C.byref(args[cur]), stream))
+        _lib.check(L.bpg_rollout(env._h, C.byref(args[(it[0] - 1) % NBUF][cur]), stream))
         if k is not None:
             ev1[k].record()
         if world > 1:
@@ -155,6 +164,7 @@ def main():
                                'resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
                                'env-step' % (ENV_ID, B, T),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'parallelism': 'env-shard x%d' % world,
+                   'buffer_sets': NBUF,
                    'success_rate': succ_rate},
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout_vec4<masks>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -163,7 +173,7 @@ def main():
     }
 
     if rank == 0 and not a.no_extras:
-        out['extra'] = extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream)
+        out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
     if world > 1:

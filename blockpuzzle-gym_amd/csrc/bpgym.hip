@@ -239,6 +239,36 @@ __device__ __forceinline__ uint32_t synth_mask(uint32_t key, uint32_t t, uint32_
 
 __device__ __forceinline__ uint32_t nobj_of(uint32_t ever) { return (ever >> NOBJ_SHIFT) & 7u; }
 
+// Write-once reward / flag streams of the fused rollout use nontemporal stores:
+// they are never re-read by these kernels, and keeping them out of the L2 /
+// Infinity Cache leaves it to the inputs (tools/tune_rollout.hip: 86 vs 88 us
+// with cold inputs, 75 vs 88 us when the masks are cache-resident).  The
+// write-only episode streams stay plain stores: a pure float4 fill runs 5.1 TB/s
+// plain vs 4.8 TB/s nontemporal on MI355X, and the episode writer follows it.
+template <bool NT> __device__ __forceinline__ void st_u4(uint4 *p, uint4 v)
+{
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
+template <bool NT> __device__ __forceinline__ void st_f4(float4 *p, float4 v)
+{
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
+template <bool NT, typename V> __device__ __forceinline__ void st_1(V *p, V v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // ------------------------------ reset ---------------------------------------
 // fetch_env.py:247-255: has_succeeded = False, matrix kept (Q1);
 // Variation :646-679: matrix = -1, num_objs = 4 + num_grey.  TimeLimit: t = 0.
@@ -450,7 +480,7 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned lo
 // T steps in one launch, 4 envs per lane, state in registers.  Masks / rewards
 // are time-major (T, n) so every access is a 16-byte-per-lane coalesced stream.
 // Optionally resets first (rollout.py:79) and counts the final successes.
-template <int SRC>
+template <int SRC, bool NT>
 __global__ void __launch_bounds__(1024)
 k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
                uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
@@ -492,8 +522,9 @@ k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const ui
                     mm[k] = synth_mask(key[k], (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX, valid[k], forced[k]);
                 step_core(an[k], ee[k], mm[k], c, rb[k], fl[k]);
             }
-            if (reward_tb) rrow[(int64_t)t * nvec] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
-            if (flags_tb) frow[(int64_t)t * nvec] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+            if (reward_tb) st_u4<NT>(&rrow[(int64_t)t * nvec], make_uint4(rb[0], rb[1], rb[2], rb[3]));
+            if (flags_tb)
+                st_1<NT>(&frow[(int64_t)t * nvec], fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24));
         }
         reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
         reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
@@ -555,7 +586,7 @@ __device__ __forceinline__ float tern(uint32_t now, uint32_t ever, uint32_t p)
 // The wave's output region is contiguous, so lanes take consecutive float4
 // chunks (1 KiB per wave store); (env, row) is tracked incrementally.
 // hist[e * R + r] = (now, ever) of env e at row r, in LDS.
-template <int SIDE>
+template <int SIDE, bool NT>
 __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int nvalid, int rows,
                                                     const uint2 *hist, int R, const PairTable *tab, int lane)
 {
@@ -576,7 +607,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
             v.y = tern(h.x, h.y, (pw >> 5) & 31u);
             v.z = tern(h.x, h.y, (pw >> 10) & 31u);
             v.w = tern(h.x, h.y, (pw >> 15) & 31u);
-            o4[cidx] = v;
+            st_f4<NT>(&o4[cidx], v);
             rem += 64;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
@@ -588,7 +619,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
         for (int f = lane; f < total; f += 64) {
             const int r = rem / DIMG, k = rem - r * DIMG;
             const uint2 h = hist[e * R + r];
-            out[f] = tern(h.x, h.y, tab->flat[k]);
+            st_1<NT>(&out[f], tern(h.x, h.y, tab->flat[k]));
             rem += 64;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
@@ -641,7 +672,7 @@ k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, in
 // LDS (row stride R odd -> conflict-free ds_write_b64).  Phase 2: the wave
 // streams its contiguous slices of episode['ag'] (B,T+1,dimg), episode['g']
 // (B,T,dimg) and episode['info_is_success'] (B,T,1) as float32.
-template <int SIDE, int SRC>
+template <int SIDE, int SRC, bool NT>
 __global__ void __launch_bounds__(64)
 k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
@@ -690,7 +721,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     }
     __syncthreads();
     if (ep_ag)
-        wave_write_matrices<SIDE>(ep_ag + base * (int64_t)(T + 1) * DIMG, nvalid, T + 1, hist, R, tab, lane);
+        wave_write_matrices<SIDE, NT>(ep_ag + base * (int64_t)(T + 1) * DIMG, nvalid, T + 1, hist, R, tab, lane);
     if (ep_g) {
         // episode['g']: T copies of the constant goal row per env (rollout.py:151)
         float *o = ep_g + base * (int64_t)T * DIMG;
@@ -700,11 +731,11 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             float4 *o4 = reinterpret_cast<float4 *>(o);
             for (int cidx = lane; cidx < total / 4; cidx += 64) {
                 const int q = cidx % QPR;
-                o4[cidx] = make_float4(tab->goal[4 * q], tab->goal[4 * q + 1], tab->goal[4 * q + 2],
-                                       tab->goal[4 * q + 3]);
+                st_f4<NT>(&o4[cidx], make_float4(tab->goal[4 * q], tab->goal[4 * q + 1], tab->goal[4 * q + 2],
+                                                 tab->goal[4 * q + 3]));
             }
         } else {
-            for (int f = lane; f < total; f += 64) o[f] = tab->goal[f % DIMG];
+            for (int f = lane; f < total; f += 64) st_1<NT>(&o[f], tab->goal[f % DIMG]);
         }
     }
     if (ep_succ) {
@@ -714,7 +745,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         int e = 0, rem = lane;
         while (rem >= T) { rem -= T; e++; }
         for (int f = lane; f < total; f += 64) {
-            o[f] = (hist[e * R + rem + 1].y >> 31) ? 1.0f : 0.0f;
+            st_1<NT>(&o[f], (hist[e * R + rem + 1].y >> 31) ? 1.0f : 0.0f);
             rem += 64;
             while (rem >= T) { rem -= T; e++; }
         }
@@ -1248,10 +1279,10 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         if (vec) {
             const dim3 grid(fat_grid(b->n / 4)), block(1024);
             if (a->d_masks)
-                hipLaunchKernelGGL(k_rollout_vec4<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
+                hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
             else
-                hipLaunchKernelGGL(k_rollout_vec4<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
+                hipLaunchKernelGGL((k_rollout_vec4<SRC_SYNTH, true>), grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
         } else {
             const dim3 grid(fat_grid(b->n)), block(1024);
@@ -1275,19 +1306,19 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         const bool synth = (a->d_masks == nullptr);
         rcode = dispatch_side(b->info.side, [&](auto side) {
             constexpr int S = decltype(side)::value;
-            const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH>)
-                                   : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS>);
+            const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH, false>)
+                                   : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS, false>);
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess)
                     return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
             }
             if (synth)
-                hipLaunchKernelGGL((k_episode<S, SRC_SYNTH>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
                                    rc, cnt, znext);
             else
-                hipLaunchKernelGGL((k_episode<S, SRC_MASKS>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
+                hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
                                    rc, cnt, znext);
             return BPG_OK;
