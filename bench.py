@@ -35,6 +35,9 @@ def parse():
     p.add_argument('--T', type=int, default=50)
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--buffers', type=int, default=4, help='independent mask/output buffer sets used round-robin')
+    p.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    p.add_argument('--single-device', action='store_true',
+                   help='rehearsal only: every rank uses cuda:0 (use with --backend gloo on a 1-GPU box)')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -67,7 +70,9 @@ def main():
     import blockpuzzle_gym_amd as bpg
     from blockpuzzle_gym_amd import _lib, distributed as D
 
-    rank, world, local = D.init_from_env()
+    if a.single_device:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, world, local = D.init_from_env(backend=a.backend)
     assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     torch.cuda.set_device(local)
@@ -97,31 +102,34 @@ def main():
         reward.append(torch.empty((T, B), dtype=torch.float32, device=dev))
         flags.append(torch.empty((T, B), dtype=torch.uint8, device=dev))
     env.seed(a.seed)
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)      # ping-pong success counters
-    cptr = [counts.data_ptr(), counts.data_ptr() + 8]
-    # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167)
-    args = [[_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[j].data_ptr(),
-                              d_reward_tb=reward[j].data_ptr(), d_flags_tb=flags[j].data_ptr(),
-                              d_success_count=cptr[k], d_zero_count=cptr[1 - k])
-             for k in range(2)] for j in range(NBUF)]
-    stats = torch.zeros(2, dtype=torch.float64, device=dev)
-    stats[1] = B
-
+    # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167).
+    # Rollout i adds its success count straight into row i of `stats` = [successes, envs]; with
+    # N>1 GPUs that row is all-reduced asynchronously (RCCL runs it on its own stream, so the
+    # collective of rollout i overlaps the kernel of rollout i+1).
+    n_it = a.warmup + a.steps
+    stats = torch.zeros((n_it, 2), dtype=torch.int64, device=dev)
+    stats[:, 1] = B
+    rows = [stats[i] for i in range(n_it)]
+    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(),
+                             d_masks=masks[i % NBUF].data_ptr(), d_reward_tb=reward[i % NBUF].data_ptr(),
+                             d_flags_tb=flags[i % NBUF].data_ptr(),
+                             d_success_count=stats.data_ptr() + 16 * i) for i in range(n_it)]
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    it = [0]
+    works = []
 
-    def one_rollout(k=None):
-        cur = it[0] & 1
-        it[0] += 1
+    def one_rollout(i, k=None):
         if k is not None:
             ev0[k].record()
-        _lib.check(L.bpg_rollout(env._h, C.byref(args[(it[0] - 1) % NBUF][cur]), stream))
+        _lib.check(L.bpg_rollout(env._h, C.byref(args[i]), stream))
         if k is not None:
             ev1[k].record()
         if world > 1:
-            stats[0] = counts[cur]
-            dist.all_reduce(stats)          # the one collective per rollout (RCCL over xGMI)
+            works.append(dist.all_reduce(rows[i], async_op=True))   # the one collective per rollout
+
+    def drain():
+        while works:
+            works.pop().wait()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -129,12 +137,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        one_rollout()
+    for i in range(a.warmup):
+        one_rollout(i)
+    drain()
     fence()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        one_rollout(k)
+        one_rollout(a.warmup + k, k)
+    drain()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -142,7 +152,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)) / a.steps
-    succ_rate = float(counts[(it[0] - 1) & 1].item()) / B
+    last = stats[-1].tolist()
+    succ_rate = last[0] / last[1]            # global: the row was all-reduced when world > 1
 
     # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env packed state 8 B in + 8 B out

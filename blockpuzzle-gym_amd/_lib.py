@@ -37,6 +37,12 @@ class RolloutArgs(C.Structure):
     ]
 
 
+class PhysState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ('d_grip_pos', 'd_grip_velp', 'd_gripper_state', 'd_gripper_vel',
+                 'd_obj_pos', 'd_obj_rot', 'd_obj_velp', 'd_obj_velr')] + [('dt', C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/bpgym.h declares
 SIGNATURES = {
     'bpg_last_error': (C.c_char_p, []),
@@ -60,6 +66,8 @@ SIGNATURES = {
     'bpg_get_achieved_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_get_achieved_goal_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_get_desired_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_assemble_obs_f64': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_assemble_obs_f32': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_state_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'bpg_compute_reward_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_int, C.c_void_p]),

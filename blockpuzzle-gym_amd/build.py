@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-shared', '-fPIC',
-           '-Wall', '-o', OUT, SRC]
+           '-ffp-contract=off', '-Wall', '-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -23,6 +23,12 @@
 
 #include <hip/hip_runtime.h>
 
+// Bit-exact float64/float32 parity with the reference's NumPy arithmetic needs
+// every product and sum rounded separately: HIP's __dmul_rn/__dadd_rn are plain
+// operators, and hipcc contracts a*b+c into an fma by default.  Nothing in this
+// file is FLOP-bound, so contraction is simply off (also -ffp-contract=off in build.py).
+#pragma STDC FP_CONTRACT OFF
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -666,6 +672,62 @@ k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, in
     }
 }
 
+// ------------------------------ observation assembly ------------------------
+// obs['observation'] of _get_obs (fetch_env.py:187-228, Variation :567-621) from the
+// quantities the reference reads off the simulator.  One output element per lane
+// (coalesced stores); float64 products / differences are left unfused so the
+// result is bit-identical to the reference's NumPy arithmetic.
+struct ObsConst {
+    int32_t dimo, nb_max, is_variation;
+    int32_t colors[BPG_MAX_OBJS];
+    double dt;
+};
+
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, ObsConst oc,
+               OutT *__restrict__ out, int64_t ld)
+{
+    const int64_t total = n * oc.dimo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += stride) {
+        const int64_t e = f / oc.dimo;
+        int k = (int)(f - e * oc.dimo);
+        const int nblocks = (int)nobj_of(ever[e]) - 2;
+        double v = 0.0;
+        bool done = false;
+        if (oc.is_variation) {
+            if (k == 0) { v = (double)nblocks; done = true; }      // :580
+            k -= 1;
+        }
+        if (!done) {
+            if (k < 10) {
+                // [grip_pos, gripper_state, grip_velp * dt, gripper_vel * dt]  (:222 / :580)
+                if (k < 3) v = ph.d_grip_pos[e * 3 + k];
+                else if (k < 5) v = ph.d_gripper_state[e * 2 + (k - 3)];
+                else if (k < 8) v = __dmul_rn(ph.d_grip_velp[e * 3 + (k - 5)], oc.dt);
+                else v = __dmul_rn(ph.d_gripper_vel[e * 2 + (k - 8)], oc.dt);
+            } else {
+                const int per = oc.is_variation ? 19 : 15;
+                const int blk = (k - 10) / per, j = (k - 10) - blk * per;
+                if (blk < nblocks) {
+                    const int64_t o = (e * oc.nb_max + blk) * 3;
+                    const int grp = j / 3, c = j - grp * 3;
+                    if (j >= 15) v = (oc.colors[blk + 2] == (j - 15)) ? 1.0 : 0.0;        // one_hot_color :599
+                    else if (grp == 0) v = ph.d_obj_pos[o + c];
+                    else if (grp == 1) v = __dsub_rn(ph.d_obj_pos[o + c], ph.d_grip_pos[e * 3 + c]);   // :210
+                    else if (grp == 2) v = ph.d_obj_rot[o + c];
+                    else if (grp == 3)                                                    // :207, :211
+                        v = __dsub_rn(__dmul_rn(ph.d_obj_velp[o + c], oc.dt),
+                                      __dmul_rn(ph.d_grip_velp[e * 3 + c], oc.dt));
+                    else v = __dmul_rn(ph.d_obj_velr[o + c], oc.dt);                      // :208
+                }                                                                         // else zero padding :606-607
+            }
+        }
+        out[e * ld + (f - e * oc.dimo)] = (OutT)v;
+    }
+}
+
 // ------------------------------ episode writer ------------------------------
 // rollout.py:100-172 for one wave = 64 consecutive envs per block.  Phase 1:
 // lane = env, T fused steps, packed (now, ever) history of every step kept in
@@ -1216,6 +1278,41 @@ int bpg_get_desired_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *strea
     hipLaunchKernelGGL(k_fill_goal, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, d_out, total,
                        b->info.dimg, ld, pair_table(b->info));
     return check_launch("k_fill_goal");
+}
+
+static int assemble_obs(bpg_batch *b, const bpg_phys_state *ph, void *d_obs, int64_t ld, bool f64, void *stream)
+{
+    if (!b || !ph || !d_obs) return fail(BPG_ERR_ARG, "NULL argument");
+    if (ld < b->info.dimo) return fail(BPG_ERR_ARG, "ld must be >= dimo");
+    if (!ph->d_grip_pos || !ph->d_grip_velp || !ph->d_gripper_state || !ph->d_gripper_vel || !ph->d_obj_pos ||
+        !ph->d_obj_rot || !ph->d_obj_velp || !ph->d_obj_velr)
+        return fail(BPG_ERR_ARG, "every bpg_phys_state array is required");
+    DeviceGuard guard(b->device);
+    ObsConst oc;
+    oc.dimo = b->info.dimo;
+    oc.nb_max = b->info.num_objs - 2;
+    oc.is_variation = b->info.is_variation;
+    for (int i = 0; i < BPG_MAX_OBJS; i++) oc.colors[i] = b->info.obj_colors[i];
+    oc.dt = ph->dt;
+    const int64_t total = b->n * b->info.dimo;
+    const dim3 grid(grid_for(total, 256)), block(256);
+    if (f64)
+        hipLaunchKernelGGL(k_assemble_obs<double>, grid, block, 0, (hipStream_t)stream, b->ever, b->n, *ph, oc,
+                           static_cast<double *>(d_obs), ld);
+    else
+        hipLaunchKernelGGL(k_assemble_obs<float>, grid, block, 0, (hipStream_t)stream, b->ever, b->n, *ph, oc,
+                           static_cast<float *>(d_obs), ld);
+    return check_launch("k_assemble_obs");
+}
+
+int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream)
+{
+    return assemble_obs(b, ph, d_obs, ld, true, stream);
+}
+
+int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream)
+{
+    return assemble_obs(b, ph, d_obs, ld, false, stream);
 }
 
 int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever)

@@ -35,8 +35,9 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend == 'nccl':
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
+        if backend == 'nccl':
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local))
         else:

@@ -405,6 +405,32 @@ class BatchedBlocksEnv:
             onehot[self.info.obj_colors[i + 2]] = 1.0
             self.observation[:, off + BLOCK_BASE_FEATURES:off + BLOCK_FEATURES] = onehot[None, :] * present[:, None]
 
+    PHYS_FIELDS = ('grip_pos', 'grip_velp', 'gripper_state', 'gripper_vel',
+                   'obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')
+
+    def assemble_observation(self, phys, dt=0.04, dtype=torch.float32, out=None):
+        """_get_obs' observation vector (fetch_env.py:187-228, Variation :567-621) from a
+        physics backend's state: `phys` maps PHYS_FIELDS to float64 arrays/tensors shaped
+        (B,3),(B,3),(B,2),(B,2),(B,nb,3)x4 (euler angles in obj_rot; velocities unscaled);
+        dt = nsubsteps * timestep = 20 * 0.002 for every preset (tasks.py).  float64 output
+        is bit-identical to the reference; float32 is what rollout.py stores.  With
+        out=None and float32 the env's shared `observation` buffer is updated."""
+        t = {k: self._to_dev(phys[k], torch.float64) for k in self.PHYS_FIELDS}
+        nb = self.num_objs - 2
+        for k in ('grip_pos', 'grip_velp'):
+            assert t[k].shape == (self.num_envs, 3), k
+        for k in ('gripper_state', 'gripper_vel'):
+            assert t[k].shape == (self.num_envs, 2), k
+        for k in ('obj_pos', 'obj_rot', 'obj_velp', 'obj_velr'):
+            assert t[k].shape == (self.num_envs, nb, 3), k
+        ph = _lib.PhysState(dt=float(dt), **{'d_' + k: t[k].data_ptr() for k in self.PHYS_FIELDS})
+        if out is None:
+            out = self.observation if dtype == torch.float32 else torch.empty(
+                self.num_envs, self.dimo, dtype=torch.float64, device=self.device)
+        fn = self._L.bpg_assemble_obs_f32 if out.dtype == torch.float32 else self._L.bpg_assemble_obs_f64
+        _lib.check(fn(self._h, C.byref(ph), _ptr(out), int(out.stride(0)), _stream(self.device)))
+        return out
+
     def num_objs_per_env(self):
         return (self.state_ever >> 21) & 7
 

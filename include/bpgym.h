@@ -155,6 +155,23 @@ int bpg_get_achieved_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stre
 int bpg_get_achieved_goal_f64(bpg_batch *b, double *d_out, int64_t ld, void *stream);
 int bpg_get_desired_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream);
 
+/* obs['observation'] of _get_obs (fetch_env.py:187-228; Variation :567-621) assembled
+ * from what the reference reads off the simulator -- all float64 device arrays, as
+ * mujoco_py returns them, nb = num_objs-2 block slots per env (Variation: 4):
+ *   d_grip_pos (n,3)  get_site_xpos('robot0:grip')     d_grip_velp (n,3) get_site_xvelp, unscaled
+ *   d_gripper_state (n,2) robot_qpos[-2:]              d_gripper_vel (n,2) robot_qvel[-2:], unscaled
+ *   d_obj_pos / d_obj_rot / d_obj_velp / d_obj_velr (n,nb,3): site pos, mat2euler(site xmat),
+ *   site linear / angular velocity (unscaled);  dt = nsubsteps * timestep (fetch_env.py:190).
+ * Layout, dt scaling, relative quantities, Variation's num_blocks / colour one-hots /
+ * zero padding are produced here; the _f64 form is bit-identical to the reference. */
+typedef struct {
+    const double *d_grip_pos, *d_grip_velp, *d_gripper_state, *d_gripper_vel;
+    const double *d_obj_pos, *d_obj_rot, *d_obj_velp, *d_obj_velr;
+    double dt;
+} bpg_phys_state;
+int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream);
+int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream);
+
 /* Raw packed state, device pointers owned by the handle (zero-copy views). */
 int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);
 

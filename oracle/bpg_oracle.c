@@ -209,6 +209,44 @@ void orc_get_achieved_goal(const orc_env *e, double *out)
         out[k] = e->achieved_goal[k];
 }
 
+/* fetch_env.py:187-228: obs = [grip_pos, gripper_state, grip_velp*dt, gripper_vel*dt] +
+ * per block [pos, pos - grip_pos, euler, velp*dt - grip_velp*dt, velr*dt].
+ * Variation :567-621: leading num_blocks, per block + one_hot_color (:34-37), zero
+ * padding up to max_num_blocks = 4 blocks of 19 features. */
+int orc_get_obs(const orc_env *e, const orc_phys *p, double dt, double *obs)
+{
+    int n = 0;
+    const int num_blocks = e->num_objs - 2;
+    double grip_velp[3], gripper_vel[2];
+    for (int c = 0; c < 3; c++) grip_velp[c] = p->grip_velp[c] * dt;        /* :191 */
+    for (int c = 0; c < 2; c++) gripper_vel[c] = p->gripper_vel[c] * dt;    /* :197 */
+    if (e->is_variation) obs[n++] = (double)num_blocks;                     /* :580 */
+    for (int c = 0; c < 3; c++) obs[n++] = p->grip_pos[c];
+    for (int c = 0; c < 2; c++) obs[n++] = p->gripper_state[c];
+    for (int c = 0; c < 3; c++) obs[n++] = grip_velp[c];
+    for (int c = 0; c < 2; c++) obs[n++] = gripper_vel[c];
+    for (int i = 0; i < num_blocks; i++) {
+        const double *pos = p->obj_pos + 3 * i, *rot = p->obj_rot + 3 * i;
+        double velp[3], velr[3];
+        for (int c = 0; c < 3; c++) {
+            velp[c] = p->obj_velp[3 * i + c] * dt;                           /* :207 */
+            velr[c] = p->obj_velr[3 * i + c] * dt;                           /* :208 */
+        }
+        for (int c = 0; c < 3; c++) velp[c] -= grip_velp[c];                 /* :211 */
+        for (int c = 0; c < 3; c++) obs[n++] = pos[c];
+        for (int c = 0; c < 3; c++) obs[n++] = pos[c] - p->grip_pos[c];      /* :210 */
+        for (int c = 0; c < 3; c++) obs[n++] = rot[c];
+        for (int c = 0; c < 3; c++) obs[n++] = velp[c];
+        for (int c = 0; c < 3; c++) obs[n++] = velr[c];
+        if (e->is_variation)
+            for (int c = 0; c < ORC_NUM_COLORS; c++)
+                obs[n++] = (e->obj_colors[i + 2] == c) ? 1.0 : 0.0;          /* :599 */
+    }
+    if (e->is_variation)
+        for (int k = 0; k < 19 * (4 - num_blocks); k++) obs[n++] = 0.0;      /* :606-607 */
+    return n;
+}
+
 static float reward_of_state(const orc_env *e)
 {
     double g[ORC_MAX_G];

@@ -104,6 +104,17 @@ void orc_env_step_mask(orc_env *e, uint32_t mask, float *reward, int *done, int 
 /* achieved_goal as _get_obs returns it (fetch_env.py:220 / :610-613). */
 void orc_get_achieved_goal(const orc_env *e, double *out);
 
+/* What _get_obs reads from the simulator (all float64, as mujoco_py returns them):
+ * site pos / linear velocity of robot0:grip, the last two robot joint positions and
+ * velocities, and per block the site pos, euler angles (rotations.mat2euler of the site
+ * matrix -- third-party, passed in), linear and angular site velocities. */
+typedef struct {
+    const double *grip_pos, *grip_velp, *gripper_state, *gripper_vel;   /* 3,3,2,2 */
+    const double *obj_pos, *obj_rot, *obj_velp, *obj_velr;              /* [nblocks][3] */
+} orc_phys;
+/* fetch_env.py:187-228 (Variation :567-621): obs['observation'].  Returns its length. */
+int orc_get_obs(const orc_env *e, const orc_phys *p, double dt, double *obs);
+
 /* pair index of unordered pair (i,j), i,j < 6: row-major upper triangle
  * including the diagonal (build-defined packing, 21 pairs). */
 int orc_pair_index(int i, int j);

@@ -20,6 +20,12 @@ VARIANTS = {
 }
 
 
+class Phys(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in
+                ('grip_pos', 'grip_velp', 'gripper_state', 'gripper_vel',
+                 'obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')]
+
+
 class Env(C.Structure):
     _fields_ = [
         ('variant', C.c_int), ('num_objs', C.c_int), ('side', C.c_int),
@@ -65,6 +71,7 @@ def lib():
                                    P(C.c_float), P(C.c_int), P(C.c_int)]
         L.orc_env_step_mask.argtypes = [P(Env), C.c_uint32, P(C.c_float), P(C.c_int), P(C.c_int)]
         L.orc_get_achieved_goal.argtypes = [P(Env), P(C.c_double)]
+        L.orc_get_obs.argtypes = [P(Env), P(Phys), C.c_double, P(C.c_double)]
         L.orc_pair_index.argtypes = [C.c_int, C.c_int]
         L.orc_contacts_to_mask.argtypes = [P(C.c_int), P(C.c_int), C.c_int]
         L.orc_contacts_to_mask.restype = C.c_uint32
@@ -119,6 +126,14 @@ class OracleEnv:
         self.L.orc_env_step(C.byref(self.e), _p(id2obj, C.c_int), _p(con, C.c_int), len(con),
                             C.byref(r), C.byref(d), C.byref(s))
         return self.achieved_goal(), np.float32(r.value), bool(d.value), bool(s.value)
+
+    def get_obs(self, phys, dt):
+        """phys: dict of float64 arrays named as Phys fields (one env).  Returns observation."""
+        keep = {k: np.ascontiguousarray(phys[k], np.float64) for k, _ in Phys._fields_}
+        ph = Phys(**{k: _p(v, C.c_double) for k, v in keep.items()})
+        out = np.zeros(128)
+        n = self.L.orc_get_obs(C.byref(self.e), C.byref(ph), float(dt), _p(out, C.c_double))
+        return out[:n].copy()
 
     def step_mask(self, mask):
         r, d, s = C.c_float(), C.c_int(), C.c_int()

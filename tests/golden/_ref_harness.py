@@ -112,6 +112,24 @@ class FakeData:
         self.grip = GRIP_XPOS0.copy()
         self.mocap_pos = np.zeros(3)
         self.mocap_quat = np.zeros(4)
+        # "rich" mode: every site / robot quantity _get_obs reads is a fresh seeded random
+        # value per step, so the reference's observation ASSEMBLY is exercised on
+        # non-trivial inputs (the values themselves are physics stand-ins)
+        self.rich = None
+        self.sites = {}
+        self.robot = (np.zeros(15), np.zeros(15))
+
+    def regenerate(self):
+        if self.rich is not None:
+            self.sites = {}
+            self.robot = (self.rich.normal(size=15), self.rich.normal(size=15))
+
+    def _site(self, name):
+        if name not in self.sites:
+            r = self.rich
+            self.sites[name] = dict(xpos=r.uniform(-1, 2, size=3), xmat=r.normal(size=(3, 3)),
+                                    xvelp=r.normal(size=3), xvelr=r.normal(size=3))
+        return self.sites[name]
 
     def set_joint_qpos(self, name, value):
         self.qpos[name] = np.array(value, dtype=np.float64).copy()
@@ -126,18 +144,20 @@ class FakeData:
         self.mocap_quat = np.array(v, dtype=np.float64)
 
     def get_site_xpos(self, name):
+        if self.rich is not None:
+            return self._site(name)['xpos'].copy()
         if name == 'robot0:grip':
             return self.grip
         return np.array(self.qpos[name + ':joint'][:3])
 
     def get_site_xmat(self, name):
-        return np.eye(3)
+        return self._site(name)['xmat'].copy() if self.rich is not None else np.eye(3)
 
     def get_site_xvelp(self, name):
-        return np.zeros(3)
+        return self._site(name)['xvelp'].copy() if self.rich is not None else np.zeros(3)
 
     def get_site_xvelr(self, name):
-        return np.zeros(3)
+        return self._site(name)['xvelr'].copy() if self.rich is not None else np.zeros(3)
 
 
 class FakeSim:
@@ -152,6 +172,7 @@ class FakeSim:
         self.n_forward = 0
 
     def step(self):
+        self.data.regenerate()
         if self.script is not None:
             pairs = self.script()
             assert len(pairs) <= FakeData.MAXCON
@@ -169,6 +190,7 @@ class FakeSim:
     def set_state(self, st):
         self.data.qpos = copy.deepcopy(st[0])
         self.data.grip = st[1].copy()
+        self.data.regenerate()
 
 
 class FakeTextureModder:
@@ -278,8 +300,12 @@ def install():
         ctrl_set_action=lambda sim, action: None,
         mocap_set_action=mocap_set_action,
         reset_mocap_welds=lambda sim: None,
-        robot_get_obs=lambda sim: (np.zeros(15), np.zeros(15)))
-    rotations = _mod('gym.envs.robotics.rotations', mat2euler=lambda m: np.zeros(3))
+        robot_get_obs=lambda sim: (sim.data.robot[0].copy(), sim.data.robot[1].copy()))
+    # mat2euler stand-in: a deterministic function of the matrix (its first row) in rich
+    # mode, so the fixture can hand the same "euler angles" to the build's assembly kernel
+    rotations = _mod('gym.envs.robotics.rotations',
+                     mat2euler=lambda m: np.asarray(m)[0].copy() if np.any(np.asarray(m) != np.eye(3))
+                     else np.zeros(3))
     gym.envs.robotics = _mod('gym.envs.robotics', utils=robotics_utils, rotations=rotations)
 
     mj = _mod('mujoco_py',

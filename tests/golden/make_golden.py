@@ -169,6 +169,51 @@ def step_trace(env_id, seed, lens, test_eps=()):
     return out
 
 
+def obs_trace(env_id, seed, n_eps=3, n_steps=6):
+    """Reference _get_obs assembly (fetch_env.py:187-228, Variation :567-621) on seeded random
+    site / robot values.  Records the raw inputs the reference read and the observation."""
+    env = H.make(env_id)
+    u = env.unwrapped
+    log = []
+    attach_scripts(env, seed, log)
+    sims = getattr(u, 'sims', None) or [u.sim]
+    rich = np.random.RandomState(seed + 7)
+    for sim in sims + [u.sim]:
+        sim.data.rich = rich
+    np.random.seed(seed)
+    env.seed(seed)
+    NB = 4 if 'Variation' in env_id else u.num_objs - 2
+    rows = dict(grip_pos=[], grip_velp=[], gripper_state=[], gripper_vel=[], obj_pos=[], obj_rot=[],
+                obj_velp=[], obj_velr=[], num_objs=[], obs=[])
+
+    def record(obs):
+        d = u.sim.data
+        nb = u.num_objs - 2
+        rows['grip_pos'].append(d.sites['robot0:grip']['xpos'])
+        rows['grip_velp'].append(d.sites['robot0:grip']['xvelp'])
+        rows['gripper_state'].append(d.robot[0][-2:])
+        rows['gripper_vel'].append(d.robot[1][-2:])
+        z = np.zeros((NB, 3))
+        pos, rot, velp, velr = z.copy(), z.copy(), z.copy(), z.copy()
+        for i in range(nb):
+            st = d.sites['object%d' % i]
+            pos[i], rot[i], velp[i], velr[i] = st['xpos'], st['xmat'][0], st['xvelp'], st['xvelr']
+        rows['obj_pos'].append(pos); rows['obj_rot'].append(rot)
+        rows['obj_velp'].append(velp); rows['obj_velr'].append(velr)
+        rows['num_objs'].append(u.num_objs)
+        rows['obs'].append(obs['observation'])
+
+    arng = np.random.RandomState(seed)
+    for _ in range(n_eps):
+        record(env.reset())
+        for _ in range(n_steps):
+            o, _, _, _ = env.step(arng.uniform(-1, 1, size=4))
+            record(o)
+    out = {k: np.asarray(v) for k, v in rows.items()}
+    out['dt'] = np.float64(u.sim.nsubsteps * u.sim.model.opt.timestep)
+    return out
+
+
 def compute_reward_cases(rng):
     """The reference's vectorised compute_reward on ternary inputs
     (config.py:110-111 call shape: (batch, N^2) in, (batch,) float32 out)."""
@@ -323,6 +368,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'trace_%s.npz' % eid.split('-')[0]), **tr)
 
     np.savez_compressed(os.path.join(HERE, 'compute_reward.npz'), **compute_reward_cases(rng))
+    for k, eid in enumerate(ENV_IDS):
+        np.savez_compressed(os.path.join(HERE, 'obs_%s.npz' % eid.split('-')[0]), **obs_trace(eid, 300 + k))
 
     for k, eid in enumerate(ENV_IDS):
         can_test = variants[eid]['set_test'] == 'ok'

@@ -173,3 +173,20 @@ def test_synth_mask_properties():
     m4 = O.synth_masks(7, np.arange(512), 4, 4)
     valid4 = sum(1 << L.orc_pair_index(i, j) for i in range(4) for j in range(i + 1, 4))
     assert ((m4 & ~np.uint32(valid4)) == 0).all()
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_observation_assembly(env_id):
+    """Reference _get_obs (fetch_env.py:187-228, Variation :567-621) on seeded random site /
+    robot values: layout, dt scaling, relative quantities, Variation one-hots + padding.
+    Bit-exact float64.  (mat2euler is third-party: the fixture passes euler angles in.)"""
+    d = np.load(os.path.join(G, 'obs_%s.npz' % short(env_id)))
+    e = O.OracleEnv(env_id)
+    assert d['obs'].shape[1] == VARIANTS[env_id]['dimo']
+    for k in range(len(d['obs'])):
+        e.e.num_objs = int(d['num_objs'][k])
+        nb = e.e.num_objs - 2
+        phys = {f: d[f][k] for f in ('grip_pos', 'grip_velp', 'gripper_state', 'gripper_vel')}
+        phys.update({f: d[f][k][:nb] for f in ('obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')})
+        got = e.get_obs(phys, float(d['dt']))
+        np.testing.assert_array_equal(got.view(np.uint64), d['obs'][k].view(np.uint64))
