@@ -246,6 +246,13 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
     res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 16), B * T)
 
+    # (3b) compact outputs: flags alone (bit2 encodes the reward) -> mask 4 in + flags 1 out per env-step
+    a2c = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_flags_tb=flags.data_ptr())
+
+    def compact():
+        _lib.check(L.bpg_rollout(env._h, C.byref(a2c), stream))
+    res['rollout_masks_flags_only'] = line(timed(compact, 20), B * (T * 5 + 16), B * T)
+
     # (4) episode writer: float32 episode['ag'] (B,T+1,36), ['g'] (B,T,36), ['info_is_success'] (B,T,1)
     try:
         dimg = env.dimg

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libbpgym.so')
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ATTRIBUTE = 0, -1, -2, -3, -4
 MAX_OBJS, NUM_PAIRS, MAX_GEOMS, MAX_MODELS = 6, 21, 64, 3
-FLAG_SUCCESS, FLAG_DONE = 1, 2
+FLAG_SUCCESS, FLAG_DONE, FLAG_STEP_OK = 1, 2, 4
 
 
 class VariantInfo(C.Structure):
@@ -43,6 +43,14 @@ class PhysState(C.Structure):
                  'd_obj_pos', 'd_obj_rot', 'd_obj_velp', 'd_obj_velr')] + [('dt', C.c_double)]
 
 
+class PlacementArgs(C.Structure):
+    _fields_ = [('grip_x', C.c_double), ('grip_y', C.c_double), ('obj_range', C.c_double),
+                ('max_obj_range', C.c_double), ('wrong_obj_range', C.c_double),
+                ('test', C.c_int32), ('challenge', C.c_int32),
+                ('d_eu', C.c_void_p), ('n_eu', C.c_int32), ('d_gz', C.c_void_p), ('n_gz', C.c_int32),
+                ('d_gu', C.c_void_p), ('n_gu', C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/bpgym.h declares
 SIGNATURES = {
     'bpg_last_error': (C.c_char_p, []),
@@ -68,6 +76,7 @@ SIGNATURES = {
     'bpg_get_desired_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_assemble_obs_f64': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_assemble_obs_f32': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_randomize_objects': (C.c_int, [C.c_void_p, C.POINTER(PlacementArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_state_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'bpg_compute_reward_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_int, C.c_void_p]),

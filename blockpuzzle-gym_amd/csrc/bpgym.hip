@@ -208,7 +208,7 @@ __device__ __forceinline__ void step_core(uint32_t &now, uint32_t &ever, uint32_
     now = cm | (elapsed << ELAPSED_SHIFT);
     ever = (ev & ~SUCC_BIT) | (succ << 31);
     rbits = ok ? RBITS_OK : RBITS_FAIL;
-    flags = succ | ((elapsed >= c.max_steps) ? (uint32_t)BPG_FLAG_DONE : 0u);
+    flags = succ | ((elapsed >= c.max_steps) ? (uint32_t)BPG_FLAG_DONE : 0u) | (ok ? (uint32_t)BPG_FLAG_STEP_OK : 0u);
 }
 
 // build-defined counter-based contact source (DESIGN.md "synthetic contacts"):
@@ -725,6 +725,186 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
             }
         }
         out[e * ld + (f - e * oc.dimo)] = (OutT)v;
+    }
+}
+
+// ------------------------------ reset placement -----------------------------
+// _randomize_objects of the five env classes (fetch_env.py:328-336, 370-399, 448-517,
+// 697-764, 777-787): rejection-sampled xy positions of the cubes, one env per lane.
+// Draws arrive as standard variates in the reference's consumption order (per-env
+// np_random stream `eu`, global np.random stream `gz`/`gu`), or are
+// generated on the fly from the counter-based generator when the arrays are NULL.
+struct PlaceConst {
+    int32_t variant, is_variation, nb_max, test, challenge;
+    double grip_x, grip_y, obj_range, max_obj_range, wrong_obj_range;
+    const double *eu, *gz, *gu;
+    int32_t n_eu, n_gz, n_gu;
+    uint32_t seed, env_base, reset_counter;
+};
+
+struct Draws {
+    const double *eu, *gz, *gu;
+    int n_eu, n_gz, n_gu, ie, iz, iu, fail;
+    uint32_t key;
+    bool synth;
+    double z_spare;
+    bool has_spare;
+
+    __device__ __forceinline__ double u53(uint32_t stream, uint32_t ctr)
+    {
+        // counter-based uniform in [0,1) with 53 random bits (build-defined)
+        const uint32_t a = hash32(key + stream + 2u * ctr * 0x9E3779B9U);
+        const uint32_t b = hash32(key + stream + (2u * ctr + 1u) * 0x9E3779B9U);
+        return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    __device__ __forceinline__ double next_eu()
+    {
+        if (synth) return u53(0x1000193u, (uint32_t)ie++);
+        if (ie >= n_eu) { fail = 1; return 0.5; }
+        return eu[ie++];
+    }
+    __device__ __forceinline__ double next_gu()
+    {
+        if (synth) return u53(0x2000193u, (uint32_t)iu++);
+        if (iu >= n_gu) { fail = 1; return 0.5; }
+        return gu[iu++];
+    }
+    __device__ __forceinline__ double next_gz()
+    {
+        if (synth) {
+            if (has_spare) { has_spare = false; return z_spare; }
+            const double u1 = u53(0x3000193u, (uint32_t)iz), u2 = u53(0x4000193u, (uint32_t)iz);
+            iz++;
+            const double r = sqrt(-2.0 * log(1.0 - u1));          // Box-Muller
+            z_spare = r * sinpi(2.0 * u2);
+            has_spare = true;
+            return r * cospi(2.0 * u2);
+        }
+        if (iz >= n_gz) { fail = 1; return 1.0; }
+        return gz[iz++];
+    }
+};
+
+// RandomState.uniform(low, high) = low + (high - low) * random_sample()
+__device__ __forceinline__ double unif(double lo, double hi, double u) { return lo + (hi - lo) * u; }
+// np.linalg.norm of a 2-vector = sqrt(x.dot(x)); the 2-element ddot is fma(y, y, x*x) in the
+// NumPy build the fixtures were recorded with (BLAS dependent in general)
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }
+// fetch_env.py:19-32 constants in Python evaluation order
+__device__ __forceinline__ bool out_of_table(double x, double y)
+{
+    const double TABLE_W = 0.25 - 0.05 / 2, TABLE_H = 0.35 - 0.05 / 2;
+    const double TABLE_X = 1.05 + 0.25, TABLE_Y = 0.40 + 0.35;
+    return fabs(x - TABLE_X) > TABLE_W || fabs(y - TABLE_Y) > TABLE_H;
+}
+// direction = normal(size=2) / norm; mag = uniform(lo, hi); centre + direction * mag
+__device__ __forceinline__ void polar_about(Draws &d, double cx, double cy, double lo, double hi, double &x, double &y)
+{
+    double dx = d.next_gz(), dy = d.next_gz();
+    const double n = norm2(dx, dy);
+    dx = dx / n; dy = dy / n;
+    const double mag = unif(lo, hi, d.next_gu());
+    x = cx + dx * mag;
+    y = cy + dy * mag;
+}
+
+constexpr int PLACE_MAX_ITERS = 100000;     // every rejection loop is bounded (exit condition for all waves)
+
+__global__ void __launch_bounds__(256)
+k_randomize_objects(const uint32_t *__restrict__ ever, int64_t n, PlaceConst pc, double *__restrict__ xy,
+                    int32_t *__restrict__ status)
+{
+    const double MIN_BLOCK_DIST = 1.5 * 0.05;
+    const double TABLE_W = 0.25 - 0.05 / 2, TABLE_H = 0.35 - 0.05 / 2;
+    const double TABLE_X = 1.05 + 0.25, TABLE_Y = 0.40 + 0.35;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Draws d;
+        d.synth = (pc.eu == nullptr);
+        d.eu = pc.eu ? pc.eu + i * pc.n_eu : nullptr;
+        d.gz = pc.gz ? pc.gz + i * pc.n_gz : nullptr;
+        d.gu = pc.gu ? pc.gu + i * pc.n_gu : nullptr;
+        d.n_eu = pc.n_eu; d.n_gz = pc.n_gz; d.n_gu = pc.n_gu;
+        d.ie = d.iz = d.iu = d.fail = 0;
+        d.has_spare = false; d.z_spare = 0.0;
+        d.key = hash32(synth_key(pc.seed ^ 0x51ED270BU, pc.env_base + (uint32_t)i) + pc.reset_counter);
+        double *o = xy + i * pc.nb_max * 2;
+        const double gx = pc.grip_x, gy = pc.grip_y;
+        double x, y;
+        int it = 0;
+        if (pc.variant == BPG_GRIPPER_TOUCH || pc.variant == BPG_TOPPLE_TOWER) {
+            x = gx; y = gy;
+            while (!d.fail && it++ < PLACE_MAX_ITERS && norm2(x - gx, y - gy) < 0.1) {
+                x = gx + unif(-pc.obj_range, pc.obj_range, d.next_eu());
+                y = gy + unif(-pc.obj_range, pc.obj_range, d.next_eu());
+            }
+            for (int k = 0; k < pc.nb_max; k++) { o[2 * k] = x; o[2 * k + 1] = y; }
+        } else if (pc.variant == BPG_BLOCKS_TOUCH || pc.variant == BPG_BLOCKS_TOUCH_CURRICULUM) {
+            const double r = pc.test ? pc.max_obj_range : pc.obj_range;
+            const double x0 = gx + unif(-r / 2, r / 2, d.next_eu());
+            const double y0 = gy + unif(-r / 2, r / 2, d.next_eu());
+            do {
+                polar_about(d, x0, y0, MIN_BLOCK_DIST, r, x, y);
+            } while (!d.fail && it++ < PLACE_MAX_ITERS && out_of_table(x, y));
+            o[0] = x0; o[1] = y0; o[2] = x; o[3] = y;
+        } else if (pc.variant == BPG_BLOCKS_TOUCH_CHOOSE || pc.variant == BPG_BLOCKS_TOUCH_CHOOSE_CURRICULUM) {
+            double r, wrong_r, max_wrong, min_r;
+            if (pc.test || pc.challenge) { r = pc.max_obj_range; wrong_r = 0; }
+            else { r = pc.obj_range; wrong_r = pc.wrong_obj_range; }
+            if (pc.challenge) { max_wrong = 0.04; min_r = 0.15; }
+            else { min_r = MIN_BLOCK_DIST; max_wrong = pc.max_obj_range; }
+            double bx, by, qx, qy;
+            do {
+                bx = gx + unif(-r / 2, r / 2, d.next_eu());
+                by = gy + unif(-r / 2, r / 2, d.next_eu());
+            } while (!d.fail && it++ < PLACE_MAX_ITERS && out_of_table(bx, by));
+            do {
+                polar_about(d, bx, by, min_r, r, qx, qy);
+            } while (!d.fail && it++ < PLACE_MAX_ITERS && out_of_table(qx, qy));
+            const double cx = (bx + qx) / 2.0, cy = (by + qy) / 2.0;
+            do {
+                polar_about(d, cx, cy, wrong_r, max_wrong, x, y);
+            } while (!d.fail && it++ < PLACE_MAX_ITERS &&
+                     (out_of_table(x, y) || norm2(x - bx, y - by) < MIN_BLOCK_DIST ||
+                      norm2(x - qx, y - qy) < MIN_BLOCK_DIST));
+            o[2] = bx; o[3] = by;       // blue  = block 1
+            o[0] = qx; o[1] = qy;       // green = block 0
+            o[4] = x;  o[5] = y;        // grey  = block 2
+        } else {                        // Variation
+            const int num_blocks = (int)nobj_of(ever[i]) - 2;
+            const double r = pc.test ? pc.max_obj_range : pc.obj_range;
+            double px[4], py[4];
+            double bx, by, qx, qy;
+            do {
+                bx = gx + unif(-r / 2, r / 2, d.next_eu());
+                by = gy + unif(-r / 2, r / 2, d.next_eu());
+            } while (!d.fail && it++ < PLACE_MAX_ITERS && out_of_table(bx, by));
+            do {
+                polar_about(d, bx, by, MIN_BLOCK_DIST, r, qx, qy);
+            } while (!d.fail && it++ < PLACE_MAX_ITERS && out_of_table(qx, qy));
+            o[2] = bx; o[3] = by; o[0] = qx; o[1] = qy;
+            px[0] = bx; py[0] = by; px[1] = qx; py[1] = qy;
+            int np_ = 2;
+#pragma unroll
+            for (int b = 2; b < 4; b++) {
+                if (b < num_blocks) {
+                    bool again;
+                    do {
+                        x = TABLE_X + unif(-TABLE_W, TABLE_W, d.next_eu());
+                        y = TABLE_Y + unif(-TABLE_H, TABLE_H, d.next_eu());
+                        bool hit = false;
+                        for (int k = 0; k < 3; k++)
+                            if (k < np_ && !hit && norm2(x - px[k], y - py[k]) < MIN_BLOCK_DIST) hit = true;
+                        again = hit ? true : out_of_table(x, y);
+                    } while (!d.fail && it++ < PLACE_MAX_ITERS && again);
+                    o[2 * b] = x; o[2 * b + 1] = y;
+                    px[b] = x; py[b] = y;
+                    np_ = b + 1;
+                }
+            }
+        }
+        if (it >= PLACE_MAX_ITERS) d.fail = 1;
+        if (status) status[i] = d.fail;
     }
 }
 
@@ -1313,6 +1493,35 @@ int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, 
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream)
 {
     return assemble_obs(b, ph, d_obs, ld, false, stream);
+}
+
+int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_xy, int32_t *d_status, void *stream)
+{
+    if (!b || !a || !d_xy) return fail(BPG_ERR_ARG, "NULL argument");
+    const bool explicit_draws = a->d_eu || a->d_gz || a->d_gu;
+    if (explicit_draws) {
+        if (!a->d_eu || a->n_eu < 1) return fail(BPG_ERR_ARG, "d_eu / n_eu required with explicit variates");
+        const bool needs_g = b->info.variant != BPG_GRIPPER_TOUCH && b->info.variant != BPG_TOPPLE_TOWER;
+        if (needs_g && (!a->d_gz || !a->d_gu || a->n_gz < 2 || a->n_gu < 1))
+            return fail(BPG_ERR_ARG, "d_gz / d_gu required for this variant");
+    }
+    DeviceGuard guard(b->device);
+    const SynthConst s = synth_const(b);
+    PlaceConst pc;
+    pc.variant = b->info.variant;
+    pc.is_variation = b->info.is_variation;
+    pc.nb_max = b->info.num_objs - 2;
+    pc.test = a->test;
+    pc.challenge = a->challenge;
+    pc.grip_x = a->grip_x; pc.grip_y = a->grip_y;
+    pc.obj_range = a->obj_range; pc.max_obj_range = a->max_obj_range; pc.wrong_obj_range = a->wrong_obj_range;
+    pc.eu = explicit_draws ? a->d_eu : nullptr;
+    pc.gz = a->d_gz; pc.gu = a->d_gu;
+    pc.n_eu = a->n_eu; pc.n_gz = a->n_gz; pc.n_gu = a->n_gu;
+    pc.seed = s.seed; pc.env_base = s.env_base; pc.reset_counter = (uint32_t)b->reset_counter;
+    hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
+                       b->n, pc, d_xy, d_status);
+    return check_launch("k_randomize_objects");
 }
 
 int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever)

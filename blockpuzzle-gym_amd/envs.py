@@ -332,8 +332,10 @@ class BatchedBlocksEnv:
             self._fill_static_observation()
         return self._get_obs()
 
-    def step(self, action, contact_masks=None, contacts=None):
-        """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info)."""
+    def step(self, action, contact_masks=None, contacts=None, ag_out=None):
+        """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info).
+        ag_out: optional (B, dimg) float32 view with unit inner stride (e.g. a time slot of
+        a batch-major episode buffer) that receives obs['achieved_goal'] directly."""
         a = self._to_dev(action, torch.float32)
         if a is not None:
             a = a.reshape(self.num_envs, self.dimu)
@@ -365,17 +367,21 @@ class BatchedBlocksEnv:
                                                  _ptr(reward), _ptr(flags), st))
         else:
             _lib.check(self._L.bpg_step_synth(self._h, _ptr(reward), _ptr(flags), st))
-        obs = self._get_obs()
+        obs = self._get_obs(ag_out)
         done = (flags & _lib.FLAG_DONE) != 0
         succ = (flags & _lib.FLAG_SUCCESS) != 0
         if self.scalar_api:
             return obs, np.float32(reward[0].item()), bool(done[0].item()), {'is_success': bool(succ[0].item())}
         return obs, reward, done, {'is_success': succ}
 
-    def _get_obs(self):
+    def _get_obs(self, ag_out=None):
         """fetch_env.py:219-228 (achieved_goal / desired_goal parts)."""
-        ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
-        _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), self.dimg, _stream(self.device)))
+        if ag_out is None:
+            ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
+        else:
+            ag = ag_out
+            assert ag.shape == (self.num_envs, self.dimg) and ag.dtype == torch.float32 and ag.stride(1) == 1
+        _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), int(ag.stride(0)), _stream(self.device)))
         if self.scalar_api:
             # reference dtypes (quirk Q9): float64 obs/ag, int64 goal (Variation float64)
             return {'observation': self.observation[0].double().cpu().numpy(),
@@ -430,6 +436,32 @@ class BatchedBlocksEnv:
         fn = self._L.bpg_assemble_obs_f32 if out.dtype == torch.float32 else self._L.bpg_assemble_obs_f64
         _lib.check(fn(self._h, C.byref(ph), _ptr(out), int(out.stride(0)), _stream(self.device)))
         return out
+
+    def randomize_objects(self, test=False, grip_xy=(1.3419, 0.7491), variates=None, out=None):
+        """_randomize_objects for the whole batch (fetch_env.py:328-336, 370-399, 448-517,
+        697-764, 777-787): (B, nb, 2) float64 cube positions for the physics backend, using the
+        env's current curriculum state (obj_range, ...).  grip_xy = initial_gripper_xpos[:2]
+        (a physics output; the default is the settled Fetch gripper position).  variates:
+        optional dict eu (B,n_eu), gz (B,n_gz), gu (B,n_gu) of explicit standard draws in the
+        reference's order; default = the counter-based generator.  Returns (xy, status)."""
+        nb = self.num_objs - 2
+        if out is None:
+            out = torch.full((self.num_envs, nb, 2), float('nan'), dtype=torch.float64, device=self.device)
+        status = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        a = _lib.PlacementArgs(grip_x=float(grip_xy[0]), grip_y=float(grip_xy[1]), obj_range=float(self.obj_range),
+                               max_obj_range=float(getattr(self, 'max_obj_range', 0.0)),
+                               wrong_obj_range=float(getattr(self, 'wrong_obj_range', 0.0)),
+                               test=int(bool(test)), challenge=int(bool(getattr(self, 'challenge', False))))
+        keep = []
+        if variates is not None:
+            for k in ('eu', 'gz', 'gu'):
+                t = self._to_dev(variates[k], torch.float64)
+                assert t.dim() == 2 and t.shape[0] == self.num_envs
+                keep.append(t)
+                setattr(a, 'd_' + k, t.data_ptr())
+                setattr(a, 'n_' + k, int(t.shape[1]))
+        _lib.check(self._L.bpg_randomize_objects(self._h, C.byref(a), _ptr(out), _ptr(status), _stream(self.device)))
+        return out, status
 
     def num_objs_per_env(self):
         return (self.state_ever >> 21) & 7

@@ -148,9 +148,13 @@ class RolloutStudent:
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
         ep = self._alloc_episode()
-        o, ag = self.initial_o.clone(), self.initial_ag.clone()
+        # o / ag of step t ARE the episode's time slot t (rollout.py:144-153 appends copies):
+        # the env writes the next achieved_goal straight into slot t+1
+        ep['o'][:, 0] = self.initial_o
+        ep['ag'][:, 0] = self.initial_ag
         Qs = []
         for t in range(T):
+            o, ag = ep['o'][:, t], ep['ag'][:, t]
             policy_output = self.policy.get_actions(
                 *self._policy_in(o, ag, self.g),
                 compute_Q=self.compute_Q,
@@ -163,16 +167,13 @@ class RolloutStudent:
             else:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
-            ep['o'][:, t] = o
-            ep['ag'][:, t] = ag
             ep['u'][:, t] = u
-            ep['g'][:, t] = self.g
-            obs, _, _, info = env.step(u)        # reward ignored: recomputed for HER (rollout.py:123-125)
-            ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
-            o, ag = obs['observation'], obs['achieved_goal']
-        ep['o'][:, T] = o
-        ep['ag'][:, T] = ag
-        self.initial_o.copy_(o)
+            # reward ignored: recomputed for HER (rollout.py:123-125)
+            obs, _, _, info = env.step(u, ag_out=ep['ag'][:, t + 1])
+            ep['info_is_success'][:, t, 0] = info['is_success']
+            ep['o'][:, t + 1] = obs['observation']
+        ep['g'][:] = self.g[:, None, :]           # the goal is constant over the episode (rollout.py:151)
+        self.initial_o.copy_(ep['o'][:, T])
         return self._finish(ep, Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,

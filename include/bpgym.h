@@ -25,7 +25,8 @@
  *          bits 21..23 num_objs of the episode (Variation: 4..6)
  *          bit  31     has_succeeded latch (fetch_env.py:80, :275-281)
  *   pair index of (i,j), i<=j<6:  i*6 - i*(i-1)/2 + (j-i)   (bpg_pair_index)
- * flags byte written per env-step: bit0 = info['is_success'], bit1 = done.
+ * flags byte written per env-step: bit0 = info['is_success'], bit1 = done,
+ * bit2 = the step's reward is -0.0f (success condition holds this step).
  */
 #ifndef BPGYM_H
 #define BPGYM_H
@@ -48,6 +49,7 @@ extern "C" {
 #define BPG_MAX_MODELS 3
 #define BPG_FLAG_SUCCESS 1
 #define BPG_FLAG_DONE    2
+#define BPG_FLAG_STEP_OK 4   /* this step's reward is -0.0f (else -1.0f): flags alone encode the reward */
 
 /* env ids registered by gym_blocks/__init__.py:6-53, in registration order */
 enum {
@@ -171,6 +173,28 @@ typedef struct {
 } bpg_phys_state;
 int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream);
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream);
+
+/* _randomize_objects of the five env classes (fetch_env.py:328-336, 370-399, 448-517,
+ * 697-764, 777-787): rejection-sampled cube positions for every env, d_xy (n, nb, 2) float64
+ * (nb = num_objs-2 block slots; Variation leaves absent blocks untouched).  The output feeds
+ * the physics backend (object qpos[:2]).  Curriculum state is passed in (host attributes in
+ * the reference): obj_range / max_obj_range / wrong_obj_range, test (set_test / test rollouts
+ * use the maximum ranges), challenge; grip_x/grip_y = initial_gripper_xpos[:2] (physics).
+ * Random draws: either explicit STANDARD variates in the reference's consumption order --
+ * d_eu (n, n_eu) random_sample() values of the per-env np_random stream, d_gz (n, n_gz)
+ * standard normals and d_gu (n, n_gu) random_sample() values of the global np.random
+ * stream -- or, with all three NULL, the handle's counter-based generator.
+ * d_status (n) int32, optional: 0 ok, 1 = variates exhausted / iteration cap reached. */
+typedef struct {
+    double grip_x, grip_y;
+    double obj_range, max_obj_range, wrong_obj_range;
+    int32_t test, challenge;
+    const double *d_eu; int32_t n_eu;
+    const double *d_gz; int32_t n_gz;
+    const double *d_gu; int32_t n_gu;
+} bpg_placement_args;
+int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_xy, int32_t *d_status,
+                          void *stream);
 
 /* Raw packed state, device pointers owned by the handle (zero-copy views). */
 int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);

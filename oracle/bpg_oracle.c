@@ -304,6 +304,124 @@ void orc_discounted_return(const double *r, int T, double gamma, double *G)
     }
 }
 
+/* ---- reset placement, fetch_env.py:328-336, 370-399, 448-517, 697-764, 777-787 ---- */
+typedef struct { const orc_placement *p; int ie, iz, iu, fail; } draws;
+
+static double next_eu(draws *d) { if (d->ie >= d->p->n_eu) { d->fail = 1; return 0.5; } return d->p->eu[d->ie++]; }
+static double next_gz(draws *d) { if (d->iz >= d->p->n_gz) { d->fail = 1; return 1.0; } return d->p->gz[d->iz++]; }
+static double next_gu(draws *d) { if (d->iu >= d->p->n_gu) { d->fail = 1; return 0.5; } return d->p->gu[d->iu++]; }
+/* RandomState.uniform(low, high): low + (high - low) * random_sample() */
+static double unif(double lo, double hi, double u) { return lo + (hi - lo) * u; }
+/* np.linalg.norm([x, y]) = sqrt(x.dot(x)); ddot of 2 elements as the recording container computes it */
+static double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }
+
+/* direction = normal(size=2); direction /= norm; mag = uniform(lo, hi); c + direction*mag
+ * (fetch_env.py:390-393 and the same four lines at :490-493, :507-510, :734-737) */
+static void polar_about(draws *d, double cx, double cy, double lo, double hi, double *x, double *y)
+{
+    double dx = next_gz(d), dy = next_gz(d);
+    double n = norm2(dx, dy);
+    dx = dx / n; dy = dy / n;
+    double mag = unif(lo, hi, next_gu(d));
+    *x = cx + dx * mag;
+    *y = cy + dy * mag;
+}
+
+int orc_randomize_objects(const orc_env *e, const orc_placement *p, double *xy, int *used)
+{
+    draws d = {p, 0, 0, 0, 0};
+    const double MIN_BLOCK_DIST = 1.5 * 0.05;                       /* fetch_env.py:19-20 */
+    const double gx = p->grip_x, gy = p->grip_y;
+    double x, y;
+    switch (e->variant) {
+    case ORC_GRIPPER_TOUCH:                                         /* :328-336 */
+    case ORC_TOPPLE_TOWER: {                                        /* :777-787 */
+        x = gx; y = gy;
+        while (!d.fail && norm2(x - gx, y - gy) < 0.1) {
+            x = gx + unif(-p->obj_range, p->obj_range, next_eu(&d));
+            y = gy + unif(-p->obj_range, p->obj_range, next_eu(&d));
+        }
+        int nb = (e->variant == ORC_TOPPLE_TOWER) ? 4 : 1;
+        for (int i = 0; i < nb; i++) { xy[2 * i] = x; xy[2 * i + 1] = y; }
+        break;
+    }
+    case ORC_BLOCKS_TOUCH:
+    case ORC_BLOCKS_TOUCH_CURRICULUM: {                             /* :370-399 */
+        double r = p->test ? p->max_obj_range : p->obj_range;
+        double x0 = gx + unif(-r / 2, r / 2, next_eu(&d));
+        double y0 = gy + unif(-r / 2, r / 2, next_eu(&d));
+        do {
+            polar_about(&d, x0, y0, MIN_BLOCK_DIST, r, &x, &y);
+        } while (!d.fail && orc_out_of_table(x, y));
+        xy[0] = x0; xy[1] = y0; xy[2] = x; xy[3] = y;
+        break;
+    }
+    case ORC_BLOCKS_TOUCH_CHOOSE:
+    case ORC_BLOCKS_TOUCH_CHOOSE_CURRICULUM: {                      /* :448-517 */
+        double r, wrong_r, max_wrong, min_r;
+        if (p->test || p->challenge) { r = p->max_obj_range; wrong_r = 0; }
+        else { r = p->obj_range; wrong_r = p->wrong_obj_range; }
+        if (p->challenge) { max_wrong = 0.04; min_r = 0.15; }
+        else { min_r = MIN_BLOCK_DIST; max_wrong = p->max_obj_range; }
+        const int green = 0, blue = 1, wrong = 2;                   /* colours [GREEN, BLUE, GREY] :437 */
+        double bx, by, gx2, gy2;
+        do {
+            bx = gx + unif(-r / 2, r / 2, next_eu(&d));
+            by = gy + unif(-r / 2, r / 2, next_eu(&d));
+        } while (!d.fail && orc_out_of_table(bx, by));
+        do {
+            polar_about(&d, bx, by, min_r, r, &gx2, &gy2);
+        } while (!d.fail && orc_out_of_table(gx2, gy2));
+        double cx = (bx + gx2) / 2.0, cy = (by + gy2) / 2.0;
+        do {
+            polar_about(&d, cx, cy, wrong_r, max_wrong, &x, &y);
+        } while (!d.fail && (orc_out_of_table(x, y) || norm2(x - bx, y - by) < MIN_BLOCK_DIST ||
+                             norm2(x - gx2, y - gy2) < MIN_BLOCK_DIST));
+        xy[2 * blue] = bx; xy[2 * blue + 1] = by;
+        xy[2 * green] = gx2; xy[2 * green + 1] = gy2;
+        xy[2 * wrong] = x; xy[2 * wrong + 1] = y;
+        break;
+    }
+    case ORC_BLOCKS_TOUCH_VARIATION: {                              /* :697-764 */
+        const int num_blocks = e->num_objs - 2;
+        double r = p->test ? p->max_obj_range : p->obj_range;
+        const int green = 0, blue = 1;                              /* colours [GREEN, BLUE, GREY, GREY] :635 */
+        double px[4], py[4];
+        int np_ = 0;
+        double bx, by, gx2, gy2;
+        do {
+            bx = gx + unif(-r / 2, r / 2, next_eu(&d));
+            by = gy + unif(-r / 2, r / 2, next_eu(&d));
+        } while (!d.fail && orc_out_of_table(bx, by));
+        do {
+            polar_about(&d, bx, by, MIN_BLOCK_DIST, r, &gx2, &gy2);
+        } while (!d.fail && orc_out_of_table(gx2, gy2));
+        xy[2 * blue] = bx; xy[2 * blue + 1] = by;
+        xy[2 * green] = gx2; xy[2 * green + 1] = gy2;
+        px[np_] = bx; py[np_++] = by;
+        px[np_] = gx2; py[np_++] = gy2;
+        for (int i = 0; i < num_blocks; i++) {
+            if (i == blue || i == green) continue;
+            int again;
+            do {
+                again = 0;
+                x = table_x() + unif(-table_w(), table_w(), next_eu(&d));   /* _sample_from_table :88-90 */
+                y = table_y() + unif(-table_h(), table_h(), next_eu(&d));
+                int hit = 0;
+                for (int k = 0; k < np_; k++)
+                    if (norm2(x - px[k], y - py[k]) < MIN_BLOCK_DIST) { hit = 1; break; }
+                again = hit ? 1 : orc_out_of_table(x, y);           /* for-else :753-758 */
+            } while (!d.fail && again);
+            xy[2 * i] = x; xy[2 * i + 1] = y;
+            px[np_] = x; py[np_++] = y;
+        }
+        break;
+    }
+    }
+    if (used) { used[0] = d.ie; used[1] = d.iz; used[2] = d.iu; }
+    return d.fail;
+}
+
 /* ---- build-defined synthetic contact source (no reference counterpart) ---- */
 uint32_t orc_hash32(uint32_t x)
 {

@@ -128,6 +128,25 @@ void orc_discounted_return(const double *r, int T, double gamma, double *G);
 /* fetch_env.py:30-32 */
 int orc_out_of_table(double x, double y);
 
+/* _randomize_objects of the five env classes (fetch_env.py:328-336, 370-399, 448-517,
+ * 697-764, 777-787) with the random draws passed in as STANDARD variates in the order the
+ * reference consumes them: eu = random_sample() values of the per-env
+ * np_random stream, gz / gu = standard normals / uniforms of the global np.random stream.
+ * uniform(lo,hi) is restated as lo + (hi-lo)*u and normal() as z (NumPy legacy RandomState).
+ * np.linalg.norm of a 2-vector is sqrt(fma(y,y,x*x)) -- what NumPy 2.2.6 + its BLAS ddot
+ * compute in the container the fixtures were recorded in (BLAS dependent in general).
+ * xy: (num_objs-2, 2) block positions written for the blocks the reference moves.
+ * Returns 0, or 1 when a variate array ran out before the rejection loops finished. */
+typedef struct {
+    double grip_x, grip_y;                         /* initial_gripper_xpos[:2], fetch_env.py:300-301 */
+    double obj_range, max_obj_range, wrong_obj_range;
+    int test, challenge;
+    const double *eu; int n_eu;
+    const double *gz; int n_gz;
+    const double *gu; int n_gu;
+} orc_placement;
+int orc_randomize_objects(const orc_env *e, const orc_placement *p, double *xy, int *used /*[3]*/);
+
 /* ---- build-defined synthetic contact source (NO reference counterpart) ----
  * Stand-in for the physics in throughput runs.  Counter-based:
  * a pure function of (seed, env_id, t).  Table-block pairs (1,k) forced on,

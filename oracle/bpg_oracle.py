@@ -26,6 +26,15 @@ class Phys(C.Structure):
                  'obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')]
 
 
+class Placement(C.Structure):
+    _fields_ = [('grip_x', C.c_double), ('grip_y', C.c_double), ('obj_range', C.c_double),
+                ('max_obj_range', C.c_double), ('wrong_obj_range', C.c_double),
+                ('test', C.c_int), ('challenge', C.c_int),
+                ('eu', C.POINTER(C.c_double)), ('n_eu', C.c_int),
+                ('gz', C.POINTER(C.c_double)), ('n_gz', C.c_int),
+                ('gu', C.POINTER(C.c_double)), ('n_gu', C.c_int)]
+
+
 class Env(C.Structure):
     _fields_ = [
         ('variant', C.c_int), ('num_objs', C.c_int), ('side', C.c_int),
@@ -72,6 +81,7 @@ def lib():
         L.orc_env_step_mask.argtypes = [P(Env), C.c_uint32, P(C.c_float), P(C.c_int), P(C.c_int)]
         L.orc_get_achieved_goal.argtypes = [P(Env), P(C.c_double)]
         L.orc_get_obs.argtypes = [P(Env), P(Phys), C.c_double, P(C.c_double)]
+        L.orc_randomize_objects.argtypes = [P(Env), P(Placement), P(C.c_double), P(C.c_int)]
         L.orc_pair_index.argtypes = [C.c_int, C.c_int]
         L.orc_contacts_to_mask.argtypes = [P(C.c_int), P(C.c_int), C.c_int]
         L.orc_contacts_to_mask.restype = C.c_uint32
@@ -134,6 +144,18 @@ class OracleEnv:
         out = np.zeros(128)
         n = self.L.orc_get_obs(C.byref(self.e), C.byref(ph), float(dt), _p(out, C.c_double))
         return out[:n].copy()
+
+    def randomize_objects(self, grip_xy, obj_range, max_obj_range, wrong_obj_range, test, challenge,
+                          eu, gz, gu):
+        """_randomize_objects with explicit standard variates.  Returns (xy (nb,2), used[3], fail)."""
+        eu, gz, gu = (np.ascontiguousarray(a, np.float64) for a in (eu, gz, gu))
+        pl = Placement(float(grip_xy[0]), float(grip_xy[1]), float(obj_range), float(max_obj_range),
+                       float(wrong_obj_range), int(test), int(challenge),
+                       _p(eu, C.c_double), len(eu), _p(gz, C.c_double), len(gz), _p(gu, C.c_double), len(gu))
+        xy = np.full((self.e.num_objs - 2, 2), np.nan)
+        used = (C.c_int * 3)()
+        fail = self.L.orc_randomize_objects(C.byref(self.e), C.byref(pl), _p(xy, C.c_double), used)
+        return xy, list(used), bool(fail)
 
     def step_mask(self, mask):
         r, d, s = C.c_float(), C.c_int(), C.c_int()

@@ -387,3 +387,43 @@ class ContactScript:
         pairs = [pairs[i] for i in idx][:FakeData.MAXCON]
         self.log.append(pairs)
         return pairs
+
+
+class RecordingRandom:
+    """Wraps a numpy RandomState and logs the STANDARD variates behind every uniform() /
+    normal() call (uniform(lo,hi) == lo + (hi-lo)*random_sample(), normal() ==
+    standard_normal() for NumPy's legacy RandomState -- checked against a clone on every
+    call), so a fixture can hand the identical draws to the build."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.u, self.z, self.ints = [], [], []
+
+    def _clone(self):
+        c = np.random.RandomState()
+        c.set_state(self.rs.get_state())
+        return c
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        ref = self._clone().uniform(low, high, size)
+        u = self.rs.random_sample(size)
+        out = low + (high - low) * u
+        assert np.array_equal(np.asarray(out), np.asarray(ref))
+        self.u.extend(np.atleast_1d(u).tolist())
+        return out
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        assert loc == 0.0 and scale == 1.0
+        ref = self._clone().normal(size=size)
+        z = self.rs.standard_normal(size)
+        assert np.array_equal(np.asarray(z), np.asarray(ref))
+        self.z.extend(np.atleast_1d(z).tolist())
+        return z
+
+    def randint(self, *a, **k):
+        v = self.rs.randint(*a, **k)
+        self.ints.append(int(v))
+        return v
+
+    def clear(self):
+        del self.u[:], self.z[:], self.ints[:]

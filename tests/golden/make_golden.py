@@ -214,6 +214,80 @@ def obs_trace(env_id, seed, n_eps=3, n_steps=6):
     return out
 
 
+def placement_trace(env_id, seed, n_resets=40):
+    """Reference _randomize_objects (through the real reset()/set_test()/increase_difficulty())
+    with both RNG streams wrapped so every consumed standard variate is recorded."""
+    env = H.make(env_id)
+    u = env.unwrapped
+    E = H.RecordingRandom(seed)
+    Gs = H.RecordingRandom(seed + 1)
+    u.np_random = E
+    saved = (np.random.normal, np.random.uniform)
+    np.random.normal, np.random.uniform = Gs.normal, Gs.uniform      # the global stream (quirk Q7)
+    rows = dict(grip_xy=[], eu=[], gz=[], gu=[], xy=[], num_objs=[], test=[], obj_range=[], max_obj_range=[],
+                wrong_obj_range=[], difficulty=[], challenge=[])
+    nbmax = 4 if 'Variation' in env_id else u.num_objs - 2
+    try:
+        for k in range(n_resets):
+            E.clear(); Gs.clear()
+            test = False
+            if hasattr(u, 'challenge'):
+                u.challenge = (k % 11 == 10)
+            # the gripper start position is a physics output; move it next to the table edge
+            # on some episodes so the out-of-table rejection branches are exercised
+            base = H.GRIP_XPOS0[:2]
+            u.initial_gripper_xpos = np.array(
+                [base[0] + [0, 0.2, -0.21][k % 3], base[1] + [0, 0.3, -0.31][k % 3], H.GRIP_XPOS0[2]])
+            env.reset()
+            if k % 4 == 3 and variants_can_test(u):
+                # set_test re-randomises at maximum difficulty (fetch_env.py:365-368, :443-446)
+                E.clear(); Gs.clear()
+                u.set_test()
+                test = env_id != 'BlocksTouchVariation-v0'     # Variation's set_test does not re-place
+                if not test:
+                    continue
+            xy = np.full((nbmax, 2), np.nan)
+            for i in range(u.num_objs - 2):
+                xy[i] = u.sim.data.qpos['object%d:joint' % i][:2]
+            rows['eu'].append(list(E.u)); rows['gz'].append(list(Gs.z)); rows['gu'].append(list(Gs.u))
+            rows['xy'].append(xy); rows['num_objs'].append(u.num_objs); rows['test'].append(test)
+            rows['grip_xy'].append(u.initial_gripper_xpos[:2].copy())
+            rows['obj_range'].append(u.obj_range)
+            rows['max_obj_range'].append(getattr(u, 'max_obj_range', np.nan))
+            rows['wrong_obj_range'].append(getattr(u, 'wrong_obj_range', np.nan))
+            rows['difficulty'].append(u.difficulty)
+            rows['challenge'].append(bool(getattr(u, 'challenge', False)))
+            if k % 5 == 4:
+                try:
+                    u.increase_difficulty()
+                except (NotImplementedError, AttributeError):
+                    pass
+    finally:
+        np.random.normal, np.random.uniform = saved
+
+    def pad(lists):
+        m = max(1, max(len(x) for x in lists))
+        out = np.full((len(lists), m), np.nan)
+        for i, x in enumerate(lists):
+            out[i, :len(x)] = x
+        return out, np.asarray([len(x) for x in lists], np.int32)
+    out = {}
+    for k in ('eu', 'gz', 'gu'):
+        out[k], out['n_' + k] = pad(rows[k])
+    for k in ('grip_xy', 'xy', 'num_objs', 'test', 'obj_range', 'max_obj_range', 'wrong_obj_range', 'difficulty', 'challenge'):
+        out[k] = np.asarray(rows[k])
+    return out
+
+
+def variants_can_test(u):
+    try:
+        type(u).set_test
+    except AttributeError:
+        return False
+    import gym_blocks.envs.fetch_env as fe
+    return type(u).set_test is not fe.BlocksEnv.set_test
+
+
 def compute_reward_cases(rng):
     """The reference's vectorised compute_reward on ternary inputs
     (config.py:110-111 call shape: (batch, N^2) in, (batch,) float32 out)."""
@@ -370,6 +444,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'compute_reward.npz'), **compute_reward_cases(rng))
     for k, eid in enumerate(ENV_IDS):
         np.savez_compressed(os.path.join(HERE, 'obs_%s.npz' % eid.split('-')[0]), **obs_trace(eid, 300 + k))
+    for k, eid in enumerate(ENV_IDS):
+        np.savez_compressed(os.path.join(HERE, 'placement_%s.npz' % eid.split('-')[0]),
+                            **placement_trace(eid, 900 + k))
 
     for k, eid in enumerate(ENV_IDS):
         can_test = variants[eid]['set_test'] == 'ok'

@@ -218,7 +218,7 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
         for t in range(T):
             _, r, done, succ = e.step_mask(int(masks[t, b]))
             exp_r[t, b] = np.float32(r).view(np.uint32)
-            exp_f[t, b] = int(succ) | (int(done) << 1)
+            exp_f[t, b] = int(succ) | (int(done) << 1) | (int(r == 0) << 2)
     exp_ag = np.stack([e.achieved_goal() for e in oenvs])
 
     L = bpg._lib.lib()
@@ -231,7 +231,7 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
         obs, r, done, info = env.step(None, contact_masks=dm[t])
         np.testing.assert_array_equal(bits(r), exp_r[t])
         f = info['is_success'].cpu().numpy().astype(np.uint8) | (done.cpu().numpy().astype(np.uint8) << 1)
-        np.testing.assert_array_equal(f, exp_f[t])
+        np.testing.assert_array_equal(f, exp_f[t] & 3)
     np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), exp_ag.astype(np.float32))
     np.testing.assert_array_equal(env.achieved_goal_f64().cpu().numpy(), exp_ag)
     assert int(env.success_count().item()) == int((exp_f[-1] & 1).sum())
@@ -431,7 +431,7 @@ def test_full_size_properties():
     for t in range(T):
         _, r, done, info = step.step(None)
         assert torch.equal(r.view(torch.int32), rew[t].view(torch.int32))
-        f = info['is_success'].to(torch.uint8) | (done.to(torch.uint8) << 1)
+        f = info['is_success'].to(torch.uint8) | (done.to(torch.uint8) << 1) | ((r == 0).to(torch.uint8) << 2)
         assert torch.equal(f, flg[t])
     assert torch.equal(step.state_now, full.state_now) and torch.equal(step.state_ever, full.state_ever)
     # (b)
@@ -488,3 +488,69 @@ def test_golden_observation_assembly(env_id):
     env.assemble_observation(phys, dt=float(d['dt']), out=ep_o[:, 1])
     np.testing.assert_array_equal(ep_o[:, 1].cpu().numpy(), d['obs'].astype(np.float32))
     assert (ep_o[:, 0] == 0).all() and (ep_o[:, 2] == 0).all()
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_golden_reset_placement(env_id):
+    """Reference _randomize_objects replayed on the GPU with the recorded standard variates:
+    bit-identical float64 positions (fixture rows grouped by their launch constants)."""
+    d = np.load(os.path.join(GOLDEN, 'placement_%s.npz' % short(env_id)))
+    keys = np.stack([d['grip_xy'][:, 0], d['grip_xy'][:, 1], d['obj_range'], np.nan_to_num(d['max_obj_range']),
+                     np.nan_to_num(d['wrong_obj_range']), d['test'].astype(float), d['challenge'].astype(float)], 1)
+    groups = {}
+    for k, row in enumerate(map(tuple, keys)):
+        groups.setdefault(row, []).append(k)
+    assert len(groups) >= 3
+    for row, idx in groups.items():
+        idx = np.asarray(idx)
+        env = bpg.make(env_id, num_envs=len(idx), device=DEV)
+        env.reset(num_grey=d['num_objs'][idx] - 4)
+        env.obj_range, env.max_obj_range, env.wrong_obj_range = row[2], row[3], row[4]
+        env.challenge = bool(row[6])
+        var = {k: np.nan_to_num(d[k][idx], nan=0.5) for k in ('eu', 'gz', 'gu')}
+        for k in var:       # kernels need at least the minimum count of columns
+            if var[k].shape[1] < 2:
+                var[k] = np.concatenate([var[k], np.full((len(idx), 2), 0.5)], 1)
+        xy, status = env.randomize_objects(test=bool(row[5]), grip_xy=row[:2], variates=var)
+        assert (status == 0).all()
+        got, exp = xy.cpu().numpy(), d['xy'][idx]
+        for j, k in enumerate(idx):
+            nb = int(d['num_objs'][k]) - 2
+            np.testing.assert_array_equal(got[j, :nb].view(np.uint64), exp[j, :nb].view(np.uint64))
+            assert np.isnan(got[j, nb:]).all()          # absent Variation blocks are left untouched
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_reset_placement_generator_properties(env_id):
+    """Counter-based draw mode (build-defined): every constraint the reference's rejection
+    loops enforce holds, results are deterministic in (seed, global env index)."""
+    B = 20000
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=11)
+    env.reset()
+    xy, status = env.randomize_objects()
+    assert (status == 0).all()
+    xy = xy.cpu().numpy()
+    nobj = env.num_objs_per_env().cpu().numpy()
+    TW, TH, TX, TY, MIN = 0.225, 0.32499999999999996, 1.3, 0.75, 0.07500000000000001
+    grip = np.array([1.3419, 0.7491])
+    present = np.arange(xy.shape[1])[None, :] < (nobj - 2)[:, None]
+    assert not np.isnan(xy[present]).any()
+    if env_id in ('GripperTouch-v0', 'ToppleTower-v0'):
+        assert (np.linalg.norm(xy[:, 0] - grip, axis=1) >= 0.1).all()
+        assert (np.abs(xy[:, 0] - grip) <= env.obj_range).all()
+    else:
+        moved = xy[:, 1:] if env_id.startswith('BlocksTouch-') or 'Curriculum-v0' == env_id[11:] else xy
+        on = (np.abs(moved[..., 0] - TX) <= TW) & (np.abs(moved[..., 1] - TY) <= TH)
+        assert on[present[:, -moved.shape[1]:]].all()
+        dist01 = np.linalg.norm(xy[:, 0] - xy[:, 1], axis=1)
+        assert (dist01 >= MIN - 1e-12).all() and (dist01 <= env.obj_range + 1e-12).all()
+    if 'Variation' in env_id or 'Choose' in env_id:
+        for a in range(xy.shape[1]):
+            for b in range(a + 1, xy.shape[1]):
+                both = present[:, a] & present[:, b]
+                assert (np.linalg.norm(xy[both, a] - xy[both, b], axis=1) >= MIN - 1e-12).all()
+    # shard invariance + determinism
+    half = bpg.make(env_id, num_envs=B // 2, device=DEV, seed=11, env_id_base=B // 2)
+    half.reset()
+    xy2, _ = half.randomize_objects()
+    np.testing.assert_array_equal(np.nan_to_num(xy2.cpu().numpy()), np.nan_to_num(xy[B // 2:]))

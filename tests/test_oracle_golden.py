@@ -190,3 +190,33 @@ def test_observation_assembly(env_id):
         phys.update({f: d[f][k][:nb] for f in ('obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')})
         got = e.get_obs(phys, float(d['dt']))
         np.testing.assert_array_equal(got.view(np.uint64), d['obs'][k].view(np.uint64))
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_reset_placement(env_id):
+    """Reference _randomize_objects (all five classes, train / set_test / challenge modes,
+    curriculum levels, gripper near the table edge) replayed with the recorded standard
+    variates: identical accept/reject decisions (same number of draws consumed) and
+    bit-identical positions against the fixture (NumPy 2.2.6 of the build container; the
+    2-vector norm goes through BLAS ddot, so other BLAS builds may differ by an ulp)."""
+    d = np.load(os.path.join(G, 'placement_%s.npz' % short(env_id)))
+    e = O.OracleEnv(env_id)
+    assert len(d['xy']) >= 30
+    for k in range(len(d['xy'])):
+        e.e.num_objs = int(d['num_objs'][k])
+        nb = e.e.num_objs - 2
+        xy, used, fail = e.randomize_objects(
+            d['grip_xy'][k], d['obj_range'][k], np.nan_to_num(d['max_obj_range'][k]),
+            np.nan_to_num(d['wrong_obj_range'][k]), d['test'][k], d['challenge'][k],
+            d['eu'][k, :d['n_eu'][k]], d['gz'][k, :d['n_gz'][k]], d['gu'][k, :d['n_gu'][k]])
+        assert not fail
+        assert used == [int(d['n_eu'][k]), int(d['n_gz'][k]), int(d['n_gu'][k])]
+        np.testing.assert_array_equal(xy.view(np.uint64), d['xy'][k, :nb].view(np.uint64))
+    # one variate short -> reports exhaustion instead of looping
+    k = int(np.argmax(d['n_eu']))
+    e.e.num_objs = int(d['num_objs'][k])
+    _, _, fail = e.randomize_objects(d['grip_xy'][k], d['obj_range'][k], np.nan_to_num(d['max_obj_range'][k]),
+                                     np.nan_to_num(d['wrong_obj_range'][k]), d['test'][k], d['challenge'][k],
+                                     d['eu'][k, :d['n_eu'][k] - 1], d['gz'][k, :d['n_gz'][k]],
+                                     d['gu'][k, :d['n_gu'][k]])
+    assert fail or d['n_eu'][k] == 0
