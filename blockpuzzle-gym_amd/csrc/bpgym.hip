@@ -1654,19 +1654,29 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     std::vector<double> pw((size_t)T);
     for (int k = 0; k < T; k++) pw[(size_t)k] = std::pow(gamma, (double)k);
     double *d_pw = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&d_pw), sizeof(double) * (size_t)T, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync(d_pw, pw.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // pw is a stack-lifetime host buffer
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_pw), sizeof(double) * (size_t)T));
+    hipError_t ce = hipMemcpyAsync(d_pw, pw.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice,
+                                   (hipStream_t)stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize((hipStream_t)stream);   // pw is a host temporary
+    if (ce != hipSuccess) {
+        (void)hipFree(d_pw);
+        return fail(BPG_ERR_HIP, std::string("pow table upload: ") + hipGetErrorString(ce));
+    }
     const int R = T | 1;
     const size_t lds = (size_t)64 * R * sizeof(double);
-    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS tile");
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_discounted_return, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
-                       d_reward_tb, n, T, R, d_pw, d_G);
-    int rc = check_launch("k_discounted_return");
-    HIP_TRY(hipFreeAsync(d_pw, (hipStream_t)stream));
+    int rc = BPG_OK;
+    if (lds > 160 * 1024) rc = fail(BPG_ERR_ARG, "T too large for the LDS tile");
+    if (rc == BPG_OK && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) rc = fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    if (rc == BPG_OK) {
+        hipLaunchKernelGGL(k_discounted_return, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
+                           d_reward_tb, n, T, R, d_pw, d_G);
+        rc = check_launch("k_discounted_return");
+    }
+    (void)hipFree(d_pw);      // synchronises with the kernel that reads the table
     return rc;
 }
 

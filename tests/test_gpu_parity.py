@@ -554,3 +554,95 @@ def test_reset_placement_generator_properties(env_id):
     half.reset()
     xy2, _ = half.randomize_objects()
     np.testing.assert_array_equal(np.nan_to_num(xy2.cpu().numpy()), np.nan_to_num(xy[B // 2:]))
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 63, 64, 65, 129, 255, 257, 4100])
+def test_edge_batch_sizes(B):
+    """Partial waves / vector tails of every kernel family against the oracle (Variation,
+    T=7): per-step masks, fused packed rollout, episode writer, float views, success count."""
+    import ctypes as C
+    env_id, T = 'BlocksTouchVariation-v0', 7
+    rng = np.random.RandomState(B)
+    num_grey = rng.randint(3, size=B).astype(np.int32)
+    masks = legal_masks(rng, T, B, 4 + num_grey, density=2)
+    ref, _ = O.generate_rollouts(env_id, B, T, masks, num_grey=num_grey)
+    dm = i32(masks)
+    L = bpg._lib.lib()
+    # per-step
+    env = bpg.make(env_id, num_envs=B, device=DEV, max_episode_steps=T)
+    obs = env.reset(num_grey=num_grey)
+    np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), ref['ag'][:, 0])
+    for t in range(T):
+        obs, r, done, info = env.step(None, contact_masks=dm[t])
+        np.testing.assert_array_equal(bits(r), ref['reward'][t].view(np.uint32))
+        np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), ref['ag'][:, t + 1])
+        np.testing.assert_array_equal(info['is_success'].cpu().numpy(), ref['info_is_success'][:, t, 0] != 0)
+        assert bool(done.all()) == (t == T - 1) and bool(done.any()) == (t == T - 1)
+    assert int(env.success_count().item()) == int(ref['info_is_success'][:, -1, 0].sum())
+    # fused packed + episode writer (reset inside the launch)
+    for episode in (False, True):
+        e2 = bpg.make(env_id, num_envs=B, device=DEV, max_episode_steps=T)
+        ng = torch.as_tensor(num_grey, device=DEV)
+        rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+        cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+        kw = {}
+        if episode:
+            ag = torch.empty((B, T + 1, 36), dtype=torch.float32, device=DEV)
+            g = torch.empty((B, T, 36), dtype=torch.float32, device=DEV)
+            sc = torch.empty((B, T, 1), dtype=torch.float32, device=DEV)
+            kw = dict(d_ep_ag=ag.data_ptr(), d_ep_g=g.data_ptr(), d_ep_success=sc.data_ptr())
+        args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=dm.data_ptr(),
+                                    d_reward_tb=rew.data_ptr(), d_success_count=cnt.data_ptr(), **kw)
+        bpg._lib.check(L.bpg_rollout(e2._h, C.byref(args), None))
+        np.testing.assert_array_equal(bits(rew), ref['reward'].view(np.uint32))
+        assert int(cnt.item()) == int(ref['info_is_success'][:, -1, 0].sum())
+        assert torch.equal(e2.state_now, env.state_now) and torch.equal(e2.state_ever, env.state_ever)
+        if episode:
+            np.testing.assert_array_equal(ag.cpu().numpy(), ref['ag'])
+            np.testing.assert_array_equal(g.cpu().numpy(), ref['g'])
+            np.testing.assert_array_equal(sc.cpu().numpy(), ref['info_is_success'])
+
+
+@pytest.mark.parametrize('T', [1, 2, 127, 200])
+def test_rollout_lengths(T):
+    """T=1, and T large enough that the episode writer's LDS history tile exceeds the 64 KiB
+    default (opt-in dynamic LDS path); max_episode_steps = 100 so `done` flips inside."""
+    env_id, B = 'BlocksTouchChoose-v0', 130
+    rng = np.random.RandomState(T)
+    masks = legal_masks(rng, T, B, 5, density=3)
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, max_episode_steps=100),
+                           None, dims_of(env_id), None, T, rollout_batch_size=B)
+    ep = w.generate_rollouts_fused(masks=i32(masks), want_reward=True)
+    L = O.lib()
+    import ctypes as C
+    envs = (O.Env * B)()
+    for b in range(B):
+        L.orc_env_init(C.byref(envs[b]), O.VARIANTS[env_id], 100)
+    ref, _ = O.generate_rollouts(env_id, B, T, masks, envs=envs)
+    np.testing.assert_array_equal(ep['ag'], ref['ag'])
+    np.testing.assert_array_equal(ep['info_is_success'], ref['info_is_success'])
+    np.testing.assert_array_equal(ep['reward_tb'].view(np.uint32), ref['reward'].view(np.uint32))
+
+
+def test_argument_errors_are_reported():
+    import ctypes as C
+    L = bpg._lib.lib()
+    env = bpg.make('BlocksTouch-v0', num_envs=16, device=DEV)
+    with pytest.raises(bpg._lib.BpgError):       # contact lists before an id2obj table -> fine here, table is preset
+        bpg._lib.check(L.bpg_step_contacts(env._h, None, None, 4, None, None, None))
+    args = bpg._lib.RolloutArgs(T=0)
+    assert L.bpg_rollout(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
+    args = bpg._lib.RolloutArgs(T=5000)
+    assert L.bpg_rollout(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
+    buf = torch.empty(16 * 16 + 1, dtype=torch.float32, device=DEV)
+    assert L.bpg_get_achieved_goal_f32(env._h, C.c_void_p(buf.data_ptr()), 8, None) == bpg._lib.ERR_ARG   # ld < dimg
+    # misaligned (4-byte offset) output still works through the scalar path
+    out = buf[1:].view(16, 16)
+    bpg._lib.check(L.bpg_get_achieved_goal_f32(env._h, C.c_void_p(out.data_ptr()), 16, None))
+    assert (out == -1).all()
+    m = torch.zeros(17, dtype=torch.int32, device=DEV)[1:]
+    r = torch.empty(17, dtype=torch.float32, device=DEV)[1:]
+    bpg._lib.check(L.bpg_step_masks(env._h, C.c_void_p(m.data_ptr()), C.c_void_p(r.data_ptr()), None, None))
+    assert (bits(r) == 0xBF800000).all()
+    with pytest.raises(KeyError):
+        bpg.make('NoSuchEnv-v0')
