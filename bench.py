@@ -223,6 +223,26 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
                                     C.c_void_p(flags.data_ptr()), stream))
     res['step_masks_single_launch'] = line(timed(step_once, 200), 25 * B, B)
 
+    # (1b) one env.step launch with the contacts as the reference reads them: geom-id pair lists
+    # (B, maxcon=16, 2) int16 + ncon; bytes = 8 state + 4 ncon + 64 list in, 13 out = 89 B/env-step
+    try:
+        maxcon = 16
+        names = bpg.default_geom_names(ENV_ID)[2]
+        objs = [i for i, n in enumerate(names) if n and (n == 'table' or n.startswith('object') or 'finger' in n)]
+        gsel = torch.tensor(objs, dtype=torch.int16, device=dev)
+        idx = torch.randint(0, len(objs), (B, maxcon, 2), device=dev)
+        pairs = gsel[idx].contiguous()
+        ncon = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev)
+
+        def step_contacts():
+            _lib.check(L.bpg_step_contacts(env._h, C.c_void_p(pairs.data_ptr()), C.c_void_p(ncon.data_ptr()),
+                                           maxcon, C.c_void_p(reward.data_ptr()), C.c_void_p(flags.data_ptr()),
+                                           stream))
+        res['step_contacts_single_launch'] = line(timed(step_contacts, 100), 89 * B, B)
+        del pairs, ncon, idx
+    except Exception as e:  # noqa: BLE001
+        res['step_contacts_single_launch'] = {'error': repr(e)[:200]}
+
     # (2) the same T steps as T launches replayed from a hipGraph
     try:
         g = torch.cuda.CUDAGraph()

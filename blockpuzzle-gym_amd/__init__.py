@@ -10,10 +10,10 @@ onto this hyphenated directory).  Public surface mirrors the reference:
 from . import _lib
 from .registration import make, register, registry
 from .envs import (BatchedBlocksEnv, SyntheticContacts, ScriptedContacts, CallableContacts,
-                   compute_reward, geom2objid, default_geom_names)
+                   compute_reward, mat2euler, geom2objid, default_geom_names)
 from .rollout import RolloutStudent, PGRolloutStudent, configure_dims, discounted_return
 from . import distributed
 
 __all__ = ['make', 'register', 'registry', 'BatchedBlocksEnv', 'RolloutStudent', 'PGRolloutStudent',
            'SyntheticContacts', 'ScriptedContacts', 'CallableContacts', 'compute_reward',
-           'configure_dims', 'discounted_return', 'geom2objid', 'default_geom_names', 'distributed']
+           'configure_dims', 'discounted_return', 'mat2euler', 'geom2objid', 'default_geom_names', 'distributed']

@@ -405,44 +405,77 @@ k_step_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
 }
 
 // Contacts as the reference reads them (fetch_env.py:158-167): per env a list
-// of geom-id pairs.  The id2obj tables live in LDS; one env per lane.
+// of geom-id pairs.  One env per lane; the id2obj tables live in LDS.
+__device__ __forceinline__ uint32_t pair_bit_of(const int8_t *tab, uint32_t pr)
+{
+    const uint32_t g1 = pr & 0xFFFFu, g2 = pr >> 16;          // geom1 | geom2 << 16
+    if (g1 < BPG_MAX_GEOMS && g2 < BPG_MAX_GEOMS) {
+        const int o1 = tab[g1], o2 = tab[g2];
+        if (o1 >= 0 && o2 >= 0) {                              // both not None (:165)
+            const int lo = o1 < o2 ? o1 : o2, hi = o1 < o2 ? o2 : o1;
+            return 1u << (lo * BPG_MAX_OBJS - lo * (lo - 1) / 2 + (hi - lo));
+        }
+    }
+    return 0u;
+}
+
+// STAGED: the block's 256 contact rows are one contiguous tile; it is brought into LDS
+// with 16-byte-per-lane coalesced loads (row stride padded to maxcon+1 dwords, so the
+// per-lane row walk that follows is bank-conflict free) instead of 64 lanes each
+// striding through their own row.  Needs maxcon % 4 == 0 and a 16-byte aligned list.
+template <bool STAGED>
 __global__ void __launch_bounds__(256)
 k_step_contacts(uint32_t *__restrict__ now, uint32_t *__restrict__ ever,
                 const int16_t *__restrict__ contacts, const int32_t *__restrict__ ncon, int maxcon,
                 const int8_t *__restrict__ id2obj, int is_variation,
                 uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, int64_t n, StepConst c)
 {
-    __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t *s_tab = reinterpret_cast<int8_t *>(smem);                        // [MODELS][GEOMS]
+    uint32_t *s_con = reinterpret_cast<uint32_t *>(smem + BPG_MAX_MODELS * BPG_MAX_GEOMS);
     for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t a = now[i], e = ever[i], rb, fl;
-        int model = 0;
-        if (is_variation) {
-            model = (int)nobj_of(e) - 4;        // fetch_env.py:650-651
-            model = model < 0 ? 0 : (model > 2 ? 2 : model);
-        }
-        const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
-        int nc = ncon[i];
-        nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(contacts + (int64_t)i * maxcon * 2);
-        uint32_t m = 0;
-        for (int k = 0; k < nc; k++) {
-            const uint32_t pr = row[k];                  // geom1 | geom2 << 16
-            const uint32_t g1 = pr & 0xFFFFu, g2 = pr >> 16;
-            if (g1 < BPG_MAX_GEOMS && g2 < BPG_MAX_GEOMS) {
-                const int o1 = tab[g1], o2 = tab[g2];
-                if (o1 >= 0 && o2 >= 0) {                // both not None (:165)
-                    const int lo = o1 < o2 ? o1 : o2, hi = o1 < o2 ? o2 : o1;
-                    m |= 1u << (lo * BPG_MAX_OBJS - lo * (lo - 1) / 2 + (hi - lo));
-                }
+    const int ldc = maxcon + 1;
+    const int64_t nblocks = (n + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t base = blk * 256;
+        const int rows = (int)((n - base) < 256 ? (n - base) : 256);
+        const uint32_t *tile = reinterpret_cast<const uint32_t *>(contacts) + base * maxcon;
+        if (STAGED) {
+            __syncthreads();                                   // previous tile fully consumed
+            const int nq = rows * maxcon / 4;
+            const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);
+            for (int q = threadIdx.x; q < nq; q += 256) {
+                const uint4 v = t4[q];
+                const int d = 4 * q, r = d / maxcon, col = d - r * maxcon;
+                uint32_t *dst = s_con + r * ldc + col;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
         }
-        step_core(a, e, m, c, rb, fl);
-        now[i] = a; ever[i] = e;
-        if (reward) reward[i] = rb;
-        if (flags) flags[i] = (uint8_t)fl;
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            const int64_t i = base + threadIdx.x;
+            uint32_t a = now[i], e = ever[i], rb, fl;
+            int model = 0;
+            if (is_variation) {
+                model = (int)nobj_of(e) - 4;                   // fetch_env.py:650-651
+                model = model < 0 ? 0 : (model > 2 ? 2 : model);
+            }
+            const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
+            int nc = ncon[i];
+            nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
+            uint32_t m = 0;
+            if (STAGED) {
+                const uint32_t *row = s_con + threadIdx.x * ldc;
+                for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
+            } else {
+                const uint32_t *row = tile + (int64_t)threadIdx.x * maxcon;
+                for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
+            }
+            step_core(a, e, m, c, rb, fl);
+            now[i] = a; ever[i] = e;
+            if (reward) reward[i] = rb;
+            if (flags) flags[i] = (uint8_t)fl;
+        }
     }
 }
 
@@ -725,6 +758,24 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
             }
         }
         out[e * ld + (f - e * oc.dimo)] = (OutT)v;
+    }
+}
+
+// rotations.mat2euler of gym.envs.robotics (call site fetch_env.py:205, :588).  THIRD-PARTY
+// code that is not in the reference tree: restated from SURVEY.md A.4's recollection of gym
+// 0.10 (cy = sqrt(m22^2 + m12^2), branch on cy > 4*eps, negated arctan2 forms) -- parity
+// UNPINNED; a convenience for physics backends that hand over site rotation matrices.
+__global__ void __launch_bounds__(256)
+k_mat2euler(const double *__restrict__ mat, int64_t n, double *__restrict__ euler)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double *m = mat + i * 9;
+        const double cy = sqrt(m[8] * m[8] + m[5] * m[5]);
+        const bool cond = cy > 4.0 * 2.220446049250313e-16;
+        euler[i * 3 + 2] = cond ? -atan2(m[1], m[0]) : -atan2(-m[3], m[4]);
+        euler[i * 3 + 1] = -atan2(-m[2], cy);
+        euler[i * 3 + 0] = cond ? -atan2(m[5], m[8]) : 0.0;
     }
 }
 
@@ -1396,9 +1447,19 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
     for (int m = 0; m < models; m++)
         if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_step_contacts, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now,
-                       b->ever, d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
-                       reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
+    const int64_t nblocks = (b->n + 255) / 256;
+    const dim3 grid((unsigned)(nblocks < 4096 ? nblocks : 4096)), block(256);
+    const size_t tab_bytes = BPG_MAX_MODELS * BPG_MAX_GEOMS;
+    const size_t staged_lds = tab_bytes + (size_t)256 * (maxcon + 1) * sizeof(uint32_t);
+    const bool staged = (maxcon % 4 == 0) && staged_lds <= 64 * 1024 && aligned16(d_contacts);
+    if (staged)
+        hipLaunchKernelGGL(k_step_contacts<true>, grid, block, staged_lds, (hipStream_t)stream, b->now, b->ever,
+                           d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
+                           reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
+    else
+        hipLaunchKernelGGL(k_step_contacts<false>, grid, block, tab_bytes, (hipStream_t)stream, b->now, b->ever,
+                           d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
+                           reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
     return check_launch("k_step_contacts");
 }
 
@@ -1493,6 +1554,15 @@ int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, 
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream)
 {
     return assemble_obs(b, ph, d_obs, ld, false, stream);
+}
+
+int bpg_mat2euler_f64(const double *d_mat, int64_t n, double *d_euler, int device_id, void *stream)
+{
+    if (!d_mat || !d_euler) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n <= 0) return n == 0 ? BPG_OK : fail(BPG_ERR_ARG, "n < 0");
+    DeviceGuard guard(device_id);
+    hipLaunchKernelGGL(k_mat2euler, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_mat, n, d_euler);
+    return check_launch("k_mat2euler");
 }
 
 int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_xy, int32_t *d_status, void *stream)

@@ -489,6 +489,18 @@ class BatchedBlocksEnv:
         self.state_ever.copy_(sd['ever'])
 
 
+def mat2euler(mat, device=None):
+    """gym.envs.robotics.rotations.mat2euler on the GPU: (..., 3, 3) float64 -> (..., 3).
+    Third-party formula restated from memory (parity unpinned, see include/bpgym.h)."""
+    dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+    m = (mat if torch.is_tensor(mat) else torch.as_tensor(np.asarray(mat))).to(dev, torch.float64).contiguous()
+    assert m.shape[-2:] == (3, 3)
+    n = int(m.numel() // 9)
+    out = torch.empty(m.shape[:-2] + (3,), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().bpg_mat2euler_f64(_ptr(m), n, _ptr(out), dev.index, _stream(dev)))
+    return out
+
+
 def compute_reward(achieved_goal, goal, device=None):
     """Stateless BlocksEnv.compute_reward on the GPU.  numpy in -> numpy float32 out,
     torch in -> torch float32 out (on `device`)."""

@@ -174,6 +174,11 @@ typedef struct {
 int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream);
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream);
 
+/* gym.envs.robotics.rotations.mat2euler (call sites fetch_env.py:205, :588): n row-major 3x3
+ * site matrices -> n euler triples for bpg_phys_state.d_obj_rot.  THIRD-PARTY code absent
+ * from the reference tree, restated from memory of gym 0.10 -- parity UNPINNED. */
+int bpg_mat2euler_f64(const double *d_mat, int64_t n, double *d_euler, int device_id, void *stream);
+
 /* _randomize_objects of the five env classes (fetch_env.py:328-336, 370-399, 448-517,
  * 697-764, 777-787): rejection-sampled cube positions for every env, d_xy (n, nb, 2) float64
  * (nb = num_objs-2 block slots; Variation leaves absent blocks untouched).  The output feeds

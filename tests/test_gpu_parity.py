@@ -249,13 +249,13 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
     # (3) contact-list kernel: rebuild geom-id lists from the masks
     env3 = bpg.make(env_id, num_envs=B, device=DEV)
     env3.reset(num_grey=num_grey)
-    maxcon = 24
     pair_of = {L.bpg_pair_index(i, j): (i, j) for i in range(6) for j in range(i, 6)}
     geom_of = []                                   # per model: object id -> a geom id
     for m in v['models']:
         geom_of.append({o: g for g, o in enumerate(m['id2obj']) if o >= 0})
     none_geom = [m['id2obj'].index(-1) for m in v['models']]
     for t in range(0, T, 7):
+        maxcon = 24 if (t // 7) % 2 == 0 else 23      # LDS-staged (maxcon % 4 == 0) and direct kernels
         pairs = np.zeros((B, maxcon, 2), np.int16)
         ncon = np.zeros(B, np.int32)
         for b in range(B):
@@ -646,3 +646,21 @@ def test_argument_errors_are_reported():
     assert (bits(r) == 0xBF800000).all()
     with pytest.raises(KeyError):
         bpg.make('NoSuchEnv-v0')
+
+
+def test_mat2euler_unpinned_formula():
+    """mat2euler is third-party (gym.envs.robotics.rotations) and absent from the reference
+    tree: PARITY UNPINNED.  This only checks the kernel against a NumPy statement of the
+    recalled gym-0.10 formula, tolerance 1e-13 (device atan2 vs libm), incl. the gimbal branch."""
+    rng = np.random.RandomState(0)
+    q, _ = np.linalg.qr(rng.normal(size=(500, 3, 3)))
+    q[:5, 2, 2] = 0.0
+    q[:5, 1, 2] = 0.0                    # cy == 0 -> second branch
+    cy = np.sqrt(q[:, 2, 2] ** 2 + q[:, 1, 2] ** 2)
+    cond = cy > np.finfo(np.float64).eps * 4.0
+    exp = np.empty((500, 3))
+    exp[:, 2] = np.where(cond, -np.arctan2(q[:, 0, 1], q[:, 0, 0]), -np.arctan2(-q[:, 1, 0], q[:, 1, 1]))
+    exp[:, 1] = -np.arctan2(-q[:, 0, 2], cy)
+    exp[:, 0] = np.where(cond, -np.arctan2(q[:, 1, 2], q[:, 2, 2]), 0.0)
+    got = bpg.mat2euler(q, device=DEV).cpu().numpy()
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-13)
