@@ -273,6 +273,34 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         _lib.check(L.bpg_rollout(env._h, C.byref(a2c), stream))
     res['rollout_masks_flags_only'] = line(timed(compact, 20), B * (T * 5 + 16), B * T)
 
+    # (3c) float view of the packed state: obs['achieved_goal'] (B, 36) f32
+    agv = torch.empty((B, env.dimg), dtype=torch.float32, device=dev)
+
+    def get_ag():
+        _lib.check(L.bpg_get_achieved_goal_f32(env._h, C.c_void_p(agv.data_ptr()), env.dimg, stream))
+    res['get_achieved_goal_f32'] = line(timed(get_ag, 50), B * (8 + 4 * env.dimg), B)
+
+    # (3d) HER-style batched compute_reward on float rows (4 B rows of 36): 288 B in + 4 B out per row
+    nrow = 4 * B
+    cr_ag = torch.randint(-1, 2, (nrow, env.dimg), device=dev).to(torch.float32)
+    cr_g = env._g[:1].expand(nrow, env.dimg).contiguous()
+    cr_out = torch.empty(nrow, dtype=torch.float32, device=dev)
+
+    def cr():
+        _lib.check(L.bpg_compute_reward_f32(C.c_void_p(cr_ag.data_ptr()), C.c_void_p(cr_g.data_ptr()), nrow,
+                                            env.dimg, C.c_void_p(cr_out.data_ptr()), dev.index, stream))
+    res['compute_reward_f32_rows'] = line(timed(cr, 20), nrow * (8 * env.dimg + 4), nrow)
+    del cr_ag, cr_g, cr_out
+
+    # (3e) policy-gradient discounted return: (T,B) f32 in, (B,T) f64 out
+    G = torch.empty((B, T), dtype=torch.float64, device=dev)
+
+    def dr():
+        _lib.check(L.bpg_discounted_return(C.c_void_p(reward.data_ptr()), B, T, 1.0 - 1.0 / T,
+                                           C.c_void_p(G.data_ptr()), dev.index, stream))
+    res['discounted_return_f64'] = line(timed(dr, 5), B * T * 12, B * T)
+    del G
+
     # (4) episode writer: float32 episode['ag'] (B,T+1,36), ['g'] (B,T,36), ['info_is_success'] (B,T,1)
     try:
         dimg = env.dimg

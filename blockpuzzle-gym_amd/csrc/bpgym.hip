@@ -1049,6 +1049,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 // fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
 // staged through LDS with coalesced loads (row stride padded odd).
 constexpr int CR_ROWS = 128;
+template <bool VEC4>
 __global__ void __launch_bounds__(CR_ROWS)
 k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
                      uint32_t *__restrict__ out)
@@ -1058,12 +1059,28 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
     float *s_g = s_ag + CR_ROWS * ldp;
     const int64_t row0 = (int64_t)blockIdx.x * CR_ROWS;
     const int rows = (int)((n - row0) < CR_ROWS ? (n - row0) : CR_ROWS);
-    const int total = rows * len;
     const float *pa = ag + row0 * len, *pg = g + row0 * len;
-    for (int f = threadIdx.x; f < total; f += CR_ROWS) {
-        const int r = f / len, k = f - r * len;
-        s_ag[r * ldp + k] = pa[f];
-        s_g[r * ldp + k] = pg[f];
+    if (VEC4) {
+        // len % 4 == 0: a float4 never straddles a row; (row, col) advance incrementally
+        const int qpr = len >> 2, total = rows * qpr;
+        int r = threadIdx.x / qpr, cq = threadIdx.x - r * qpr;
+        const int r_inc = CR_ROWS / qpr, c_inc = CR_ROWS - r_inc * qpr;
+        const float4 *a4 = reinterpret_cast<const float4 *>(pa), *g4 = reinterpret_cast<const float4 *>(pg);
+        for (int q = threadIdx.x; q < total; q += CR_ROWS) {
+            const float4 va = a4[q], vg = g4[q];
+            float *da = s_ag + r * ldp + 4 * cq, *dg = s_g + r * ldp + 4 * cq;
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            dg[0] = vg.x; dg[1] = vg.y; dg[2] = vg.z; dg[3] = vg.w;
+            r += r_inc; cq += c_inc;
+            if (cq >= qpr) { cq -= qpr; r++; }
+        }
+    } else {
+        const int total = rows * len;
+        for (int f = threadIdx.x; f < total; f += CR_ROWS) {
+            const int r = f / len, k = f - r * len;
+            s_ag[r * ldp + k] = pa[f];
+            s_g[r * ldp + k] = pg[f];
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < rows) {
@@ -1071,7 +1088,7 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
         float d = 0.0f;
         int cnt = 0;
         for (int k = 0; k < len; k++) {
-            d = __fadd_rn(d, __fmul_rn(ra[k], rg[k]));     // no fma contraction
+            d = d + ra[k] * rg[k];                         // FP_CONTRACT is off: separate mul / add
             cnt += (rg[k] != 0.0f) ? 1 : 0;
         }
         out[row0 + threadIdx.x] = (d != (float)cnt) ? RBITS_FAIL : RBITS_OK;
@@ -1109,10 +1126,49 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
 
 // ------------------------------ discounted return ---------------------------
 // policy_gradient/rollout.py:255-258.  One env per lane; G[t_] starts as r[t_]
-// and adds gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64,
-// unfused multiply/add so the rounding matches the reference's NumPy).  The
-// 64 x T tile of a wave is transposed through LDS so G (n, T) is written as
-// contiguous 8-byte-per-lane rows.
+// and adds gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64, products
+// and sums rounded separately, so the result matches the reference's NumPy bit for
+// bit).  The 64 x T tile of a wave is transposed through LDS so G (n, T) is written
+// as contiguous 8-byte-per-lane rows.  gamma**k (C pow, as Python computes it) comes
+// in through the kernel arguments.
+constexpr int DR_TMAX_REG = 64;
+struct PowTable { double v[DR_TMAX_REG]; };
+
+// T <= 64 (the registered envs use T = 50): rewards live in registers, fully unrolled
+template <int TT>
+__global__ void __launch_bounds__(64)
+k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable pw, double *__restrict__ G)
+{
+    constexpr int R = TT | 1;
+    __shared__ double tile[64 * R];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        double r[TT];
+#pragma unroll
+        for (int t = 0; t < TT; t++) r[t] = (double)reward_tb[(int64_t)t * n + base + lane];
+#pragma unroll
+        for (int t_ = 0; t_ < TT; t_++) {
+            double acc = r[t_];
+#pragma unroll
+            for (int t = t_ + 1; t < TT; t++) acc = acc + pw.v[t - t_] * r[t];
+            tile[lane * R + t_] = acc;
+        }
+    }
+    __syncthreads();
+    double *o = G + base * (int64_t)TT;
+    const int total = nvalid * TT;
+    int e = 0, rem = lane;
+    while (rem >= TT) { rem -= TT; e++; }
+    for (int f = lane; f < total; f += 64) {
+        o[f] = tile[e * R + rem];
+        rem += 64;
+        while (rem >= TT) { rem -= TT; e++; }
+    }
+}
+
+// generic T: rewards staged in LDS
 __global__ void __launch_bounds__(64)
 k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R,
                     const double *__restrict__ pw, double *__restrict__ G)
@@ -1127,7 +1183,7 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
         for (int t = 0; t < T; t++) my[t] = (double)reward_tb[(int64_t)t * n + base + lane];
         for (int t_ = 0; t_ < T; t_++) {
             double acc = my[t_];
-            for (int t = t_ + 1; t < T; t++) acc = __dadd_rn(acc, __dmul_rn(pw[t - t_], my[t]));
+            for (int t = t_ + 1; t < T; t++) acc = acc + pw[t - t_] * my[t];
             my[t_] = acc;          // r[t_] is not needed by later (larger t_) rows
         }
     }
@@ -1611,11 +1667,17 @@ int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int l
     DeviceGuard guard(device_id);
     const int ldp = len | 1;
     const size_t lds = (size_t)2 * CR_ROWS * ldp * sizeof(float);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_compute_reward_f32),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_compute_reward_f32, dim3((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), dim3(CR_ROWS), lds,
-                       (hipStream_t)stream, d_ag, d_g, n, len, ldp, reinterpret_cast<uint32_t *>(d_out));
+    const bool vec = (len % 4 == 0) && (len / 4 <= CR_ROWS) && aligned16(d_ag) && aligned16(d_g);
+    const void *fn = vec ? reinterpret_cast<const void *>(k_compute_reward_f32<true>)
+                         : reinterpret_cast<const void *>(k_compute_reward_f32<false>);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), block(CR_ROWS);
+    if (vec)
+        hipLaunchKernelGGL(k_compute_reward_f32<true>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp,
+                           reinterpret_cast<uint32_t *>(d_out));
+    else
+        hipLaunchKernelGGL(k_compute_reward_f32<false>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len,
+                           ldp, reinterpret_cast<uint32_t *>(d_out));
     return check_launch("k_compute_reward_f32");
 }
 
@@ -1723,6 +1785,21 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     // gamma ** k exactly as the reference's Python float pow (C pow)
     std::vector<double> pw((size_t)T);
     for (int k = 0; k < T; k++) pw[(size_t)k] = std::pow(gamma, (double)k);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (T == 50 || T == 25 || T == 10) {
+        // register-resident fast path for the horizons in use (T = max_episode_steps = 50);
+        // fully asynchronous: the table travels in the kernel arguments
+        PowTable tab;
+        std::memset(&tab, 0, sizeof(tab));
+        for (int k = 0; k < T; k++) tab.v[k] = pw[(size_t)k];
+        if (T == 50)
+            hipLaunchKernelGGL(k_discounted_return_reg<50>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+        else if (T == 25)
+            hipLaunchKernelGGL(k_discounted_return_reg<25>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+        else
+            hipLaunchKernelGGL(k_discounted_return_reg<10>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+        return check_launch("k_discounted_return_reg");
+    }
     double *d_pw = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_pw), sizeof(double) * (size_t)T));
     hipError_t ce = hipMemcpyAsync(d_pw, pw.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice,
@@ -1742,8 +1819,8 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
         if (e != hipSuccess) rc = fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (rc == BPG_OK) {
-        hipLaunchKernelGGL(k_discounted_return, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
-                           d_reward_tb, n, T, R, d_pw, d_G);
+        hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, T, R, d_pw,
+                           d_G);
         rc = check_launch("k_discounted_return");
     }
     (void)hipFree(d_pw);      // synchronises with the kernel that reads the table
