@@ -217,6 +217,10 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         return {'ms': ms, 'GB/s': gbs, 'frac_hbm_peak': gbs / HBM_PEAK_GBS, 'bytes': nbytes,
                 'env_steps_per_sec': env_steps / (ms * 1e-3)}
 
+    # (0) on-box streaming ceiling: device-to-device copy of one (T,B) u32 array (read + write)
+    src, dst = masks, reward.view(torch.int32)
+    res['copy_ceiling_torch_d2d'] = line(timed(lambda: dst.copy_(src), 20), 2 * masks.numel() * 4, 0)
+
     # (1) one env.step launch: 12 B in (now, ever, mask) + 13 B out (now, ever, reward, flags) = 25 B/env-step
     def step_once():
         _lib.check(L.bpg_step_masks(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),

@@ -664,3 +664,46 @@ def test_mat2euler_unpinned_formula():
     exp[:, 0] = np.where(cond, -np.arctan2(q[:, 1, 2], q[:, 2, 2]), 0.0)
     got = bpg.mat2euler(q, device=DEV).cpu().numpy()
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-13)
+
+
+def test_rollout_student_torch_policy_matches_numpy_policy():
+    """A device-resident policy (`device_tensors = True`: torch in / torch out, nothing crosses
+    PCIe) produces the same episode as the NumPy-policy path; pg worker with an expert."""
+    env_id, B, T = 'BlocksTouchChooseCurriculum-v0', 300, 50
+    rng = np.random.RandomState(1)
+    acts = rng.uniform(-1, 1, size=(T, B, 4)).astype(np.float32)
+    masks = legal_masks(rng, T, B, 5, density=4)
+
+    class NpPolicy:
+        def __init__(self):
+            self.t = 0
+
+        def get_actions(self, o, ag, g, **kw):
+            assert isinstance(o, np.ndarray)
+            self.t += 1
+            return acts[self.t - 1]
+
+    class TorchPolicy(NpPolicy):
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            assert torch.is_tensor(o) and o.is_cuda and ag.shape == (B, 25)
+            self.t += 1
+            return torch.as_tensor(acts[self.t - 1], device=DEV), torch.zeros(B, device=DEV)
+
+    eps = []
+    for pol, compute_Q in ((NpPolicy(), False), (TorchPolicy(), True)):
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV,
+                                                         contact_source=bpg.ScriptedContacts(masks=i32(masks))),
+                               pol, dims_of(env_id), None, T, rollout_batch_size=B, compute_Q=compute_Q)
+        ep = w.generate_rollouts()
+        eps.append({k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in ep.items()})
+        assert (torch.is_tensor(ep['ag'])) == isinstance(pol, TorchPolicy)
+        assert w.logs('test')[0][0] == 'test/success_rate' and w.current_success_rate() == w.success_history[-1]
+    for k in eps[0]:
+        np.testing.assert_array_equal(eps[0][k], eps[1][k], err_msg=k)
+    ref, _ = O.generate_rollouts(env_id, B, T, masks)
+    np.testing.assert_array_equal(eps[0]['ag'], ref['ag'])
+    np.testing.assert_array_equal(eps[0]['u'], acts.transpose(1, 0, 2))
+    # increase_difficulty through the worker (rollout.py:66-73)
+    assert w.increase_difficulty() == 1

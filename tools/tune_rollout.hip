@@ -55,6 +55,37 @@ v_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     }
 }
 
+// time-major rows with a padded row stride (ld4 in uint4 units): do the T rows in flight alias
+// in the DRAM channel / bank mapping when the stride is a power of two?
+template <int BLOCK, int UNROLL>
+__global__ void __launch_bounds__(BLOCK)
+v_rollout_ld(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+             uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T, int64_t ld4,
+             StepConst c)
+{
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        uint4 a = reinterpret_cast<uint4 *>(now)[v];
+        uint4 e = reinterpret_cast<uint4 *>(ever)[v];
+        uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w};
+        const uint4 *mrow = reinterpret_cast<const uint4 *>(masks) + v;
+        uint4 *rrow = reinterpret_cast<uint4 *>(reward_tb) + v;
+        uint32_t *frow = reinterpret_cast<uint32_t *>(flags_tb) + v;
+#pragma unroll UNROLL
+        for (int t = 0; t < T; t++) {
+            const uint4 m = mrow[(int64_t)t * ld4];
+            uint32_t mm[4] = {m.x, m.y, m.z, m.w}, rb[4], fl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) step_core(an[k], ee[k], mm[k], c, rb[k], fl[k]);
+            st4<true>(&rrow[(int64_t)t * ld4], make_uint4(rb[0], rb[1], rb[2], rb[3]));
+            st1<true>(&frow[(int64_t)t * ld4], fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24));
+        }
+        reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
+        reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
+    }
+}
+
 // same byte mix, no env logic: the streaming ceiling for this access pattern
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -100,8 +131,8 @@ int main(int argc, char **argv)
     uint32_t *now, *ever, *masks_[NB], *reward_[NB]; uint8_t *flags_[NB];
     CK(hipMalloc(&now, B * 4)); CK(hipMalloc(&ever, B * 4));
     for (int k = 0; k < NB; k++) {
-        CK(hipMalloc(&masks_[k], (size_t)B * T * 4)); CK(hipMalloc(&reward_[k], (size_t)B * T * 4));
-        CK(hipMalloc(&flags_[k], (size_t)B * T));
+        CK(hipMalloc(&masks_[k], (size_t)(B + 65536) * T * 4)); CK(hipMalloc(&reward_[k], (size_t)(B + 65536) * T * 4));
+        CK(hipMalloc(&flags_[k], (size_t)(B + 65536) * T));
     }
     int rot = 0;
 #define masks masks_[rot % NB]
@@ -155,6 +186,27 @@ int main(int argc, char **argv)
                                     reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
         }
+        {
+            ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1;
+            static unsigned long long *cnt = nullptr;
+            if (!cnt) { CK(hipMalloc(&cnt, 16)); CK(hipMemset(cnt, 0, 16)); }
+            TIME("LIB +count 256 blocks x 1024", bytes,
+                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
+                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+            TIME("LIB +count 512 blocks x 512", bytes,
+                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(512), dim3(512), 0, 0, now, ever, masks,
+                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+            TIME("LIB +count 1024 blocks x 256", bytes,
+                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
+                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+            TIME("LIB nocount 1024 blocks x 256", bytes,
+                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
+                                    reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
+                                    (unsigned long long *)nullptr));
+            TIME("LIB +count 2048 blocks x 128", bytes,
+                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(2048), dim3(128), 0, 0, now, ever, masks,
+                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+        }
         ROLL(1024, 5, false, false, 256);
         ROLL(256, 5, false, false, 1024);
         ROLL(256, 5, false, false, 2048);
@@ -166,6 +218,11 @@ int main(int argc, char **argv)
         ROLL(256, 5, false, true, 1024);
         ROLL(256, 5, true, true, 1024);
         ROLL(1024, 5, true, true, 256);
+#define ROLLLD(PAD)                                                                                            \
+    TIME("rollout ld = B/4 + " #PAD " uint4 (nts)", bytes,                                                      \
+         hipLaunchKernelGGL((v_rollout_ld<256, 5>), dim3(1024), dim3(256), 0, 0, now, ever, masks, reward, flags, B, \
+                            T, (int64_t)(B / 4 + PAD), c))
+        ROLLLD(0); ROLLLD(16); ROLLLD(64); ROLLLD(256); ROLLLD(1024); ROLLLD(4096); ROLLLD(4112);
         ROLL(1024, 10, true, true, 256);
         printf("--\n");
     }
