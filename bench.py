@@ -227,6 +227,18 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
                                     C.c_void_p(flags.data_ptr()), stream))
     res['step_masks_single_launch'] = line(timed(step_once, 200), 25 * B, B)
 
+    # (1a) the rollout worker's step: step + float32 achieved_goal row + float32 is_success in one launch:
+    # 12 B in, 13 + 4 + 144 B out = 173 B/env-step
+    agrec = torch.empty((B, env.dimg), dtype=torch.float32, device=dev)
+    succ_f = torch.empty(B, dtype=torch.float32, device=dev)
+
+    def step_record():
+        _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
+                                     C.c_void_p(flags.data_ptr()), C.c_void_p(succ_f.data_ptr()),
+                                     C.c_void_p(agrec.data_ptr()), env.dimg, stream))
+    res['step_record_single_launch'] = line(timed(step_record, 100), (29 + 4 * env.dimg) * B, B)
+    del agrec, succ_f
+
     # (1b) one env.step launch with the contacts as the reference reads them: geom-id pair lists
     # (B, maxcon=16, 2) int16 + ncon; bytes = 8 state + 4 ncon + 64 list in, 13 out = 89 B/env-step
     try:

@@ -705,6 +705,88 @@ k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, in
     }
 }
 
+// One env.step as the rollout worker consumes it (rollout.py:121-131): the step, the
+// float32 obs['achieved_goal'] row (at out + e*ld: a dense (n, dimg) array or the time slot
+// of an episode buffer) and info['is_success'] as float32, in ONE launch -- the packed state
+// never makes a second trip through HBM and the host issues one launch instead of five.
+template <int SIDE, int SRC, bool VEC4>
+__global__ void __launch_bounds__(64)
+k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+              uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, float *__restrict__ succ_f32,
+              float *__restrict__ ag, int64_t ld, int64_t n, StepConst c, SynthConst s, PairTable tabv)
+{
+    constexpr int DIMG = SIDE * SIDE;
+    __shared__ uint2 hist[64];
+    __shared__ PairTable tab;
+    const int lane = threadIdx.x;
+    if (lane == 0) tab = tabv;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        const int64_t i = base + lane;
+        uint32_t a = now[i], e = ever[i], rb, fl;
+        uint32_t key = 0;
+        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        step_core(a, e, mk, c, rb, fl);
+        now[i] = a; ever[i] = e;
+        hist[lane] = make_uint2(a, e);
+        if (reward) reward[i] = rb;
+        if (flags) flags[i] = (uint8_t)fl;
+        if (succ_f32) succ_f32[i] = (fl & BPG_FLAG_SUCCESS) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (!ag) return;
+    float *o = ag + base * ld;
+    if (VEC4) {
+        constexpr int QPR = DIMG / 4;
+        for (int cidx = lane; cidx < nvalid * QPR; cidx += 64) {
+            const int e = cidx / QPR, q = cidx - e * QPR;
+            const uint2 h = hist[e];
+            const uint32_t pw = tab.quad[q];
+            float4 v;
+            v.x = tern(h.x, h.y, pw & 31u);
+            v.y = tern(h.x, h.y, (pw >> 5) & 31u);
+            v.z = tern(h.x, h.y, (pw >> 10) & 31u);
+            v.w = tern(h.x, h.y, (pw >> 15) & 31u);
+            *reinterpret_cast<float4 *>(o + e * ld + 4 * q) = v;
+        }
+    } else {
+        for (int f = lane; f < nvalid * DIMG; f += 64) {
+            const int e = f / DIMG, k = f - e * DIMG;
+            const uint2 h = hist[e];
+            o[e * ld + k] = tern(h.x, h.y, tab.flat[k]);
+        }
+    }
+}
+
+// Geom-id contact lists -> packed pair masks (fetch_env.py:158-167 up to the matrix write), so
+// a backend that produces contact lists can feed the mask-based fused kernels.
+__global__ void __launch_bounds__(256)
+k_contacts_to_masks(const uint32_t *__restrict__ ever, const int16_t *__restrict__ contacts,
+                    const int32_t *__restrict__ ncon, int maxcon, const int8_t *__restrict__ id2obj,
+                    int is_variation, uint32_t valid, uint32_t *__restrict__ out, int64_t n)
+{
+    __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
+    for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int model = 0;
+        if (is_variation) {
+            model = (int)nobj_of(ever[i]) - 4;
+            model = model < 0 ? 0 : (model > 2 ? 2 : model);
+        }
+        const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
+        int nc = ncon[i];
+        nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(contacts) + i * maxcon;
+        uint32_t m = 0;
+        for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
+        out[i] = m & valid;
+    }
+}
+
 // ------------------------------ observation assembly ------------------------
 // obs['observation'] of _get_obs (fetch_env.py:187-228, Variation :567-621) from the
 // quantities the reference reads off the simulator.  One output element per lane
@@ -1517,6 +1599,55 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
                            d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
                            reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
     return check_launch("k_step_contacts");
+}
+
+int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
+                          uint32_t *d_masks, void *stream)
+{
+    if (!b || !d_contacts || !d_ncon || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
+    if (maxcon < 1 || maxcon > 4096) return fail(BPG_ERR_ARG, "maxcon must be in 1..4096");
+    if (!aligned4(d_contacts) || !aligned4(d_masks)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
+    for (int m = 0; m < models; m++)
+        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_contacts_to_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
+                       d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
+                       b->n);
+    return check_launch("k_contacts_to_masks");
+}
+
+int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, float *d_success_f32,
+                    float *d_ag, int64_t ld, void *stream)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (d_ag && ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
+    if (!aligned4(d_masks) || !aligned4(d_reward) || !aligned4(d_success_f32) || !aligned4(d_ag))
+        return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    DeviceGuard guard(b->device);
+    const StepConst c = step_const(b);
+    const SynthConst s = synth_const(b);
+    const PairTable tab = pair_table(b->info);
+    const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+    const bool vec = (b->info.side % 2 == 0) && (ld % 4 == 0) && aligned16(d_ag);
+    const bool synth = (d_masks == nullptr);
+    uint32_t *rw = reinterpret_cast<uint32_t *>(d_reward);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dispatch_side(b->info.side, [&](auto side) {
+        constexpr int S = decltype(side)::value;
+        constexpr bool EVEN = (S % 2 == 0);
+#define BPG_LAUNCH_SR(SRC, V)                                                                                  \
+        hipLaunchKernelGGL((k_step_record<S, SRC, V>), grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags, \
+                           d_success_f32, d_ag, ld, b->n, c, s, tab)
+        if (synth) {
+            if (vec) BPG_LAUNCH_SR(SRC_SYNTH, EVEN); else BPG_LAUNCH_SR(SRC_SYNTH, false);
+        } else {
+            if (vec) BPG_LAUNCH_SR(SRC_MASKS, EVEN); else BPG_LAUNCH_SR(SRC_MASKS, false);
+        }
+#undef BPG_LAUNCH_SR
+        return BPG_OK;
+    });
+    return rc != BPG_OK ? rc : check_launch("k_step_record");
 }
 
 int bpg_synth_masks(bpg_batch *b, int t0, int T, uint32_t *d_masks, void *stream)

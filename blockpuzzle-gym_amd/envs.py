@@ -332,10 +332,8 @@ class BatchedBlocksEnv:
             self._fill_static_observation()
         return self._get_obs()
 
-    def step(self, action, contact_masks=None, contacts=None, ag_out=None):
-        """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info).
-        ag_out: optional (B, dimg) float32 view with unit inner stride (e.g. a time slot of
-        a batch-major episode buffer) that receives obs['achieved_goal'] directly."""
+    def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None):
+        """Launches one env step; returns (reward, flags, achieved_goal) device tensors."""
         a = self._to_dev(action, torch.float32)
         if a is not None:
             a = a.reshape(self.num_envs, self.dimu)
@@ -353,26 +351,54 @@ class BatchedBlocksEnv:
         # the kernels write straight into them, so this costs an allocation, not a copy
         reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
         flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
-        if contact_masks is not None:
-            m = self._to_dev(contact_masks, torch.int32) if not (
-                torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
-            ) else contact_masks.to(self.device).contiguous()
-            assert m.numel() == self.num_envs
-            _lib.check(self._L.bpg_step_masks(self._h, _ptr(m), _ptr(reward), _ptr(flags), st))
-        elif contacts is not None:
+        if ag_out is None:
+            ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
+        else:
+            ag = ag_out
+            assert ag.shape == (self.num_envs, self.dimg) and ag.dtype == torch.float32 and ag.stride(1) == 1
+        if contacts is not None:
             pairs = self._to_dev(contacts[0], torch.int16)
             ncon = self._to_dev(contacts[1], torch.int32)
             assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
             _lib.check(self._L.bpg_step_contacts(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]),
                                                  _ptr(reward), _ptr(flags), st))
+            _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), int(ag.stride(0)), st))
+            if succ_out is not None:
+                succ_out.copy_((flags & _lib.FLAG_SUCCESS).reshape(succ_out.shape))
         else:
-            _lib.check(self._L.bpg_step_synth(self._h, _ptr(reward), _ptr(flags), st))
-        obs = self._get_obs(ag_out)
+            m = None
+            if contact_masks is not None:
+                m = contact_masks.to(self.device).contiguous() if (
+                    torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
+                ) else self._to_dev(contact_masks, torch.int32)
+                assert m.numel() == self.num_envs
+            if succ_out is not None:
+                assert succ_out.numel() == self.num_envs and succ_out.is_contiguous() and succ_out.dtype == torch.float32
+            # step + float achieved_goal (+ float success) in one launch; NULL masks = synthetic source
+            _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
+                                               _ptr(ag), int(ag.stride(0)), st))
+        return reward, flags, ag
+
+    def step(self, action, contact_masks=None, contacts=None, ag_out=None):
+        """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info).
+        ag_out: optional (B, dimg) float32 view with unit inner stride (e.g. a time slot of
+        an episode buffer) that receives obs['achieved_goal'] directly."""
+        reward, flags, ag = self._step_core(action, contact_masks, contacts, ag_out)
+        obs = self._obs_dict(ag)
         done = (flags & _lib.FLAG_DONE) != 0
         succ = (flags & _lib.FLAG_SUCCESS) != 0
         if self.scalar_api:
             return obs, np.float32(reward[0].item()), bool(done[0].item()), {'is_success': bool(succ[0].item())}
         return obs, reward, done, {'is_success': succ}
+
+    def _obs_dict(self, ag):
+        if self.scalar_api:
+            # reference dtypes (quirk Q9): float64 obs/ag, int64 goal (Variation float64)
+            return {'observation': self.observation[0].double().cpu().numpy(),
+                    'achieved_goal': ag[0].double().cpu().numpy(),
+                    'desired_goal': self.goal.copy()}
+        # achieved_goal is a fresh tensor; observation / desired_goal are the env's shared buffers
+        return {'observation': self.observation, 'achieved_goal': ag, 'desired_goal': self._g}
 
     def _get_obs(self, ag_out=None):
         """fetch_env.py:219-228 (achieved_goal / desired_goal parts)."""
@@ -382,13 +408,7 @@ class BatchedBlocksEnv:
             ag = ag_out
             assert ag.shape == (self.num_envs, self.dimg) and ag.dtype == torch.float32 and ag.stride(1) == 1
         _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), int(ag.stride(0)), _stream(self.device)))
-        if self.scalar_api:
-            # reference dtypes (quirk Q9): float64 obs/ag, int64 goal (Variation float64)
-            return {'observation': self.observation[0].double().cpu().numpy(),
-                    'achieved_goal': ag[0].double().cpu().numpy(),
-                    'desired_goal': self.goal.copy()}
-        # achieved_goal is a fresh tensor; observation / desired_goal are the env's shared buffers
-        return {'observation': self.observation, 'achieved_goal': ag, 'desired_goal': self._g}
+        return self._obs_dict(ag)
 
     def achieved_goal_f64(self):
         out = torch.empty(self.num_envs, self.dimg, dtype=torch.float64, device=self.device)

@@ -122,12 +122,20 @@ class RolloutStudent:
             return ts
         return tuple(t.cpu().numpy() for t in ts)
 
-    def _alloc_episode(self):
+    def _alloc_episode(self, time_major=False, o=True, g=True):
+        """Episode buffers.  time_major=True allocates (T[+1], B, .) and the caller returns
+        transposed views -- exactly what the reference hands out: convert_episode_to_batch_major
+        (util.py:118-128) is a swapaxes(0, 1) VIEW of the time-major arrays."""
         B, T, d = self.rollout_batch_size, self.T, self.dims
         f32 = dict(dtype=torch.float32, device=self.device)
-        return dict(o=torch.zeros((B, T + 1, d['o']), **f32), u=torch.zeros((B, T, d['u']), **f32),
-                    g=torch.empty((B, T, d['g']), **f32), ag=torch.empty((B, T + 1, d['g']), **f32),
-                    info_is_success=torch.empty((B, T, 1), **f32))
+        shp = (lambda n, k: (n, B, k)) if time_major else (lambda n, k: (B, n, k))
+        ep = dict(u=torch.zeros(shp(T, d['u']), **f32), ag=torch.empty(shp(T + 1, d['g']), **f32),
+                  info_is_success=torch.empty(shp(T, 1), **f32))
+        if o:
+            ep['o'] = torch.empty(shp(T + 1, d['o']), **f32)
+        if g:
+            ep['g'] = torch.empty(shp(T, d['g']), **f32)
+        return ep
 
     def _finish(self, episode, Qs=()):
         succ_last = episode['info_is_success'][:, -1, 0]
@@ -147,14 +155,15 @@ class RolloutStudent:
         for the whole batch per time step.  Returns the batch-major episode."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
-        ep = self._alloc_episode()
-        # o / ag of step t ARE the episode's time slot t (rollout.py:144-153 appends copies):
-        # the env writes the next achieved_goal straight into slot t+1
-        ep['o'][:, 0] = self.initial_o
-        ep['ag'][:, 0] = self.initial_ag
+        # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
+        # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
+        # the next achieved_goal straight into slot t+1
+        ep = self._alloc_episode(time_major=True, g=False)
+        ep['o'][0] = self.initial_o
+        ep['ag'][0] = self.initial_ag
         Qs = []
         for t in range(T):
-            o, ag = ep['o'][:, t], ep['ag'][:, t]
+            o, ag = ep['o'][t], ep['ag'][t]
             policy_output = self.policy.get_actions(
                 *self._policy_in(o, ag, self.g),
                 compute_Q=self.compute_Q,
@@ -167,31 +176,41 @@ class RolloutStudent:
             else:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
-            ep['u'][:, t] = u
-            # reward ignored: recomputed for HER (rollout.py:123-125)
-            obs, _, _, info = env.step(u, ag_out=ep['ag'][:, t + 1])
-            ep['info_is_success'][:, t, 0] = info['is_success']
-            ep['o'][:, t + 1] = obs['observation']
-        ep['g'][:] = self.g[:, None, :]           # the goal is constant over the episode (rollout.py:151)
-        self.initial_o.copy_(ep['o'][:, T])
+            ep['u'][t] = u
+            # reward ignored: recomputed for HER (rollout.py:123-125); the step kernel writes the
+            # next achieved_goal and the float is_success column straight into their slots
+            env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t])
+            ep['o'][t + 1] = env.observation
+        self.initial_o.copy_(ep['o'][T])
+        ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
+        # the goal is constant over the episode (rollout.py:151 appends the same array T times)
+        ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         return self._finish(ep, Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
-                                want_reward=False):
+                                want_reward=False, materialize_constants=False):
         """Whole rollout in ONE kernel launch (no policy between steps): contacts
         come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
         source when None.  Same episode dict as generate_rollouts; `o` is the
-        env's physics-less observation repeated, `u` = `actions` or zeros."""
+        env's physics-less observation repeated, `u` = `actions` or zeros.
+        The arrays that are constant over the episode (`g`, and `o` without a physics
+        backend) are returned as stride-0 expanded views unless materialize_constants=True,
+        which makes the kernel write contiguous float32 copies of them as well."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
-        ep = self._alloc_episode()
-        ep['o'][:] = self.initial_o[:, None, :]
+        ep = self._alloc_episode(o=materialize_constants, g=materialize_constants)
+        if materialize_constants:
+            ep['o'].copy_(self.initial_o[:, None, :].expand(B, T + 1, self.dims['o']))
+        else:
+            ep['o'] = self.initial_o.clone()[:, None, :].expand(B, T + 1, self.dims['o'])
+            ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         if actions is not None:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device).clamp(-1, 1))
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device) if want_reward else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
-                                d_ep_ag=ep['ag'].data_ptr(), d_ep_g=ep['g'].data_ptr(),
+                                d_ep_ag=ep['ag'].data_ptr(),
+                                d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
                                 d_ep_success=ep['info_is_success'].data_ptr())
         if masks is not None:
             assert masks.shape == (T, B) and masks.is_contiguous() and masks.element_size() == 4
@@ -257,11 +276,13 @@ class PGRolloutStudent(RolloutStudent):
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
         beta = self.beta() if self.expert is not None else 0
-        ep = self._alloc_episode()
-        ep['sigma'] = torch.zeros((B, T, self.dims['u']), dtype=torch.float32, device=self.device)
+        ep = self._alloc_episode(time_major=True, g=False)
+        ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device)
-        o, ag = self.initial_o.clone(), self.initial_ag.clone()
+        ep['o'][0] = self.initial_o
+        ep['ag'][0] = self.initial_ag
         for t in range(T):
+            o, ag = ep['o'][t], ep['ag'][t]
             if np.random.rand() < beta:
                 if o.shape[-1] != self.expert.dimo:
                     raise NotImplementedError('expert observation trimming (policy_gradient/rollout.py:105-171)')
@@ -272,15 +293,14 @@ class PGRolloutStudent(RolloutStudent):
             if self.expert is not None:
                 sigma = None
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
-            raw = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
-            ep['o'][:, t], ep['ag'][:, t], ep['u'][:, t], ep['g'][:, t] = o, ag, raw, self.g
+            ep['u'][t] = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
             if sigma is not None:
-                ep['sigma'][:, t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
-            obs, r, _, info = env.step(u)
+                ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
+            r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t])
             reward[t] = r
-            ep['info_is_success'][:, t, 0] = info['is_success'].to(torch.float32)
-            o, ag = obs['observation'], obs['achieved_goal']
-        ep['o'][:, T], ep['ag'][:, T] = o, ag
-        self.initial_o.copy_(o)
+            ep['o'][t + 1] = env.observation
+        self.initial_o.copy_(ep['o'][T])
+        ep = {k: v.transpose(0, 1) for k, v in ep.items()}
+        ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         ep['G'] = discounted_return(reward, self.gamma)
         return self._finish(ep)

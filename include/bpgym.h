@@ -140,6 +140,19 @@ int bpg_step_masks(bpg_batch *b, const uint32_t *d_masks, float *d_reward,
 int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon,
                       int maxcon, float *d_reward, uint8_t *d_flags, void *stream);
 
+/* The id2obj half of _step_callback on its own (fetch_env.py:158-166): geom-id pair lists ->
+ * packed pair masks d_masks[n_envs], so a backend that emits contact lists can drive the
+ * mask-based kernels (bpg_step_record, bpg_rollout). */
+int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
+                          uint32_t *d_masks, void *stream);
+
+/* One env.step exactly as the rollout worker consumes it (rollout.py:121-131), in ONE launch:
+ * the step of bpg_step_masks (d_masks NULL = synthetic source) plus obs['achieved_goal'] as
+ * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32) and
+ * info['is_success'] as float32 d_success_f32[n_envs].  Every output pointer is optional. */
+int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
+                    float *d_success_f32, float *d_ag, int64_t ld, void *stream);
+
 /* One step whose contacts come from the build-defined counter-based synthetic
  * source keyed (seed, global env id, elapsed step) -- physics stand-in for
  * throughput runs, no reference counterpart. */
