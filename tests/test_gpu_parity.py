@@ -707,3 +707,31 @@ def test_rollout_student_torch_policy_matches_numpy_policy():
     np.testing.assert_array_equal(eps[0]['u'], acts.transpose(1, 0, 2))
     # increase_difficulty through the worker (rollout.py:66-73)
     assert w.increase_difficulty() == 1
+
+
+@pytest.mark.parametrize('env_id', ['BlocksTouchVariation-v0', 'ToppleTower-v0', 'GripperTouch-v0'])
+def test_contacts_to_masks_matches_oracle(env_id):
+    """bpg_contacts_to_masks (the id2obj half of _step_callback) on the golden rollouts'
+    geom-id contact lists == the oracle's mask of the same list; feeding those masks to the
+    fused kernel reproduces the reference episode."""
+    import ctypes as C
+    d = np.load(os.path.join(GOLDEN, 'rollout_%s.npz' % short(env_id)))
+    B, T = int(d['B']), int(d['T'])
+    L = bpg._lib.lib()
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
+                           dims_of(env_id), None, T, rollout_batch_size=B)
+    for r in range(2):
+        w.env.reset(num_grey=d['r%d_num_objs' % r] - 4)          # selects each env's id2obj model
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        dm = torch.empty((T, B), dtype=torch.int32, device=DEV)
+        for t in range(T):
+            pairs = torch.as_tensor(np.ascontiguousarray(con[:, t]), device=DEV)
+            ncon = torch.as_tensor(np.ascontiguousarray(d['r%d_ncon' % r][:, t]), device=DEV)
+            bpg._lib.check(L.bpg_contacts_to_masks(w.env._h, C.c_void_p(pairs.data_ptr()), C.c_void_p(ncon.data_ptr()),
+                                                   int(pairs.shape[1]), C.c_void_p(dm[t].data_ptr()), None))
+        exp = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
+        np.testing.assert_array_equal(dm.cpu().numpy().view(np.uint32), exp)
+        ep = w.generate_rollouts_fused(masks=dm, num_grey=d['r%d_num_objs' % r] - 4)
+        np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
+        np.testing.assert_array_equal(ep['info_is_success'], d['r%d_info_is_success' % r])
