@@ -1,0 +1,73 @@
+"""Two ranks, one process each, both on cuda:0 (the GPU box has a single card), gloo for the
+collectives: the sharded path end to end on the real kernels -- contiguous env shards keyed by
+global env index, no data-path collective, one all-gather / all-reduce per rollout."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV_ID, TOTAL, T, SEED = 'BlocksTouchVariation-v0', 40001, 50, 77
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rollout(env):
+    import ctypes as C
+    import blockpuzzle_gym_amd as bpg
+    rew = torch.empty((T, env.num_envs), dtype=torch.float32, device=env.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=env.device)
+    args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_reward_tb=rew.data_ptr(), d_success_count=cnt.data_ptr())
+    bpg._lib.check(bpg._lib.lib().bpg_rollout(env._h, C.byref(args), None))
+    ret = rew.double().sum(0).float()                  # per-env undiscounted episode return
+    succ = (env.state_ever < 0).float()
+    return ret, succ, cnt
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from blockpuzzle_gym_amd import distributed as D
+    r, w, _ = D.init_from_env(backend='gloo')
+    env = D.make_sharded(ENV_ID, TOTAL, r, w, device='cuda:0', seed=SEED)
+    ret, succ, cnt = _rollout(env)
+    all_ret = D.all_gather_per_env(ret.cpu())
+    all_succ = D.all_gather_per_env(succ.cpu())
+    rate = D.global_success_rate(cnt.cpu()[0], env.num_envs)
+    q.put((r, env.num_envs, all_ret.numpy(), all_succ.numpy(), rate))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharded_rollout_equals_single_batch():
+    sys.path.insert(0, ROOT)
+    import blockpuzzle_gym_amd as bpg
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = bpg.make(ENV_ID, num_envs=TOTAL, device='cuda:0', seed=SEED)
+    ret, succ, cnt = _rollout(full)
+    assert sorted(r[1] for r in results) == [TOTAL // 2, TOTAL - TOTAL // 2]
+    for _, _, all_ret, all_succ, rate in results:
+        np.testing.assert_array_equal(all_ret, ret.cpu().numpy())
+        np.testing.assert_array_equal(all_succ, succ.cpu().numpy())
+        assert rate == pytest.approx(float(cnt.item()) / TOTAL, abs=1e-12)

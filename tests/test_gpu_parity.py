@@ -735,3 +735,32 @@ def test_contacts_to_masks_matches_oracle(env_id):
         ep = w.generate_rollouts_fused(masks=dm, num_grey=d['r%d_num_objs' % r] - 4)
         np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
         np.testing.assert_array_equal(ep['info_is_success'], d['r%d_info_is_success' % r])
+
+
+def test_time_limit_saturation_at_maximum_horizon():
+    """max_episode_steps = T = 1023 (the largest the 10-bit elapsed field allows): `done` flips
+    exactly at step 1023 and stays set; further steps keep saturating instead of wrapping."""
+    import ctypes as C
+    env_id, B, T = 'BlocksTouch-v0', 70, 1023
+    rng = np.random.RandomState(0)
+    masks = legal_masks(rng, T, B, 4, density=5)
+    env = bpg.make(env_id, num_envs=B, device=DEV, max_episode_steps=T)
+    env.reset()
+    flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, d_masks=i32(masks).data_ptr(), d_flags_tb=flg.data_ptr(), d_reward_tb=rew.data_ptr())
+    bpg._lib.check(bpg._lib.lib().bpg_rollout(env._h, C.byref(args), None))
+    f = flg.cpu().numpy()
+    assert not (f[:-1] & 2).any() and (f[-1] & 2).all()
+    L = O.lib()
+    envs = (O.Env * B)()
+    for b in range(B):
+        L.orc_env_init(C.byref(envs[b]), O.VARIANTS[env_id], T)
+    ref, _ = O.generate_rollouts(env_id, B, T, masks, envs=envs)
+    np.testing.assert_array_equal(bits(rew), ref['reward'].view(np.uint32))
+    for _ in range(3):                                   # past the limit: still done, no wrap-around
+        _, _, done, _ = env.step(None, contact_masks=np.zeros(B, np.int32))
+        assert done.all()
+    assert ((env.state_now >> 21) & 1023 == 1023).all()
+    with pytest.raises(bpg._lib.BpgError):
+        bpg.make(env_id, num_envs=4, device=DEV, max_episode_steps=1024)
