@@ -79,6 +79,7 @@ SIGNATURES = {
     'bpg_get_desired_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_assemble_obs_f64': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_assemble_obs_f32': (C.c_int, [C.c_void_p, C.POINTER(PhysState), C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_set_action_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_mat2euler_f64': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_randomize_objects': (C.c_int, [C.c_void_p, C.POINTER(PlacementArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_state_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

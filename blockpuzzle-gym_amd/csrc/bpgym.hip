@@ -843,6 +843,27 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
     }
 }
 
+// robot_env.py:58 clip + BlocksEnv._set_action (fetch_env.py:170-185): the 9-vector
+// [pos_ctrl * 0.05 (float32 product), 1, 0, 1, 0, grip, grip] the reference hands to the
+// physics (gripper targets zeroed when block_gripper), one env per lane.
+__global__ void __launch_bounds__(256)
+k_set_action(const float *__restrict__ action, int64_t n, int block_gripper, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 a4 = reinterpret_cast<const float4 *>(action)[i];
+        float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] = a[k] < -1.0f ? -1.0f : (a[k] > 1.0f ? 1.0f : a[k]);
+        double *o = out + i * 9;
+        o[0] = (double)(a[0] * 0.05f);
+        o[1] = (double)(a[1] * 0.05f);
+        o[2] = (double)(a[2] * 0.05f);
+        o[3] = 1.0; o[4] = 0.0; o[5] = 1.0; o[6] = 0.0;
+        o[7] = o[8] = block_gripper ? 0.0 : (double)a[3];
+    }
+}
+
 // rotations.mat2euler of gym.envs.robotics (call site fetch_env.py:205, :588).  THIRD-PARTY
 // code that is not in the reference tree: restated from SURVEY.md A.4's recollection of gym
 // 0.10 (cy = sqrt(m22^2 + m12^2), branch on cy > 4*eps, negated arctan2 forms) -- parity
@@ -1741,6 +1762,16 @@ int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, 
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream)
 {
     return assemble_obs(b, ph, d_obs, ld, false, stream);
+}
+
+int bpg_set_action_f64(bpg_batch *b, const float *d_actions, double *d_out9, void *stream)
+{
+    if (!b || !d_actions || !d_out9) return fail(BPG_ERR_ARG, "NULL argument");
+    if (!aligned16(d_actions)) return fail(BPG_ERR_ARG, "d_actions must be 16-byte aligned");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_set_action, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, d_actions, b->n,
+                       b->info.block_gripper, d_out9);
+    return check_launch("k_set_action");
 }
 
 int bpg_mat2euler_f64(const double *d_mat, int64_t n, double *d_euler, int device_id, void *stream)

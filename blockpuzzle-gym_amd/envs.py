@@ -431,6 +431,14 @@ class BatchedBlocksEnv:
             onehot[self.info.obj_colors[i + 2]] = 1.0
             self.observation[:, off + BLOCK_BASE_FEATURES:off + BLOCK_FEATURES] = onehot[None, :] * present[:, None]
 
+    def set_action_vector(self, action):
+        """robot_env.py:58 + fetch_env.py:170-185: (B,4) actions -> the (B,9) float64 vector
+        [pos delta, fixed quaternion, finger targets] a physics backend consumes."""
+        a = self._to_dev(action, torch.float32).reshape(self.num_envs, self.dimu)
+        out = torch.empty(self.num_envs, 9, dtype=torch.float64, device=self.device)
+        _lib.check(self._L.bpg_set_action_f64(self._h, _ptr(a), _ptr(out), _stream(self.device)))
+        return out
+
     PHYS_FIELDS = ('grip_pos', 'grip_velp', 'gripper_state', 'gripper_vel',
                    'obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')
 

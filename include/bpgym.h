@@ -187,6 +187,12 @@ typedef struct {
 int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream);
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream);
 
+/* robot_env.py:58 (clip to the action Box) + BlocksEnv._set_action (fetch_env.py:170-185):
+ * d_actions (n,4) float32 -> d_out9 (n,9) float64 = [pos_ctrl*0.05 (float32 product), the fixed
+ * quaternion 1,0,1,0, gripper target twice (zeros when block_gripper)], i.e. the vector the
+ * reference passes to gym's ctrl_set_action / mocap_set_action -- the physics backend's input. */
+int bpg_set_action_f64(bpg_batch *b, const float *d_actions, double *d_out9, void *stream);
+
 /* gym.envs.robotics.rotations.mat2euler (call sites fetch_env.py:205, :588): n row-major 3x3
  * site matrices -> n euler triples for bpg_phys_state.d_obj_rot.  THIRD-PARTY code absent
  * from the reference tree, restated from memory of gym 0.10 -- parity UNPINNED. */

@@ -209,6 +209,22 @@ void orc_get_achieved_goal(const orc_env *e, double *out)
         out[k] = e->achieved_goal[k];
 }
 
+/* robot_env.py:58: np.clip(action, -1, 1) (float32 Box bounds); fetch_env.py:170-185:
+ * pos_ctrl *= 0.05 in place on the float32 array, fixed quaternion, both finger targets =
+ * action[3] (zeros if block_gripper), concatenated into a float64 vector. */
+void orc_set_action(const float *action, int block_gripper, double *out9)
+{
+    float a[4];
+    for (int k = 0; k < 4; k++)
+        a[k] = action[k] < -1.0f ? -1.0f : (action[k] > 1.0f ? 1.0f : action[k]);
+    for (int k = 0; k < 3; k++) {
+        float p = a[k] * 0.05f;              /* float32 array *= python float -> float32 product */
+        out9[k] = (double)p;
+    }
+    out9[3] = 1.; out9[4] = 0.; out9[5] = 1.; out9[6] = 0.;
+    out9[7] = out9[8] = block_gripper ? 0.0 : (double)a[3];
+}
+
 /* fetch_env.py:187-228: obs = [grip_pos, gripper_state, grip_velp*dt, gripper_vel*dt] +
  * per block [pos, pos - grip_pos, euler, velp*dt - grip_velp*dt, velr*dt].
  * Variation :567-621: leading num_blocks, per block + one_hot_color (:34-37), zero

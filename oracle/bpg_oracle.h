@@ -104,6 +104,11 @@ void orc_env_step_mask(orc_env *e, uint32_t mask, float *reward, int *done, int 
 /* achieved_goal as _get_obs returns it (fetch_env.py:220 / :610-613). */
 void orc_get_achieved_goal(const orc_env *e, double *out);
 
+/* robot_env.py:58 clip + fetch_env.py:170-185 _set_action: float32 action (4) -> the float64
+ * 9-vector [pos_ctrl*0.05 (float32 product), 1,0,1,0, grip, grip] handed to the robotics
+ * utils (gripper entries zeroed when block_gripper). */
+void orc_set_action(const float *action, int block_gripper, double *out9);
+
 /* What _get_obs reads from the simulator (all float64, as mujoco_py returns them):
  * site pos / linear velocity of robot0:grip, the last two robot joint positions and
  * velocities, and per block the site pos, euler angles (rotations.mat2euler of the site

@@ -80,6 +80,7 @@ def lib():
                                    P(C.c_float), P(C.c_int), P(C.c_int)]
         L.orc_env_step_mask.argtypes = [P(Env), C.c_uint32, P(C.c_float), P(C.c_int), P(C.c_int)]
         L.orc_get_achieved_goal.argtypes = [P(Env), P(C.c_double)]
+        L.orc_set_action.argtypes = [P(C.c_float), C.c_int, P(C.c_double)]
         L.orc_get_obs.argtypes = [P(Env), P(Phys), C.c_double, P(C.c_double)]
         L.orc_randomize_objects.argtypes = [P(Env), P(Placement), P(C.c_double), P(C.c_int)]
         L.orc_pair_index.argtypes = [C.c_int, C.c_int]
@@ -161,6 +162,13 @@ class OracleEnv:
         r, d, s = C.c_float(), C.c_int(), C.c_int()
         self.L.orc_env_step_mask(C.byref(self.e), int(mask), C.byref(r), C.byref(d), C.byref(s))
         return self.achieved_goal(), np.float32(r.value), bool(d.value), bool(s.value)
+
+
+def set_action(action, block_gripper):
+    a = np.ascontiguousarray(action, np.float32)
+    out = np.zeros(9)
+    lib().orc_set_action(_p(a, C.c_float), int(block_gripper), _p(out, C.c_double))
+    return out
 
 
 def compute_reward(ag, g):

@@ -272,6 +272,7 @@ class TimeLimitStandIn:
 
 
 REGISTRY = []
+CTRL_LOG = []        # every 9-vector _set_action hands to the robotics utils (fetch_env.py:181-185)
 
 
 def install():
@@ -297,7 +298,7 @@ def install():
 
     robotics_utils = _mod(
         'gym.envs.robotics.utils',
-        ctrl_set_action=lambda sim, action: None,
+        ctrl_set_action=lambda sim, action: CTRL_LOG.append(np.array(action, copy=True)),
         mocap_set_action=mocap_set_action,
         reset_mocap_welds=lambda sim: None,
         robot_get_obs=lambda sim: (sim.data.robot[0].copy(), sim.data.robot[1].copy()))

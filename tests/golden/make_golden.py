@@ -204,12 +204,21 @@ def obs_trace(env_id, seed, n_eps=3, n_steps=6):
         rows['obs'].append(obs['observation'])
 
     arng = np.random.RandomState(seed)
+    acts, ctrl = [], []
     for _ in range(n_eps):
         record(env.reset())
         for _ in range(n_steps):
-            o, _, _, _ = env.step(arng.uniform(-1, 1, size=4))
+            a = arng.uniform(-1.6, 1.6, size=4).astype(np.float32)     # beyond the clip range
+            del H.CTRL_LOG[:]
+            o, _, _, _ = env.step(a)
             record(o)
+            acts.append(a)
+            assert len(H.CTRL_LOG) == 1 and H.CTRL_LOG[0].dtype == np.float64
+            ctrl.append(H.CTRL_LOG[0])
     out = {k: np.asarray(v) for k, v in rows.items()}
+    out['actions'] = np.asarray(acts)              # float32 (n, 4) as a policy hands them over
+    out['set_action'] = np.asarray(ctrl)           # float64 (n, 9): _set_action's vector (fetch_env.py:170-185)
+    out['block_gripper'] = np.bool_(u.block_gripper)
     out['dt'] = np.float64(u.sim.nsubsteps * u.sim.model.opt.timestep)
     return out
 

@@ -764,3 +764,12 @@ def test_time_limit_saturation_at_maximum_horizon():
     assert ((env.state_now >> 21) & 1023 == 1023).all()
     with pytest.raises(bpg._lib.BpgError):
         bpg.make(env_id, num_envs=4, device=DEV, max_episode_steps=1024)
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_golden_set_action_vector(env_id):
+    """_set_action's 9-vector (fetch_env.py:170-185 after the robot_env.py:58 clip), bit-exact."""
+    d = np.load(os.path.join(GOLDEN, 'obs_%s.npz' % short(env_id)))
+    env = bpg.make(env_id, num_envs=len(d['actions']), device=DEV)
+    got = env.set_action_vector(d['actions']).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint64), d['set_action'].view(np.uint64))

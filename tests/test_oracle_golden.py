@@ -220,3 +220,14 @@ def test_reset_placement(env_id):
                                      d['eu'][k, :d['n_eu'][k] - 1], d['gz'][k, :d['n_gz'][k]],
                                      d['gu'][k, :d['n_gu'][k]])
     assert fail or d['n_eu'][k] == 0
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_set_action_vector(env_id):
+    """robot_env.py:58 clip + fetch_env.py:170-185: the 9-vector the reference hands to the
+    robotics utils (float32 scaling by 0.05, block_gripper zeroing), bit-exact."""
+    d = np.load(os.path.join(G, 'obs_%s.npz' % short(env_id)))
+    assert bool(d['block_gripper']) == VARIANTS[env_id]['block_gripper']
+    assert (np.abs(d['actions']) > 1).any()
+    for a, exp in zip(d['actions'], d['set_action']):
+        np.testing.assert_array_equal(O.set_action(a, bool(d['block_gripper'])).view(np.uint64), exp.view(np.uint64))
