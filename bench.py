@@ -183,7 +183,7 @@ def main():
                      'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms},
     }
 
-    if rank == 0 and not a.no_extras:
+    if rank == 0 and world == 1 and not a.no_extras:
         out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
