@@ -36,6 +36,9 @@ def parse():
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--buffers', type=int, default=4, help='independent mask/output buffer sets used round-robin')
     p.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    p.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
+                   help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of the '
+                        'per-env final flag bytes [1 B/env]')
     p.add_argument('--single-device', action='store_true',
                    help='rehearsal only: every rank uses cuda:0 (use with --backend gloo on a 1-GPU box)')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
@@ -117,6 +120,8 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     works = []
+    gathered = [torch.empty(world * B, dtype=torch.uint8, device=dev) for _ in range(2)] \
+        if (world > 1 and a.collective == 'allgather') else None
 
     def one_rollout(i, k=None):
         if k is not None:
@@ -124,8 +129,11 @@ def main():
         _lib.check(L.bpg_rollout(env._h, C.byref(args[i]), stream))
         if k is not None:
             ev1[k].record()
-        if world > 1:
-            works.append(dist.all_reduce(rows[i], async_op=True))   # the one collective per rollout
+        if world > 1:                                               # the one collective per rollout
+            if a.collective == 'allreduce':
+                works.append(dist.all_reduce(rows[i], async_op=True))
+            else:   # per-env final (is_success | done<<1 | step_ok<<2) bytes of every shard, global env order
+                works.append(dist.all_gather_into_tensor(gathered[i % 2], flags[i % NBUF][T - 1], async_op=True))
 
     def drain():
         while works:
@@ -152,8 +160,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)) / a.steps
-    last = stats[-1].tolist()
-    succ_rate = last[0] / last[1]            # global: the row was all-reduced when world > 1
+    if world > 1 and a.collective == 'allgather':
+        succ_rate = float((gathered[(n_it - 1) % 2] & 1).float().mean().item())
+    else:
+        last = stats[-1].tolist()
+        succ_rate = last[0] / last[1]        # global: the row was all-reduced when world > 1
 
     # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env packed state 8 B in + 8 B out
@@ -175,7 +186,7 @@ def main():
                                'resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
                                'env-step' % (ENV_ID, B, T),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'parallelism': 'env-shard x%d' % world,
-                   'buffer_sets': NBUF,
+                   'buffer_sets': NBUF, 'collective': (a.collective if world > 1 else None),
                    'success_rate': succ_rate},
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout_vec4<masks>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
