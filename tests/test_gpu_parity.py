@@ -773,3 +773,33 @@ def test_golden_set_action_vector(env_id):
     env = bpg.make(env_id, num_envs=len(d['actions']), device=DEV)
     got = env.set_action_vector(d['actions']).cpu().numpy()
     np.testing.assert_array_equal(got.view(np.uint64), d['set_action'].view(np.uint64))
+
+
+@pytest.mark.parametrize('env_id', ENV_IDS)
+def test_random_contact_lists_vs_oracle(env_id):
+    """Ragged geom-id contact lists (0..12 entries drawn from ALL geoms of the env's model:
+    fingers, table, cubes and None-mapped robot / floor / mocap geoms, duplicates, self
+    pairs) through the contact-list kernel vs the oracle's list form, 2 episodes x 30 steps."""
+    v = VARIANTS[env_id]
+    B, T, maxcon = 300, 30, 12
+    rng = np.random.RandomState(len(env_id))
+    env = bpg.make(env_id, num_envs=B, device=DEV)
+    oenvs = [O.OracleEnv(env_id) for _ in range(B)]
+    for ep in range(2):
+        num_grey = rng.randint(3, size=B).astype(np.int32)
+        obs = env.reset(num_grey=num_grey)
+        model = num_grey if 'Variation' in env_id else np.zeros(B, np.int32)
+        ngeom = np.array([len(v['models'][m]['id2obj']) for m in model])
+        exp0 = np.stack([e.reset(num_grey=int(g)) for e, g in zip(oenvs, num_grey)])
+        np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), exp0.astype(np.float32))
+        for t in range(T):
+            ncon = rng.randint(0, maxcon + 1, size=B).astype(np.int32)
+            pairs = (rng.randint(0, 1 << 30, size=(B, maxcon, 2)) % ngeom[:, None, None]).astype(np.int16)
+            obs, r, done, info = env.step(None, contacts=(pairs, ncon))
+            exp = [e.step(v['models'][int(m)]['id2obj'], pairs[b, :ncon[b]])
+                   for b, (e, m) in enumerate(zip(oenvs, model))]
+            np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(),
+                                          np.stack([x[0] for x in exp]).astype(np.float32))
+            np.testing.assert_array_equal(bits(r), np.array([np.float32(x[1]).view(np.uint32) for x in exp]))
+            np.testing.assert_array_equal(done.cpu().numpy(), np.array([x[2] for x in exp]))
+            np.testing.assert_array_equal(info['is_success'].cpu().numpy(), np.array([x[3] for x in exp]))
