@@ -61,9 +61,23 @@ def cpu_baseline(T, seconds):
     t0 = time.perf_counter()
     L.orc_bench_rollout(variant, envs, T, 0)
     dt = time.perf_counter() - t0
-    return dict(value=envs * T / dt, unit='env-steps/s', cores=1, kind='port',
-                sample='%d envs x %d steps of %s, synthetic contacts, %.1f s on 1 thread '
-                       '(oracle/bpg_oracle.c matrix-form port)' % (envs, T, ENV_ID, dt))
+    out = dict(value=envs * T / dt, unit='env-steps/s', cores=1, kind='port',
+               sample='%d envs x %d steps of %s, synthetic contacts, %.1f s on 1 thread '
+                      '(oracle/bpg_oracle.c matrix-form port)' % (envs, T, ENV_ID, dt))
+    # context: the same port on every host core the process may use (ctypes releases the GIL)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        cores = len(os.sched_getaffinity(0))
+        per = max(8192, envs // 4)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda k: L.orc_bench_rollout(variant, per, T, k), range(cores)))
+        dt = time.perf_counter() - t0
+        out['all_cores'] = dict(value=cores * per * T / dt, unit='env-steps/s', cores=cores,
+                                sample='%d threads x %d envs x %d steps, %.1f s' % (cores, per, T, dt))
+    except Exception as e:  # noqa: BLE001
+        out['all_cores'] = {'error': repr(e)[:200]}
+    return out
 
 
 def main():
