@@ -127,6 +127,9 @@ class ScriptedContacts:
         self.masks, self.pairs, self.ncon = masks, pairs, ncon
         self.t = 0
 
+    def on_reset(self, env):
+        self.t = 0                      # a full reset starts the script over
+
     def next(self, env, actions):
         t = self.t
         self.t += 1
@@ -330,6 +333,8 @@ class BatchedBlocksEnv:
         _lib.check(self._L.bpg_reset(self._h, _ptr(ng), _ptr(em), _stream(self.device)))
         if self.info.is_variation:
             self._fill_static_observation()
+        if env_mask is None and hasattr(self.contact_source, 'on_reset'):
+            self.contact_source.on_reset(self)
         return self._get_obs()
 
     def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None):
@@ -417,19 +422,22 @@ class BatchedBlocksEnv:
 
     def _fill_static_observation(self):
         """The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607):
-        obs[0] = num_blocks, colour one-hot of every present block, zero padding."""
+        obs[0] = num_blocks, colour one-hot of every present block, zero padding.
+        Pure device-tensor ops (capturable into a hipGraph)."""
         if not self.info.is_variation:
             return
-        nobj = (self.state_ever >> 21) & 7
-        nblocks = (nobj - 2).to(torch.float32)
-        self.observation[:, 0] = nblocks
-        for i in range(self.max_num_blocks):
-            off = 1 + ENV_FEATURES + BLOCK_FEATURES * i
-            present = (nobj - 2 > i).to(torch.float32)
-            self.observation[:, off:off + BLOCK_FEATURES] *= present[:, None]
-            onehot = torch.zeros(COLOR_FEATURES, device=self.device)
-            onehot[self.info.obj_colors[i + 2]] = 1.0
-            self.observation[:, off + BLOCK_BASE_FEATURES:off + BLOCK_FEATURES] = onehot[None, :] * present[:, None]
+        if not hasattr(self, '_color_onehot'):
+            oh = torch.zeros(self.max_num_blocks, COLOR_FEATURES)
+            for i in range(self.max_num_blocks):
+                oh[i, self.info.obj_colors[i + 2]] = 1.0
+            self._color_onehot = oh.to(self.device)
+            self._blk_idx = torch.arange(self.max_num_blocks, device=self.device)
+        nblocks = ((self.state_ever >> 21) & 7) - 2
+        self.observation[:, 0] = nblocks.to(torch.float32)
+        blk = self.observation[:, 1 + ENV_FEATURES:].view(self.num_envs, self.max_num_blocks, BLOCK_FEATURES)
+        present = (self._blk_idx[None, :] < nblocks[:, None]).to(torch.float32)
+        blk *= present[:, :, None]
+        blk[:, :, BLOCK_BASE_FEATURES:] = self._color_onehot[None] * present[:, :, None]
 
     def set_action_vector(self, action):
         """robot_env.py:58 + fetch_env.py:170-185: (B,4) actions -> the (B,9) float64 vector

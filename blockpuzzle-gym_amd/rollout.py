@@ -142,7 +142,8 @@ class RolloutStudent:
         success_rate = float(succ_last.mean().item())           # rollout.py:163-167
         self.success_history.append(success_rate)
         if self.compute_Q and len(Qs):
-            self.Q_history.append(np.mean(Qs))
+            self.Q_history.append(float(np.mean([float(np.mean(q.detach().cpu().numpy() if torch.is_tensor(q) else q))
+                                                  for q in Qs])))
         self.n_episodes += self.rollout_batch_size
         if 'is_success' not in self.info_keys:       # only keys named in dims (rollout.py:35,160-161)
             episode = {k: v for k, v in episode.items() if k != 'info_is_success'}
@@ -153,6 +154,10 @@ class RolloutStudent:
     def generate_rollouts(self, render=False, test=False, compute_Attention=False, num_grey=None):
         """rollout.py:75-172 with the policy in the loop: one HIP step launch
         for the whole batch per time step.  Returns the batch-major episode."""
+        ep, Qs = self._rollout_body(test, num_grey, compute_Attention)
+        return self._finish(ep, Qs)
+
+    def _rollout_body(self, test, num_grey, compute_Attention=False):
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
         # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
@@ -172,7 +177,7 @@ class RolloutStudent:
                 use_target_net=self.use_target_net)
             if self.compute_Q:
                 u, Q = policy_output[0], policy_output[1]
-                Qs.append(float(np.mean(Q.cpu().numpy() if torch.is_tensor(Q) else Q)))
+                Qs.append(Q)
             else:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
@@ -185,7 +190,37 @@ class RolloutStudent:
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
         # the goal is constant over the episode (rollout.py:151 appends the same array T times)
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
-        return self._finish(ep, Qs)
+        return ep, Qs
+
+    def generate_rollouts_graphed(self, test=False, num_grey=None):
+        """generate_rollouts for DEVICE-RESIDENT policies with the whole T-step loop (reset,
+        policy, step kernels, episode writes) captured once into a hipGraph and replayed: below
+        ~64 K envs the per-step path is bound by host launches (~50 us per step), a replay is
+        one launch.  Requirements: `policy.device_tensors`, a capturable policy / contact
+        source (no host syncs, no host->device copies inside), output='torch'.  The returned
+        tensors are the graph's static buffers: they are overwritten by the next replay.
+        Launch arguments are baked at capture: pass Variation's per-episode draws through
+        `num_grey` (copied into a static tensor before each replay) to vary them."""
+        assert self.output == 'torch' and getattr(self.policy, 'device_tensors', False)
+        B = self.rollout_batch_size
+        if getattr(self, '_graph', None) is None or self._graph_test != bool(test):
+            self._static_ng = torch.zeros(B, dtype=torch.int32, device=self.device)
+            if num_grey is not None:
+                self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                      # warm-up outside the capture
+                self._rollout_body(test, self._static_ng)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_ep, self._graph_Qs = self._rollout_body(test, self._static_ng)
+            self._graph, self._graph_test = graph, bool(test)
+        if num_grey is not None:
+            self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
+        self._graph.replay()
+        return self._finish(dict(self._graph_ep), self._graph_Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
                                 want_reward=False, materialize_constants=False):

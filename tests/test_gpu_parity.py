@@ -803,3 +803,35 @@ def test_random_contact_lists_vs_oracle(env_id):
             np.testing.assert_array_equal(bits(r), np.array([np.float32(x[1]).view(np.uint32) for x in exp]))
             np.testing.assert_array_equal(done.cpu().numpy(), np.array([x[2] for x in exp]))
             np.testing.assert_array_equal(info['is_success'].cpu().numpy(), np.array([x[3] for x in exp]))
+
+
+def test_graphed_rollout_equals_eager():
+    """The per-step rollout loop captured into a hipGraph and replayed == the eager loop,
+    replay after replay (Variation: fresh explicit num_grey per replay)."""
+    env_id, B, T = 'BlocksTouchVariation-v0', 2048, 50
+    rng = np.random.RandomState(4)
+    masks = i32(legal_masks(rng, T, B, 4, density=3))       # pairs among the 4 always-present objects
+
+    class Policy:
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            return torch.tanh(ag[:, :4] * 0.5 + o[:, :4])     # depends on the evolving state
+
+    def worker():
+        src = bpg.ScriptedContacts(masks=masks)
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, contact_source=src),
+                               Policy(), dims_of(env_id), None, T, rollout_batch_size=B)
+        return w, src
+    wg, _ = worker()
+    we, src_e = worker()
+    for r in range(3):
+        ng = rng.randint(3, size=B).astype(np.int32)
+        epg = wg.generate_rollouts_graphed(num_grey=ng)
+        src_e.t = 0
+        epe = we.generate_rollouts(num_grey=ng)
+        for k in epe:
+            assert torch.equal(epg[k], epe[k]), k
+        assert wg.success_history[-1] == we.success_history[-1]
+        assert torch.equal(wg.env.state_ever, we.env.state_ever)
+    assert (epg['o'][:, 0, 0] == torch.as_tensor(ng + 2, device=DEV).float()).all()   # Variation obs[0] = num_blocks

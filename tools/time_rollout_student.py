@@ -21,6 +21,7 @@ env = bpg.make(env_id, num_envs=B, device='cuda:0')
 dims = dict(o=env.dimo, u=4, g=env.dimg, info_is_success=1)
 w = bpg.RolloutStudent(lambda num_envs: env, RandomPolicy(), dims, None, T, rollout_batch_size=B)
 for name, fn in (('generate_rollouts (per-step launches, policy in loop)', w.generate_rollouts),
+                 ('generate_rollouts_graphed (same loop, hipGraph replay)', w.generate_rollouts_graphed),
                  ('generate_rollouts_fused (one launch)', w.generate_rollouts_fused)):
     fn()
     torch.cuda.synchronize()
