@@ -5,8 +5,9 @@ path at 1 048 576 envs per GPU (BASELINE.json metric), one JSON line on rank 0.
 A bench "step" = one rollout pass over the batch in ONE kernel launch: reset of
 all envs, T=50 fused env steps (contacts read as packed masks resident in HBM --
 the contacts-in boundary -- rewards + success/done flags written per env-step)
-and the success-count reduction; with N>1 GPUs one RCCL all-reduce of
-(successes, envs) per rollout.  Weak scaling: every GPU holds `--envs` envs.
+and the success-count reduction; with N>1 GPUs the (successes, envs) rows are
+all-reduced over RCCL in slabs of `--reduce-every` rollouts (default 8), asynchronously.
+Weak scaling: every GPU holds `--envs` envs.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -39,8 +40,13 @@ def parse():
     p.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
                    help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of the '
                         'per-env final flag bytes [1 B/env]')
+    p.add_argument('--reduce-every', type=int, default=8,
+                   help='N>1: rollouts per collective (the statistics rows of R rollouts travel in one all-reduce; the '
+                        'reference averages across ranks once per epoch, train.py:21-26,67-76)')
     p.add_argument('--single-device', action='store_true',
                    help='rehearsal only: every rank uses cuda:0 (use with --backend gloo on a 1-GPU box)')
+    p.add_argument('--default-stream', action='store_true',
+                   help='launch on the legacy default stream instead of a dedicated non-blocking stream')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -90,8 +96,15 @@ def main():
     if a.single_device:
         os.environ['LOCAL_RANK'] = '0'
     rank, world, local = D.init_from_env(backend=a.backend)
+    force_dist = os.environ.get('BPG_BENCH_FORCE_DIST') == '1'     # rehearsal: RCCL path on one rank
+    if force_dist and world == 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        torch.cuda.set_device(local)
+        dist.init_process_group(a.backend or 'nccl', rank=0, world_size=1, device_id=torch.device('cuda', local))
     assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    multi = world > 1 or force_dist          # take the collective code path
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     L = _lib.lib()
@@ -99,6 +112,9 @@ def main():
     total = B * world
     env = D.make_sharded(ENV_ID, total, rank, world, device=dev, seed=a.seed)
     assert env.num_envs == B
+    if not a.default_stream:
+        # a dedicated stream: the legacy default stream serialises against the RCCL stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     # inputs resident in HBM before the timed region: (T, B) contact masks from the
@@ -134,8 +150,10 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     works = []
+    pending = [0]                  # first statistics row that has not been all-reduced yet
+    R = max(1, a.reduce_every)
     gathered = [torch.empty(world * B, dtype=torch.uint8, device=dev) for _ in range(2)] \
-        if (world > 1 and a.collective == 'allgather') else None
+        if (multi and a.collective == 'allgather') else None
 
     def one_rollout(i, k=None):
         if k is not None:
@@ -143,11 +161,14 @@ def main():
         _lib.check(L.bpg_rollout(env._h, C.byref(args[i]), stream))
         if k is not None:
             ev1[k].record()
-        if world > 1:                                               # the one collective per rollout
+        if multi and ((i + 1) % R == 0 or i == n_it - 1 or i == a.warmup - 1):
+            # one collective per R rollouts: the [successes, envs] rows not yet reduced
+            lo, pending[0] = pending[0], i + 1
             if a.collective == 'allreduce':
-                works.append(dist.all_reduce(rows[i], async_op=True))
+                works.append(dist.all_reduce(stats[lo:i + 1], async_op=True))
             else:   # per-env final (is_success | done<<1 | step_ok<<2) bytes of every shard, global env order
-                works.append(dist.all_gather_into_tensor(gathered[i % 2], flags[i % NBUF][T - 1], async_op=True))
+                works.append(dist.all_gather_into_tensor(gathered[(i // R) % 2], flags[i % NBUF][T - 1],
+                                                         async_op=True))
 
     def drain():
         while works:
@@ -155,7 +176,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -166,16 +187,17 @@ def main():
     t0 = time.perf_counter()
     for k in range(a.steps):
         one_rollout(a.warmup + k, k)
+    host_dt = time.perf_counter() - t0          # time to ENQUEUE the K steps (host side only)
     drain()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)) / a.steps
-    if world > 1 and a.collective == 'allgather':
-        succ_rate = float((gathered[(n_it - 1) % 2] & 1).float().mean().item())
+    if multi and a.collective == 'allgather':
+        succ_rate = float((gathered[((n_it - 1) // R) % 2] & 1).float().mean().item())
     else:
         last = stats[-1].tolist()
         succ_rate = last[0] / last[1]        # global: the row was all-reduced when world > 1
@@ -194,6 +216,7 @@ def main():
     out = {
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+        'host_enqueue_ms_per_step': host_dt / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
         'data': 'synthetic',
         'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
@@ -201,6 +224,7 @@ def main():
                                'env-step' % (ENV_ID, B, T),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'parallelism': 'env-shard x%d' % world,
                    'buffer_sets': NBUF, 'collective': (a.collective if world > 1 else None),
+                   'rollouts_per_collective': (R if world > 1 else None),
                    'success_rate': succ_rate},
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout_vec4<masks>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -212,11 +236,11 @@ def main():
         out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
