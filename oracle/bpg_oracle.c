@@ -522,3 +522,29 @@ uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed)
     }
     return sum;
 }
+
+void orc_fill_masks(uint32_t seed, uint32_t env_base, int B, int T, int num_objs, uint32_t *masks)
+{
+    for (int t = 0; t < T; t++)
+        for (int b = 0; b < B; b++)
+            masks[(size_t)t * B + b] = orc_synth_mask(seed, env_base + (uint32_t)b, (uint32_t)t, num_objs);
+}
+
+uint64_t orc_bench_rollout_masks(int variant, int B, int T, int num_grey, const uint32_t *masks,
+                                 float *reward_tb, uint8_t *flags_tb)
+{
+    uint64_t sum = 0;
+    orc_env e;
+    for (int b = 0; b < B; b++) {
+        orc_env_init(&e, variant, T);
+        orc_env_reset(&e, num_grey);
+        for (int t = 0; t < T; t++) {
+            float r; int done, succ;
+            orc_env_step_mask(&e, masks[(size_t)t * B + b], &r, &done, &succ);
+            reward_tb[(size_t)t * B + b] = r;
+            flags_tb[(size_t)t * B + b] = (uint8_t)(succ | (done << 1) | ((r == 0) << 2));
+        }
+        sum += (uint64_t)e.has_succeeded;
+    }
+    return sum;
+}

@@ -171,6 +171,12 @@ double orc_generate_rollouts(orc_env *envs, int B, int T, const uint32_t *masks,
 /* cpu_baseline leg: B envs x T steps of the matrix-form step on synthetic
  * masks, no episode buffers.  Returns a checksum so the work is not elided. */
 uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed);
+/* Same workload as the GPU headline: the (T, B) masks are generated beforehand
+ * (orc_fill_masks, untimed) and READ from memory by the timed loop, which also
+ * writes the per-step reward (float32) and flags byte like the kernel does. */
+void orc_fill_masks(uint32_t seed, uint32_t env_base, int B, int T, int num_objs, uint32_t *masks);
+uint64_t orc_bench_rollout_masks(int variant, int B, int T, int num_grey, const uint32_t *masks,
+                                 float *reward_tb, uint8_t *flags_tb);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,10 @@ def lib():
         L.orc_generate_rollouts.restype = C.c_double
         L.orc_bench_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.orc_bench_rollout.restype = C.c_uint64
+        L.orc_fill_masks.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, P(C.c_uint32)]
+        L.orc_bench_rollout_masks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint32), P(C.c_float),
+                                              P(C.c_uint8)]
+        L.orc_bench_rollout_masks.restype = C.c_uint64
         _lib = L
     return _lib
 
