@@ -84,8 +84,8 @@ def cpu_baseline(T, seconds):
     # context: the same port on every host core the process may use (ctypes releases the GIL)
     try:
         from concurrent.futures import ThreadPoolExecutor
-        cores = len(os.sched_getaffinity(0))
-        per = max(8192, envs // 4)
+        cores = min(len(os.sched_getaffinity(0)), 16)      # the GPU box's CPU share per GPU
+        per = max(8192, int(envs * 3.0 / max(dt, 1e-6)))   # ~3 s of work per thread
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
             times = list(ex.map(lambda k: run(per, k), range(cores)))
