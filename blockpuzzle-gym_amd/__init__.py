@@ -8,12 +8,12 @@ onto this hyphenated directory).  Public surface mirrors the reference:
   PGRolloutStudent                gym_blocks/policy_gradient/rollout.py (return G)
 """
 from . import _lib
-from .registration import make, register, registry
+from .registration import make, register, registry, register_with_gym
 from .envs import (BatchedBlocksEnv, SyntheticContacts, ScriptedContacts, CallableContacts,
                    compute_reward, mat2euler, geom2objid, default_geom_names)
 from .rollout import RolloutStudent, PGRolloutStudent, configure_dims, discounted_return
 from . import distributed
 
-__all__ = ['make', 'register', 'registry', 'BatchedBlocksEnv', 'RolloutStudent', 'PGRolloutStudent',
+__all__ = ['make', 'register', 'registry', 'register_with_gym', 'BatchedBlocksEnv', 'RolloutStudent', 'PGRolloutStudent',
            'SyntheticContacts', 'ScriptedContacts', 'CallableContacts', 'compute_reward',
            'configure_dims', 'discounted_return', 'mat2euler', 'geom2objid', 'default_geom_names', 'distributed']

@@ -51,3 +51,31 @@ def make(env_id, num_envs=None, **kwargs):
     if num_envs is None:
         return BatchedBlocksEnv(env_id, num_envs=1, scalar_api=True, **kw)
     return BatchedBlocksEnv(env_id, num_envs=num_envs, **kw)
+
+
+def _gym_entry(env_id):
+    def entry(**kwargs):
+        from .envs import BatchedBlocksEnv
+        kwargs.pop('reward_type', None)
+        # gym.make wraps the env in its own TimeLimit (max_episode_steps below), which then
+        # agrees with the env's built-in step counter
+        return BatchedBlocksEnv(env_id, num_envs=1, scalar_api=True, **kwargs)
+    return entry
+
+
+def register_with_gym(prefix=''):
+    """Optional: if the real `gym` package is installed, register the seven ids with it
+    (same names, max_episode_steps=50, kwargs={'reward_type': 'sparse'} as
+    gym_blocks/__init__.py:6-53), so `gym.make('BlocksTouch-v0')` returns the drop-in single
+    env.  gym is not a dependency and is absent from the build image, so this path is
+    untested there; returns the list of ids registered (empty if gym is missing)."""
+    try:
+        from gym.envs.registration import register as gym_register
+    except Exception:  # noqa: BLE001
+        return []
+    done = []
+    for spec in registry.values():
+        gym_register(id=prefix + spec.id, entry_point=_gym_entry(spec.id), kwargs=dict(spec.kwargs),
+                     max_episode_steps=spec.max_episode_steps)
+        done.append(prefix + spec.id)
+    return done
