@@ -835,3 +835,35 @@ def test_graphed_rollout_equals_eager():
         assert wg.success_history[-1] == we.success_history[-1]
         assert torch.equal(wg.env.state_ever, we.env.state_ever)
     assert (epg['o'][:, 0, 0] == torch.as_tensor(ng + 2, device=DEV).float()).all()   # Variation obs[0] = num_blocks
+
+
+class _ZeroPolicy:                       # module level so save_policy can pickle it
+    def get_actions(self, o, ag, g, **kw):
+        return np.zeros((o.shape[0], 4), np.float32)
+
+
+def test_rollout_worker_small_surface(tmp_path):
+    """reset_rollout(i) (rollout.py:47-58), logs() prefixes (:186-204), save_policy (:180-184),
+    clear_history, the reference default rollout_batch_size=2 through a single-env factory."""
+    import pickle
+    P = _ZeroPolicy
+
+    env_id = 'BlocksTouch-v0'
+    w = bpg.RolloutStudent(lambda: bpg.make(env_id, device=DEV), P(), dims_of(env_id), None, 50,
+                           rollout_batch_size=2, compute_Q=False)
+    assert w.env.num_envs == 2 and not w.env.scalar_api
+    pair = 1 << bpg._lib.lib().bpg_pair_index(2, 3)
+    w.env.step(None, contact_masks=np.array([pair, 0], np.int32))
+    assert w.env.state_ever.cpu().numpy()[0] < 0                   # env 0 latched success
+    w.reset_rollout(0)
+    assert (w.env.state_ever.cpu().numpy() >= 0).all()
+    assert w.initial_ag[0, 2 * 4 + 3].item() == 1.0                # matrix persists over the reset (Q1)
+    ep = w.generate_rollouts()
+    assert ep['o'].shape == (2, 51, 40) and ep['info_is_success'].shape == (2, 50, 1)
+    assert w.logs('worker')[0][0] == 'worker/success_rate' and w.logs('')[-1] == ('episode', 2)
+    assert w.logs('a/')[0][0] == 'success_rate'      # reference quirk: a trailing '/' drops the prefix (rollout.py:201-204)
+    path = tmp_path / 'policy.pkl'
+    w.save_policy(str(path))
+    assert isinstance(pickle.load(open(path, 'rb')), P)
+    w.clear_history()
+    assert len(w.success_history) == 0
