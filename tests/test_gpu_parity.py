@@ -867,3 +867,41 @@ def test_rollout_worker_small_surface(tmp_path):
     assert isinstance(pickle.load(open(path, 'rb')), P)
     w.clear_history()
     assert len(w.success_history) == 0
+
+
+def test_callable_contact_source_with_observation():
+    """The physics hook of INTEGRATION.md: a CallableContacts backend that returns geom-id
+    contact lists (or masks) and fills env.observation through assemble_observation; the
+    rollout worker records those observations and the resulting touch matrices."""
+    env_id, B, T = 'BlocksTouchChoose-v0', 64, 6
+    d = np.load(os.path.join(GOLDEN, 'obs_%s.npz' % short(env_id)))
+    phys = {k: np.repeat(d[k][:1], B, 0) for k in bpg.BatchedBlocksEnv.PHYS_FIELDS}
+    finger, cube0, cube1 = 17, 23, 24
+    calls = []
+
+    def physics(env, actions):
+        assert actions.shape == (B, 4) and float(actions.abs().max()) <= 1.0     # clipped (robot_env.py:58)
+        calls.append(env.set_action_vector(actions))
+        env.assemble_observation(phys, dt=float(d['dt']))
+        if len(calls) % 2:
+            pairs = torch.tensor([[cube0, cube1], [finger, cube0]], dtype=torch.int16, device=DEV).expand(B, 2, 2)
+            return pairs.contiguous(), torch.full((B,), 2, dtype=torch.int32, device=DEV)
+        return torch.zeros(B, dtype=torch.int32, device=DEV)                     # masks form: nothing touches
+
+    class Pol:
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            return torch.full((B, 4), 3.0, device=DEV)                           # beyond the clip range
+
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV,
+                                                     contact_source=bpg.CallableContacts(physics)),
+                           Pol(), dims_of(env_id), None, T, rollout_batch_size=B)
+    ep = w.generate_rollouts()
+    assert len(calls) == T and torch.equal(calls[0][:, :3], torch.full((B, 3), float(np.float32(0.05)), device=DEV).double())
+    exp_obs = torch.as_tensor(d['obs'][0].astype(np.float32), device=DEV)
+    assert torch.equal(ep['o'][:, 1], exp_obs.expand(B, -1)) and torch.equal(ep['o'][:, T], exp_obs.expand(B, -1))
+    ag = ep['ag'].reshape(B, T + 1, 5, 5)
+    assert (ag[:, 1, 2, 3] == 1).all() and (ag[:, 1, 0, 2] == 1).all()          # step 1: cubes touch, finger on cube0
+    assert (ag[:, 2, 2, 3] == 0).all() and (ag[:, 2, 1, 1] == -1).all()         # step 2: touched before / never
+    assert (ep['info_is_success'] == 1).all()                                    # (2,3) is the goal pair
