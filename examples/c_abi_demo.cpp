@@ -1,0 +1,81 @@
+// Plain C++ host driving the C-ABI (include/bpgym.h) with nothing but the HIP runtime:
+// what a non-Python binding (cgo / JNI / N-API ...) of the env boundary would do.
+//   hipcc -O2 -std=c++17 -Iinclude -o /tmp/c_abi_demo examples/c_abi_demo.cpp \
+//         -Lblockpuzzle-gym_amd/lib -lbpgym -Wl,-rpath,$PWD/blockpuzzle-gym_amd/lib && /tmp/c_abi_demo
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "bpgym.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_ != BPG_OK) { std::printf("%s failed: %d %s\n", #x, rc_, bpg_last_error()); return 1; } } while (0)
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main()
+{
+    const int64_t B = 1000;
+    const int variant = bpg_variant_from_id("BlocksTouch-v0");
+    bpg_variant_info info;
+    CHECK(bpg_get_variant_info(variant, &info));
+    std::printf("%s: num_objs %d dimg %d dimo %d\n", info.env_id, info.num_objs, info.dimg, info.dimo);
+
+    bpg_batch *h = nullptr;
+    CHECK(bpg_create(&h, variant, B, 0, info.max_episode_steps, 1234, 0));
+
+    // id2obj as fetch_env.py:284 builds it, from the scene's geom names
+    const char *geoms[] = {"floor0", nullptr, "robot0:base_link", "robot0:r_gripper_finger_link",
+                           "robot0:l_gripper_finger_link", "table", "object0", "object1"};
+    int8_t id2obj[8];
+    for (int i = 0; i < 8; i++) id2obj[i] = (int8_t)bpg_geom2objid(geoms[i]);
+    CHECK(bpg_set_id2obj(h, 0, id2obj, 8));
+
+    // every env: object0-object1 touch, finger touches object0, floor contact ignored
+    const int maxcon = 4;
+    std::vector<int16_t> con((size_t)B * maxcon * 2, 0);
+    std::vector<int32_t> ncon((size_t)B, 3);
+    for (int64_t b = 0; b < B; b++) {
+        int16_t *c = &con[(size_t)b * maxcon * 2];
+        c[0] = 6; c[1] = 7;       // object0, object1   -> the goal pair (2,3)
+        c[2] = 3; c[3] = 6;       // finger, object0
+        c[4] = 0; c[5] = 7;       // floor (None), object1 -> ignored
+    }
+    int16_t *d_con; int32_t *d_ncon; float *d_reward, *d_ag; uint8_t *d_flags;
+    HIP(hipMalloc(&d_con, con.size() * 2)); HIP(hipMalloc(&d_ncon, ncon.size() * 4));
+    HIP(hipMalloc(&d_reward, B * 4)); HIP(hipMalloc(&d_flags, B)); HIP(hipMalloc(&d_ag, B * info.dimg * 4));
+    HIP(hipMemcpy(d_con, con.data(), con.size() * 2, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_ncon, ncon.data(), ncon.size() * 4, hipMemcpyHostToDevice));
+
+    CHECK(bpg_reset(h, nullptr, nullptr, nullptr));
+    CHECK(bpg_step_contacts(h, d_con, d_ncon, maxcon, d_reward, d_flags, nullptr));
+    CHECK(bpg_get_achieved_goal_f32(h, d_ag, info.dimg, nullptr));
+    HIP(hipDeviceSynchronize());
+
+    std::vector<float> reward((size_t)B), ag((size_t)B * info.dimg);
+    std::vector<uint8_t> flags((size_t)B);
+    HIP(hipMemcpy(reward.data(), d_reward, B * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(flags.data(), d_flags, B, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(ag.data(), d_ag, B * info.dimg * 4, hipMemcpyDeviceToHost));
+    uint32_t rbits; std::memcpy(&rbits, &reward[B - 1], 4);
+    std::printf("env %lld: reward bits 0x%08X (-0.0f on success), flags 0x%02X\n", (long long)(B - 1), rbits, flags[B - 1]);
+    const float *m = &ag[(size_t)(B - 1) * info.dimg];
+    for (int i = 0; i < info.side; i++) {
+        for (int j = 0; j < info.side; j++) std::printf("%5.1f", m[i * info.side + j]);
+        std::printf("\n");
+    }
+    int bad = 0;
+    for (int64_t b = 0; b < B; b++) {
+        std::memcpy(&rbits, &reward[b], 4);
+        const float *a = &ag[(size_t)b * info.dimg];
+        bad += rbits != 0x80000000u || flags[b] != (BPG_FLAG_SUCCESS | BPG_FLAG_STEP_OK);
+        bad += a[2 * 4 + 3] != 1.f || a[3 * 4 + 2] != 1.f || a[0 * 4 + 2] != 1.f || a[1 * 4 + 3] != -1.f;
+    }
+    unsigned long long *d_cnt, cnt = 0;
+    HIP(hipMalloc(&d_cnt, 8)); HIP(hipMemset(d_cnt, 0, 8));
+    CHECK(bpg_success_count(h, d_cnt, nullptr));
+    HIP(hipMemcpy(&cnt, d_cnt, 8, hipMemcpyDeviceToHost));
+    std::printf("success count %llu of %lld, mismatches %d\n", cnt, (long long)B, bad);
+    CHECK(bpg_destroy(h));
+    return (bad == 0 && cnt == (unsigned long long)B) ? 0 : 2;
+}

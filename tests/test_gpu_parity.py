@@ -905,3 +905,20 @@ def test_callable_contact_source_with_observation():
     assert (ag[:, 1, 2, 3] == 1).all() and (ag[:, 1, 0, 2] == 1).all()          # step 1: cubes touch, finger on cube0
     assert (ag[:, 2, 2, 3] == 0).all() and (ag[:, 2, 1, 1] == -1).all()         # step 2: touched before / never
     assert (ep['info_is_success'] == 1).all()                                    # (2,3) is the goal pair
+
+
+def test_c_abi_from_plain_cpp_host(tmp_path):
+    """examples/c_abi_demo.cpp: a C++ host with only the HIP runtime (no Python, no torch)
+    drives libbpgym.so through include/bpgym.h -- build it with hipcc and run it."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    libdir = os.path.join(root, 'blockpuzzle-gym_amd', 'lib')
+    exe = str(tmp_path / 'c_abi_demo')
+    subprocess.check_call([hipcc, '-O2', '-std=c++17', '-I' + os.path.join(root, 'include'), '-o', exe,
+                           os.path.join(root, 'examples', 'c_abi_demo.cpp'), '-L' + libdir, '-lbpgym',
+                           '-Wl,-rpath,' + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'reward bits 0x80000000' in out.stdout and 'success count 1000 of 1000, mismatches 0' in out.stdout
