@@ -83,6 +83,7 @@ SIGNATURES = {
     'bpg_mat2euler_f64': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_randomize_objects': (C.c_int, [C.c_void_p, C.POINTER(PlacementArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_state_ptrs': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'bpg_counter_ptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'bpg_compute_reward_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_int, C.c_void_p]),
     'bpg_compute_reward_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

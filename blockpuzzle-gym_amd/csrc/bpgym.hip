@@ -147,7 +147,9 @@ struct bpg_batch {
     int max_steps;
     uint64_t seed;
     int64_t env_base;
-    uint64_t reset_counter;
+    uint32_t *d_reset_counter;   // two device words: [0] generator-drawn resets so far, [1] generator-drawn
+                                 // placements so far (stream indices); on the device so that hipGraph
+                                 // replays advance them too
     uint32_t *now;
     uint32_t *ever;
     int8_t *d_id2obj;   // [BPG_MAX_MODELS][BPG_MAX_GEOMS]
@@ -282,7 +284,8 @@ struct ResetConst {
     int32_t enabled;        // apply the reset before step 0 (fused rollouts)
     int32_t is_variation;
     uint32_t base_nobj;
-    uint32_t seed, env_base, reset_counter;
+    uint32_t seed, env_base;
+    const uint32_t *reset_counter;   // device word, read (uniformly) by every lane
     const int32_t *num_grey;   // explicit variates for np_random.randint(3) (:647) or NULL
 };
 
@@ -295,7 +298,7 @@ __device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_
             g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
         } else {
             // counter-based stand-in for np_random.randint(3)
-            g = hash32(synth_key(rc.seed ^ 0xA511E9B3U, rc.env_base + (uint32_t)i) + rc.reset_counter) % 3u;
+            g = hash32(synth_key(rc.seed ^ 0xA511E9B3U, rc.env_base + (uint32_t)i) + *rc.reset_counter) % 3u;
         }
         now = 0u;
         ever = (4u + g) << NOBJ_SHIFT;
@@ -318,6 +321,10 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
         ever[i] = e;
     }
 }
+
+// Enqueued right after every launch that reset the batch: stream order makes all lanes of the
+// reset see the old value and the next reset the new one, also under hipGraph replay.
+__global__ void k_bump_counter(uint32_t *counter) { *counter += 1u; }
 
 __global__ void __launch_bounds__(256)
 k_init(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, uint32_t nobj)
@@ -893,7 +900,8 @@ struct PlaceConst {
     double grip_x, grip_y, obj_range, max_obj_range, wrong_obj_range;
     const double *eu, *gz, *gu;
     int32_t n_eu, n_gz, n_gu;
-    uint32_t seed, env_base, reset_counter;
+    uint32_t seed, env_base;
+    const uint32_t *reset_counter;
 };
 
 struct Draws {
@@ -981,7 +989,7 @@ k_randomize_objects(const uint32_t *__restrict__ ever, int64_t n, PlaceConst pc,
         d.n_eu = pc.n_eu; d.n_gz = pc.n_gz; d.n_gu = pc.n_gu;
         d.ie = d.iz = d.iu = d.fail = 0;
         d.has_spare = false; d.z_spare = 0.0;
-        d.key = hash32(synth_key(pc.seed ^ 0x51ED270BU, pc.env_base + (uint32_t)i) + pc.reset_counter);
+        d.key = hash32(synth_key(pc.seed ^ 0x51ED270BU, pc.env_base + (uint32_t)i) + *pc.reset_counter);
         double *o = xy + i * pc.nb_max * 2;
         const double gx = pc.grip_x, gy = pc.grip_y;
         double x, y;
@@ -1363,7 +1371,7 @@ ResetConst reset_const(const bpg_batch *b, int enabled, const int32_t *d_num_gre
     rc.base_nobj = (uint32_t)b->info.num_objs;
     rc.seed = s.seed;
     rc.env_base = s.env_base;
-    rc.reset_counter = (uint32_t)b->reset_counter;
+    rc.reset_counter = b->d_reset_counter;
     rc.num_grey = d_num_grey;
     return rc;
 }
@@ -1482,18 +1490,20 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     b->info.max_episode_steps = max_episode_steps;
     b->seed = seed;
     b->env_base = env_id_base;
-    b->reset_counter = 0;
+    b->d_reset_counter = nullptr;
     b->now = b->ever = nullptr;
     b->d_id2obj = nullptr;
     std::memset(b->ngeom, 0, sizeof(b->ngeom));
     const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
     hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
     hipError_t e3 = hipMalloc(&b->d_id2obj, BPG_MAX_MODELS * BPG_MAX_GEOMS);
+    if (e3 == hipSuccess) e3 = hipMalloc(&b->d_reset_counter, 2 * sizeof(uint32_t));
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         bpg_destroy(b);
         return fail(BPG_ERR_HIP, "hipMalloc failed for the packed state");
     }
     hipError_t e4 = hipMemset(b->d_id2obj, 0xFF, BPG_MAX_MODELS * BPG_MAX_GEOMS);
+    if (e4 == hipSuccess) e4 = hipMemset(b->d_reset_counter, 0, 2 * sizeof(uint32_t));
     hipLaunchKernelGGL(k_init, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, b->now, b->ever, n_envs,
                        (uint32_t)b->info.num_objs);
     hipError_t e5 = hipDeviceSynchronize();
@@ -1512,6 +1522,7 @@ int bpg_destroy(bpg_batch *b)
     if (b->now) (void)hipFree(b->now);
     if (b->ever) (void)hipFree(b->ever);
     if (b->d_id2obj) (void)hipFree(b->d_id2obj);
+    if (b->d_reset_counter) (void)hipFree(b->d_reset_counter);
     delete b;
     return BPG_OK;
 }
@@ -1522,7 +1533,8 @@ int bpg_seed(bpg_batch *b, uint64_t seed)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
     b->seed = seed;
-    b->reset_counter = 0;
+    DeviceGuard guard(b->device);
+    HIP_TRY(hipMemset(b->d_reset_counter, 0, 2 * sizeof(uint32_t)));   // synchronous: seeding restarts the streams
     return BPG_OK;
 }
 
@@ -1549,7 +1561,8 @@ int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask
     DeviceGuard guard(b->device);
     hipLaunchKernelGGL(k_reset, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now, b->ever,
                        b->n, reset_const(b, 1, d_num_grey), d_env_mask);
-    b->reset_counter++;
+    if (b->info.is_variation && !d_num_grey)     // only generator-drawn resets consume a stream index
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter);
     return check_launch("k_reset");
 }
 
@@ -1806,9 +1819,11 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
     pc.eu = explicit_draws ? a->d_eu : nullptr;
     pc.gz = a->d_gz; pc.gu = a->d_gu;
     pc.n_eu = a->n_eu; pc.n_gz = a->n_gz; pc.n_gu = a->n_gu;
-    pc.seed = s.seed; pc.env_base = s.env_base; pc.reset_counter = (uint32_t)b->reset_counter;
+    pc.seed = s.seed; pc.env_base = s.env_base; pc.reset_counter = b->d_reset_counter + 1;
     hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        b->n, pc, d_xy, d_status);
+    if (!explicit_draws)
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter + 1);
     return check_launch("k_randomize_objects");
 }
 
@@ -1817,6 +1832,13 @@ int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever)
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
     if (d_now) *d_now = b->now;
     if (d_ever) *d_ever = b->ever;
+    return BPG_OK;
+}
+
+int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters)
+{
+    if (!b || !d_counters) return fail(BPG_ERR_ARG, "NULL argument");
+    *d_counters = b->d_reset_counter;
     return BPG_OK;
 }
 
@@ -1925,7 +1947,10 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         });
         if (rcode == BPG_OK) rcode = check_launch("k_episode");
     }
-    if (rcode == BPG_OK && a->reset_first) b->reset_counter++;
+    if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey) {
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, st, b->d_reset_counter);
+        rcode = check_launch("k_bump_counter");
+    }
     return rcode;
 }
 

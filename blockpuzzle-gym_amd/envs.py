@@ -206,6 +206,9 @@ class BatchedBlocksEnv:
         _lib.check(L.bpg_state_ptrs(self._h, C.byref(now), C.byref(ever)))
         self.state_now = torch.as_tensor(_DevicePtr(now.value, B, '<i4'), device=dev)
         self.state_ever = torch.as_tensor(_DevicePtr(ever.value, B, '<i4'), device=dev)
+        cnt = C.c_void_p()
+        _lib.check(L.bpg_counter_ptr(self._h, C.byref(cnt)))
+        self.state_counters = torch.as_tensor(_DevicePtr(cnt.value, 2, '<i4'), device=dev)
         self.set_geom_names(default_geom_names(env_id))
         # robot_env.py:38-44
         self.action_space = Box(-1., 1., shape=(self.dimu,), dtype='float32')
@@ -518,11 +521,14 @@ class BatchedBlocksEnv:
 
     # ------------------------------------------------------------ state I/O
     def state_dict(self):
-        return {'now': self.state_now.clone(), 'ever': self.state_ever.clone()}
+        return {'now': self.state_now.clone(), 'ever': self.state_ever.clone(),
+                'counters': self.state_counters.clone()}
 
     def load_state_dict(self, sd):
         self.state_now.copy_(sd['now'])
         self.state_ever.copy_(sd['ever'])
+        if 'counters' in sd:
+            self.state_counters.copy_(sd['counters'])
 
 
 def mat2euler(mat, device=None):

@@ -199,25 +199,32 @@ class RolloutStudent:
         one launch.  Requirements: `policy.device_tensors`, a capturable policy / contact
         source (no host syncs, no host->device copies inside), output='torch'.  The returned
         tensors are the graph's static buffers: they are overwritten by the next replay.
-        Launch arguments are baked at capture: pass Variation's per-episode draws through
-        `num_grey` (copied into a static tensor before each replay) to vary them."""
+        Launch arguments are baked at capture; what varies between replays lives on the device:
+        explicit `num_grey` draws are copied into a static tensor before each replay, and with
+        num_grey=None Variation's draws come from the env's counter-based generator, whose
+        stream index is a device word that every (replayed) reset advances."""
         assert self.output == 'torch' and getattr(self.policy, 'device_tensors', False)
         B = self.rollout_batch_size
-        if getattr(self, '_graph', None) is None or self._graph_test != bool(test):
+        explicit = num_grey is not None
+        if (getattr(self, '_graph', None) is None or self._graph_test != bool(test)
+                or self._graph_explicit != explicit):
             self._static_ng = torch.zeros(B, dtype=torch.int32, device=self.device)
-            if num_grey is not None:
+            if explicit:
                 self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
-            side = torch.cuda.Stream(self.device)
+            ng = self._static_ng if explicit else None       # None: the env's counter-based draw, whose
+            side = torch.cuda.Stream(self.device)            # device-side stream index advances per replay
             side.wait_stream(torch.cuda.current_stream(self.device))
+            snapshot = self.env.state_dict()                   # the warm-up pass must not count
             with torch.cuda.stream(side):                      # warm-up outside the capture
-                self._rollout_body(test, self._static_ng)
+                self._rollout_body(test, ng)
+                self.env.load_state_dict(snapshot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._graph_ep, self._graph_Qs = self._rollout_body(test, self._static_ng)
-            self._graph, self._graph_test = graph, bool(test)
-        if num_grey is not None:
+                self._graph_ep, self._graph_Qs = self._rollout_body(test, ng)
+            self._graph, self._graph_test, self._graph_explicit = graph, bool(test), explicit
+        if explicit:
             self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
         self._graph.replay()
         return self._finish(dict(self._graph_ep), self._graph_Qs)

@@ -222,6 +222,10 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
 
 /* Raw packed state, device pointers owned by the handle (zero-copy views). */
 int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);
+/* The handle's two generator stream indices (device uint32[2]: generator-drawn resets,
+ * generator-drawn placements so far); together with the packed state this is everything a
+ * checkpoint of the batch needs (the reference never checkpoints env state). */
+int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters);
 
 /* BlocksEnv.compute_reward (fetch_env.py:135-143), stateless and vectorised as
  * HER calls it (config.py:110-111): n rows of `len` floats each. */

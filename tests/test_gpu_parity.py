@@ -835,6 +835,19 @@ def test_graphed_rollout_equals_eager():
         assert wg.success_history[-1] == we.success_history[-1]
         assert torch.equal(wg.env.state_ever, we.env.state_ever)
     assert (epg['o'][:, 0, 0] == torch.as_tensor(ng + 2, device=DEV).float()).all()   # Variation obs[0] = num_blocks
+    # generator-drawn episodes: the stream index is a device word, so replays draw fresh num_grey
+    # and track an eager worker that performs the same sequence of resets
+    wg2, _ = worker()
+    we2, src_e2 = worker()
+    seen = []
+    for r in range(3):
+        epg = wg2.generate_rollouts_graphed()
+        src_e2.t = 0
+        epe = we2.generate_rollouts()
+        seen.append(wg2.env.num_objs_per_env().clone())
+        for k in epe:
+            assert torch.equal(epg[k], epe[k]), k
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
 
 
 class _ZeroPolicy:                       # module level so save_policy can pickle it

@@ -147,6 +147,7 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, 0, T, masks, s);
     }
     CK(hipDeviceSynchronize());
+    uint32_t *d_counter; CK(hipMalloc(&d_counter, 8)); CK(hipMemset(d_counter, 0, 8));   // ResetConst::reset_counter
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double bytes = (double)B * (T * 9 + 16);
     auto report = [&](const char *name, double ms, double nbytes) {
@@ -180,14 +181,14 @@ int main(int argc, char **argv)
         TIME("stream same byte mix B1024 g256", (double)B * T * 9,
              hipLaunchKernelGGL(v_stream<1024>, dim3(nvec / 1024), dim3(1024), 0, 0, masks, reward, flags, B, T));
         {
-            ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1;
+            ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1; rc0.reset_counter = d_counter;
             TIME("LIB k_rollout_vec4<masks,nt> 256x1024", bytes,
                  hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
         }
         {
-            ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1;
+            ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1; rc0.reset_counter = d_counter;
             static unsigned long long *cnt = nullptr;
             if (!cnt) { CK(hipMalloc(&cnt, 16)); CK(hipMemset(cnt, 0, 16)); }
             TIME("LIB +count 256 blocks x 1024", bytes,
@@ -218,6 +219,9 @@ int main(int argc, char **argv)
         ROLL(256, 5, false, true, 1024);
         ROLL(256, 5, true, true, 1024);
         ROLL(1024, 5, true, true, 256);
+        ROLL(256, 25, false, true, 1024);
+        ROLL(256, 50, false, true, 1024);
+        ROLL(128, 50, false, true, 2048);
 #define ROLLLD(PAD)                                                                                            \
     TIME("rollout ld = B/4 + " #PAD " uint4 (nts)", bytes,                                                      \
          hipLaunchKernelGGL((v_rollout_ld<256, 5>), dim3(1024), dim3(256), 0, 0, now, ever, masks, reward, flags, B, \
@@ -236,7 +240,7 @@ int main(int argc, char **argv)
         const PairTable tab = pair_table(info);
         const int R = (T + 1) | 1;
         const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
-        ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1;
+        ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1; rc.reset_counter = d_counter;
         const double ebytes = (double)B * (16 + T * 4) + 4.0 * (n_ag + n_g + n_s);
         TIME("fill float4 plain (ag buffer)", 4.0 * n_ag,
              hipLaunchKernelGGL(v_fill<false>, dim3(2048), dim3(256), 0, 0, (float4 *)ag, (int64_t)(n_ag / 4)));
