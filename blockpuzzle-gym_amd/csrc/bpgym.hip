@@ -632,8 +632,10 @@ __device__ __forceinline__ float tern(uint32_t now, uint32_t ever, uint32_t p)
 // The wave's output region is contiguous, so lanes take consecutive float4
 // chunks (1 KiB per wave store); (env, row) is tracked incrementally.
 // hist[e * R + r] = (now, ever) of env e at row r, in LDS.
+// `out` points at row `row0` of the first env; env e's rows start env_stride floats later
+// (env_stride = rows * DIMG when the whole region is contiguous).
 template <int SIDE, bool NT>
-__device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int nvalid, int rows,
+__device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int nvalid, int rows, int env_stride,
                                                     const uint2 *hist, int R, const PairTable *tab, int lane)
 {
     constexpr int DIMG = SIDE * SIDE;
@@ -641,9 +643,12 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
         constexpr int QPR = DIMG / 4;
         const int per_env = rows * QPR;
         const int total = nvalid * per_env;
+        const int es4 = env_stride >> 2;
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        // one chunk stream per lane: a 4-way interleaved variant (four LDS reads / stores in flight per
+        // iteration) measured SLOWER (3.0 vs 2.45 ms for the full episode at 1 M envs)
         int e = 0, rem = lane;
         while (rem >= per_env) { rem -= per_env; e++; }
-        float4 *o4 = reinterpret_cast<float4 *>(out);
         for (int cidx = lane; cidx < total; cidx += 64) {
             const int r = rem / QPR, q = rem - r * QPR;
             const uint2 h = hist[e * R + r];
@@ -653,7 +658,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
             v.y = tern(h.x, h.y, (pw >> 5) & 31u);
             v.z = tern(h.x, h.y, (pw >> 10) & 31u);
             v.w = tern(h.x, h.y, (pw >> 15) & 31u);
-            st_f4<NT>(&o4[cidx], v);
+            st_f4<NT>(&o4[(int64_t)e * es4 + rem], v);
             rem += 64;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
@@ -665,7 +670,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
         for (int f = lane; f < total; f += 64) {
             const int r = rem / DIMG, k = rem - r * DIMG;
             const uint2 h = hist[e * R + r];
-            st_1<NT>(&out[f], tern(h.x, h.y, tab->flat[k]));
+            st_1<NT>(&out[(int64_t)e * env_stride + rem], tern(h.x, h.y, tab->flat[k]));
             rem += 64;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
@@ -1081,9 +1086,13 @@ __global__ void __launch_bounds__(64)
 k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
-          int64_t n, int T, int R, StepConst c, SynthConst s, PairTable tabv, ResetConst rc,
+          int64_t n, int T, int RC, int R, StepConst c, SynthConst s, PairTable tabv, ResetConst rc,
           unsigned long long *__restrict__ count, unsigned long long *__restrict__ zero_next)
 {
+    // The T+1 matrices of an episode are produced in chunks of RC rows (one chunk = the whole
+    // episode for T <= 63): a short step phase (lane = env, state in registers, packed rows of
+    // the chunk into LDS, [64][R] x 8 B with R = RC | 1 odd -> conflict-free ds_write_b64)
+    // followed by the streaming phase for those rows.
     constexpr int DIMG = SIDE * SIDE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2 *hist = reinterpret_cast<uint2 *>(smem);                       // [64][R]
@@ -1093,39 +1102,72 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     if (zero_next && blockIdx.x == 0 && lane == 0) *zero_next = 0ull;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-    bool succ_final = false;
-    if (lane < nvalid) {
-        const int64_t i = base + lane;
-        uint32_t a = now[i], e = ever[i];
+    const bool active = lane < nvalid;
+    const int64_t i = base + lane;
+    uint32_t a = 0, e = 0, key = 0, valid = 0, forced = 0;
+    if (active) {
+        a = now[i]; e = ever[i];
         if (rc.enabled) reset_core(a, e, i, rc);
-        uint32_t key = 0, valid = 0, forced = 0;
         if (SRC == SRC_SYNTH) {
             key = synth_key(s.seed, s.env_base + (uint32_t)i);
             valid = s.valid_by_n[nobj_of(e)];
             forced = s.forced_by_n[nobj_of(e)];
         }
-        uint2 *my = hist + lane * R;
-        my[0] = make_uint2(a, e);                  // initial_ag (rollout.py:82-83)
-#pragma unroll 5
-        for (int t = 0; t < T; t++) {
-            uint32_t m, rb, fl;
-            if (SRC == SRC_MASKS) m = masks[(int64_t)t * n + i];
-            else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
-            step_core(a, e, m, c, rb, fl);
-            my[t + 1] = make_uint2(a, e);
-            if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
-            if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
-        }
-        now[i] = a; ever[i] = e;
-        succ_final = (e >> 31) != 0;
     }
+    uint2 *my = hist + lane * R;
+    constexpr int EP_BATCH = 10;        // masks of 10 steps are requested together: one memory
+                                        // latency per batch instead of one per step
+    for (int r0 = 0; r0 <= T; r0 += RC) {
+        const int r1 = (r0 + RC < T + 1) ? r0 + RC : T + 1;      // rows [r0, r1) of every env
+        if (active) {
+            if (r0 == 0) my[0] = make_uint2(a, e);               // row 0: initial_ag (rollout.py:82-83)
+            const int tb = (r0 == 0) ? 0 : r0 - 1, te = r1 - 1;  // steps tb .. te-1 produce rows tb+1 .. te
+            for (int t0 = tb; t0 < te; t0 += EP_BATCH) {
+                uint32_t mb[EP_BATCH];
+                if (SRC == SRC_MASKS) {
+#pragma unroll
+                    for (int u = 0; u < EP_BATCH; u++)
+                        mb[u] = (t0 + u < te) ? masks[(int64_t)(t0 + u) * n + i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < EP_BATCH; u++) {
+                    const int t = t0 + u;
+                    if (t < te) {
+                        uint32_t m, rb, fl;
+                        if (SRC == SRC_MASKS) m = mb[u];
+                        else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
+                        step_core(a, e, m, c, rb, fl);
+                        my[t + 1 - r0] = make_uint2(a, e);
+                        if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
+                        if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (ep_ag)
+            wave_write_matrices<SIDE, NT>(ep_ag + (base * (int64_t)(T + 1) + r0) * DIMG, nvalid, r1 - r0,
+                                          (T + 1) * DIMG, hist, R, tab, lane);
+        if (ep_succ) {
+            // info['is_success'] after step t = latch in row t+1 (rollout.py:127-128,131)
+            const int rs = (r0 == 0) ? 1 : r0, cnt = r1 - rs;    // rows rs .. r1-1 -> steps rs-1 .. r1-2
+            float *o = ep_succ + base * (int64_t)T + (rs - 1);
+            const int total = nvalid * cnt;
+            int ee = 0, rem = lane;
+            while (cnt > 0 && rem >= cnt) { rem -= cnt; ee++; }
+            for (int f = lane; f < total; f += 64) {
+                st_1<NT>(&o[(int64_t)ee * T + rem], (hist[ee * R + (rs - r0) + rem].y >> 31) ? 1.0f : 0.0f);
+                rem += 64;
+                while (rem >= cnt) { rem -= cnt; ee++; }
+            }
+        }
+        __syncthreads();                                         // the tile is reused by the next chunk
+    }
+    if (active) { now[i] = a; ever[i] = e; }
     if (count) {
-        const unsigned long long nb = (unsigned long long)__popcll(__ballot(succ_final));
+        const unsigned long long nb = (unsigned long long)__popcll(__ballot(active && (e >> 31) != 0));
         if (lane == 0 && nb) atomicAdd(count, nb);
     }
-    __syncthreads();
-    if (ep_ag)
-        wave_write_matrices<SIDE, NT>(ep_ag + base * (int64_t)(T + 1) * DIMG, nvalid, T + 1, hist, R, tab, lane);
     if (ep_g) {
         // episode['g']: T copies of the constant goal row per env (rollout.py:151)
         float *o = ep_g + base * (int64_t)T * DIMG;
@@ -1140,18 +1182,6 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             }
         } else {
             for (int f = lane; f < total; f += 64) st_1<NT>(&o[f], tab->goal[f % DIMG]);
-        }
-    }
-    if (ep_succ) {
-        // info['is_success'] after step t = latch in hist row t+1 (rollout.py:127-128,131)
-        float *o = ep_succ + base * (int64_t)T;
-        const int total = nvalid * T;
-        int e = 0, rem = lane;
-        while (rem >= T) { rem -= T; e++; }
-        for (int f = lane; f < total; f += 64) {
-            st_1<NT>(&o[f], (hist[e * R + rem + 1].y >> 31) ? 1.0f : 0.0f);
-            rem += 64;
-            while (rem >= T) { rem -= T; e++; }
         }
     }
 }
@@ -1920,9 +1950,17 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
             (a->d_ep_success && !aligned4(a->d_ep_success)))
             return fail(BPG_ERR_ARG, "episode buffers must be 16-byte aligned");
-        const int R = (a->T + 1) | 1;
+        // Rows per chunk.  One chunk whenever the whole episode fits a 64-row (33 KB) tile: the wave then
+        // streams ONE contiguous 64 x (T+1) x dimg region.  Splitting T = 50 into two 26-row chunks was
+        // measured 30 % SLOWER (4.1 vs 3.1 ms for the full episode, 2.4 vs 1.9 ms ag-only) although it
+        // doubles the waves per CU: the per-env 3.7 KB segments with 3.7 KB holes lose the long contiguous
+        // write streams.  Longer horizons are chunked because the tile would not fit.
+        const int rows_total = a->T + 1;
+        int nchunks = 1;
+        while ((rows_total + nchunks - 1) / nchunks > 64) nchunks++;
+        const int RC = (rows_total + nchunks - 1) / nchunks;
+        const int R = RC | 1;
         const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
-        if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "T too large for the LDS history tile");
         const PairTable tab = pair_table(b->info);
         const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
         const bool synth = (a->d_masks == nullptr);
@@ -1937,12 +1975,12 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
             }
             if (synth)
                 hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
-                                   rc, cnt, znext);
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, RC, R, c, s,
+                                   tab, rc, cnt, znext);
             else
                 hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, R, c, s, tab,
-                                   rc, cnt, znext);
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, RC, R, c, s,
+                                   tab, rc, cnt, znext);
             return BPG_OK;
         });
         if (rcode == BPG_OK) rcode = check_launch("k_episode");

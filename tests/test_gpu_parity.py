@@ -603,7 +603,7 @@ def test_edge_batch_sizes(B):
             np.testing.assert_array_equal(sc.cpu().numpy(), ref['info_is_success'])
 
 
-@pytest.mark.parametrize('T', [1, 2, 127, 200])
+@pytest.mark.parametrize('T', [1, 2, 17, 127, 200, 1023])
 def test_rollout_lengths(T):
     """T=1, and T large enough that the episode writer's LDS history tile exceeds the 64 KiB
     default (opt-in dynamic LDS path); max_episode_steps = 100 so `done` flips inside."""

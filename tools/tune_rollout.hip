@@ -122,6 +122,16 @@ __global__ void __launch_bounds__(256) v_fill(float4 *__restrict__ out, int64_t 
         st_f4<NT>(&out[v], make_float4(1.f, 0.f, -1.f, (float)(v & 1)));
 }
 
+// a float4 fill from one-wave blocks that each reserve `lds` bytes of LDS (never touched): how
+// much write bandwidth do 160 KB / lds waves per CU sustain?  (the episode writer holds 26 KB/wave)
+__global__ void __launch_bounds__(64) v_fill_occ(float4 *__restrict__ out, int64_t nvec_per_block)
+{
+    extern __shared__ float4 dummy[];
+    if (threadIdx.x == 999) dummy[0] = make_float4(0, 0, 0, 0);
+    float4 *o = out + (int64_t)blockIdx.x * nvec_per_block;
+    for (int64_t v = threadIdx.x; v < nvec_per_block; v += 64) o[v] = make_float4(1.f, 0.f, -1.f, (float)(v & 1));
+}
+
 int main(int argc, char **argv)
 {
     const int64_t B = argc > 1 ? atoll(argv[1]) : (1 << 20);
@@ -238,7 +248,7 @@ int main(int argc, char **argv)
         CK(hipMalloc(&ag, n_ag * 4)); CK(hipMalloc(&gg, n_g * 4)); CK(hipMalloc(&sc, n_s * 4));
         bpg_variant_info info; fill_variant_info(BPG_BLOCKS_TOUCH_VARIATION, &info);
         const PairTable tab = pair_table(info);
-        const int R = (T + 1) | 1;
+        const int RC = T + 1, R = RC | 1;              // one chunk, as bpg_rollout picks for T <= 63
         const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
         ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1; rc.reset_counter = d_counter;
         const double ebytes = (double)B * (16 + T * 4) + 4.0 * (n_ag + n_g + n_s);
@@ -246,23 +256,33 @@ int main(int argc, char **argv)
              hipLaunchKernelGGL(v_fill<false>, dim3(2048), dim3(256), 0, 0, (float4 *)ag, (int64_t)(n_ag / 4)));
         TIME("fill float4 nt    (ag buffer)", 4.0 * n_ag,
              hipLaunchKernelGGL(v_fill<true>, dim3(2048), dim3(256), 0, 0, (float4 *)ag, (int64_t)(n_ag / 4)));
+        for (int ldsk : {1, 8, 13, 20, 26, 40}) {
+            char nm[64]; snprintf(nm, 64, "fill, 1-wave blocks holding %d KB LDS", ldsk);
+            const int64_t per_block = (int64_t)(n_ag / 4) / (B / 64);
+            TIME(nm, 4.0 * n_ag, hipLaunchKernelGGL(v_fill_occ, dim3((unsigned)(B / 64)), dim3(64), ldsk * 1024, 0,
+                                                   (float4 *)ag, per_block));
+        }
         TIME("episode<6> plain stores", ebytes,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, false>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
-                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, R, c, s, tab,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, RC, R, c, s, tab,
                                 rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
         TIME("episode<6> nt stores", ebytes,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
-                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, R, c, s, tab,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, RC, R, c, s, tab,
                                 rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
+        TIME("episode<6> plain, ag + success only", (double)B * (16 + T * 4) + 4.0 * (n_ag + n_s),
+             hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, false>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, (float *)nullptr, sc, B, T, RC, R,
+                                c, s, tab, rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
         TIME("episode<6> nt, ag only", (double)B * (16 + T * 4) + 4.0 * n_ag,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
                                 ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, (float *)nullptr,
-                                (float *)nullptr, B, T, R, c, s, tab, rc, (unsigned long long *)nullptr,
+                                (float *)nullptr, B, T, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
                                 (unsigned long long *)nullptr));
         TIME("episode<6> nt, g only", (double)B * (16 + T * 4) + 4.0 * n_g,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
                                 ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr, gg,
-                                (float *)nullptr, B, T, R, c, s, tab, rc, (unsigned long long *)nullptr,
+                                (float *)nullptr, B, T, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
                                 (unsigned long long *)nullptr));
     }
     return 0;
