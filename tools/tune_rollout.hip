@@ -86,6 +86,37 @@ v_rollout_ld(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint
     }
 }
 
+// wave-tiled layout: masks / reward / flags stored as [tile][t][64 lanes] (uint4 per lane), so a
+// wave streams ONE contiguous T KiB run per stream instead of T pieces 4 MiB apart
+template <int BLOCK, bool NTS>
+__global__ void __launch_bounds__(BLOCK)
+v_rollout_tiled(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+                uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T, StepConst c)
+{
+    const int64_t nvec = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        uint4 a = reinterpret_cast<uint4 *>(now)[v];
+        uint4 e = reinterpret_cast<uint4 *>(ever)[v];
+        uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w};
+        const int64_t tile = v >> 6, lane = v & 63;
+        const uint4 *mrow = reinterpret_cast<const uint4 *>(masks) + tile * T * 64 + lane;
+        uint4 *rrow = reinterpret_cast<uint4 *>(reward_tb) + tile * T * 64 + lane;
+        uint32_t *frow = reinterpret_cast<uint32_t *>(flags_tb) + tile * T * 64 + lane;
+#pragma unroll 5
+        for (int t = 0; t < T; t++) {
+            const uint4 m = mrow[t * 64];
+            uint32_t mm[4] = {m.x, m.y, m.z, m.w}, rb[4], fl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) step_core(an[k], ee[k], mm[k], c, rb[k], fl[k]);
+            st4<NTS>(&rrow[t * 64], make_uint4(rb[0], rb[1], rb[2], rb[3]));
+            st1<NTS>(&frow[t * 64], fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24));
+        }
+        reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
+        reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
+    }
+}
+
 // same byte mix, no env logic: the streaming ceiling for this access pattern
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -229,6 +260,18 @@ int main(int argc, char **argv)
         ROLL(256, 5, false, true, 1024);
         ROLL(256, 5, true, true, 1024);
         ROLL(1024, 5, true, true, 256);
+        TIME("rollout TILED B256 nts g1024", bytes,
+             hipLaunchKernelGGL((v_rollout_tiled<256, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks, reward,
+                                flags, B, T, c));
+        TIME("rollout TILED B256 plain g1024", bytes,
+             hipLaunchKernelGGL((v_rollout_tiled<256, false>), dim3(1024), dim3(256), 0, 0, now, ever, masks, reward,
+                                flags, B, T, c));
+        TIME("rollout TILED B1024 nts g256", bytes,
+             hipLaunchKernelGGL((v_rollout_tiled<1024, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks, reward,
+                                flags, B, T, c));
+        TIME("rollout TILED B64 nts g4096", bytes,
+             hipLaunchKernelGGL((v_rollout_tiled<64, true>), dim3(4096), dim3(64), 0, 0, now, ever, masks, reward,
+                                flags, B, T, c));
         ROLL(256, 25, false, true, 1024);
         ROLL(256, 50, false, true, 1024);
         ROLL(128, 50, false, true, 2048);
