@@ -935,3 +935,23 @@ def test_c_abi_from_plain_cpp_host(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'reward bits 0x80000000' in out.stdout and 'success count 1000 of 1000, mismatches 0' in out.stdout
+
+
+def test_contact_list_input_is_sanitised():
+    """Out-of-range input never indexes out of bounds: ncon beyond maxcon / negative is clamped,
+    geom ids outside the id2obj table (negative int16, >= 64) are ignored like None-mapped geoms."""
+    env = bpg.make('BlocksTouch-v0', num_envs=5, device=DEV)
+    env.reset()
+    cube0, cube1, finger = 23, 24, 17
+    pairs = np.zeros((5, 4, 2), np.int16)
+    pairs[0, :2] = [[cube0, cube1], [finger, cube0]]          # normal
+    pairs[1, :] = [[cube0, cube1]] * 4                         # ncon claims 100 -> clamped to maxcon 4
+    pairs[2, 0] = [-1, cube1]                                  # negative geom id -> ignored
+    pairs[3, 0] = [200, cube0]                                 # beyond the table -> ignored
+    pairs[4, 0] = [cube0, cube1]                               # ncon negative -> no contacts
+    ncon = np.array([2, 100, 1, 1, -7], np.int32)
+    obs, r, done, info = env.step(None, contacts=(pairs, ncon))
+    ag = obs['achieved_goal'].cpu().numpy().reshape(5, 4, 4)
+    assert ag[0, 2, 3] == 1 and ag[0, 0, 2] == 1 and ag[1, 2, 3] == 1
+    assert (ag[2] == -1).all() and (ag[3] == -1).all() and (ag[4] == -1).all()
+    np.testing.assert_array_equal(info['is_success'].cpu().numpy(), [True, True, False, False, False])
