@@ -246,6 +246,17 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_extras:
         out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
+        # SURVEY 8(d)'s per-step accounting (25 B/env-step: state read+written every step) for the
+        # one-launch-per-step form of the same path, next to the fused headline above
+        one = out['extra'].get('step_masks_single_launch', {})
+        grp = out['extra'].get('step_masks_graph_T_launches', {})
+        if 'GB/s' in one:
+            out['roofline_per_step_launch'] = {
+                'bound': 'hbm', 'kernel': 'k_step_vec4<masks>', 'bytes_per_env_step': 25,
+                'achieved': one['GB/s'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': one['GB/s'] / HBM_PEAK_GBS, 'kernel_ms': one['ms'],
+                'graph_replay_of_T_launches': {k: grp.get(k) for k in ('ms', 'GB/s', 'frac_hbm_peak',
+                                                                      'env_steps_per_sec')}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
     if multi:
