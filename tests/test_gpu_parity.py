@@ -955,3 +955,43 @@ def test_contact_list_input_is_sanitised():
     assert ag[0, 2, 3] == 1 and ag[0, 0, 2] == 1 and ag[1, 2, 3] == 1
     assert (ag[2] == -1).all() and (ag[3] == -1).all() and (ag[4] == -1).all()
     np.testing.assert_array_equal(info['is_success'].cpu().numpy(), [True, True, False, False, False])
+
+
+def test_remaining_abi_entry_points():
+    """Entry points not exercised elsewhere: packed compute_reward, desired_goal with a row
+    stride, synthetic masks from a later step (t0 > 0), float64 achieved_goal with a stride."""
+    import ctypes as C
+    L = bpg._lib.lib()
+    env_id, B = 'ToppleTower-v0', 777
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=5)
+    env.reset()
+    rng = np.random.RandomState(9)
+    for t in range(5):
+        env.step(None, contact_masks=legal_masks(rng, 1, B, 6)[0].view(np.int32))
+    # packed reward == float reward of the float views == oracle
+    out = torch.empty(B, dtype=torch.float32, device=DEV)
+    bpg._lib.check(L.bpg_compute_reward_packed(C.c_void_p(env.state_now.data_ptr()), C.c_void_p(env.state_ever.data_ptr()),
+                                               env.info.want_touch, env.info.want_never, B,
+                                               C.c_void_p(out.data_ptr()), 0, None))
+    obs = env._get_obs()
+    ref = O.compute_reward(obs['achieved_goal'].cpu().numpy(), obs['desired_goal'].cpu().numpy())
+    np.testing.assert_array_equal(bits(out), ref.view(np.uint32))
+    np.testing.assert_array_equal(bits(bpg.compute_reward(obs['achieved_goal'], obs['desired_goal'])), ref.view(np.uint32))
+    # desired_goal / float64 achieved_goal into strided slots
+    slot = torch.full((B, 3, 36), 7.0, dtype=torch.float32, device=DEV)
+    bpg._lib.check(L.bpg_get_desired_goal_f32(env._h, C.c_void_p(slot[:, 1].data_ptr()), 3 * 36, None))
+    assert torch.equal(slot[:, 1], obs['desired_goal']) and (slot[:, 0] == 7).all() and (slot[:, 2] == 7).all()
+    slot64 = torch.full((B, 2, 36), 7.0, dtype=torch.float64, device=DEV)
+    bpg._lib.check(L.bpg_get_achieved_goal_f64(env._h, C.c_void_p(slot64[:, 1].data_ptr()), 2 * 36, None))
+    assert torch.equal(slot64[:, 1], obs['achieved_goal'].double()) and (slot64[:, 0] == 7).all()
+    # synthetic masks for steps 5..12 == what stepping with the in-kernel source consumes next
+    m = torch.empty((8, B), dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks(env._h, 5, 8, C.c_void_p(m.data_ptr()), None))
+    np.testing.assert_array_equal(m.cpu().numpy().view(np.uint32), O.synth_masks(5, np.arange(B), 13, 6)[5:])
+    twin = bpg.make(env_id, num_envs=B, device=DEV, seed=5)
+    twin.load_state_dict(env.state_dict())
+    for t in range(8):
+        _, r1, _, _ = env.step(None)                               # in-kernel synthetic source at elapsed = 5 + t
+        _, r2, _, _ = twin.step(None, contact_masks=m[t])
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32))
+    assert torch.equal(env.state_ever, twin.state_ever)
