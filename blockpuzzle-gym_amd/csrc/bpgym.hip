@@ -213,9 +213,20 @@ __device__ __forceinline__ void step_core(uint32_t &now, uint32_t &ever, uint32_
     flags = succ | ((elapsed >= c.max_steps) ? (uint32_t)BPG_FLAG_DONE : 0u) | (ok ? (uint32_t)BPG_FLAG_STEP_OK : 0u);
 }
 
-// build-defined counter-based contact source (DESIGN.md "synthetic contacts"):
-// lowbias32 finaliser chained over (seed, env id, step); 5 x 21 random bits are
-// combined bit-sliced into 21 Bernoulli(5/32) bits (0.00101b, LSB first).
+// build-defined counter-based contact source (DESIGN.md "synthetic contacts"), a pure function
+// of (seed, global env id, step).  Per env two 32-bit keys from the lowbias32 finaliser (once
+// per launch); per step two well-mixed words a, b: a Weyl step of the key, an xorshift, ONE
+// 32x32->64 multiply each, high half folded onto the low half (v_mad_u64_u32 + v_xor).  On gfx950
+// an integer multiply issues like any other VOP3 instruction (tools/valu_rates.hip: 3.3 vs 3.2
+// cycles), so the cost of a generator is its instruction count: round 1's four 2-multiply hashes
+// per step (about 37 instructions) made the in-kernel-contacts rollout VALU-bound at 0.38 of peak.
+// The 21 Bernoulli(5/32) bits are U < 5 on a bit-sliced 5-bit uniform per pair,
+//     A & B & (C | D),   A, B, C fair bits, D a 1/4 bit,
+// with A = a[0..20], B = b[0..20], C = a[21..31] ++ b[21..30] -- 63 fresh bits per step -- and
+// the low-order digit D_j = a[(j-7) mod 32] & b[(j-13) mod 32] taken from bits that serve as
+// A / B / C of OTHER pairs: every pair is exactly Bernoulli(5/32), steps and envs are independent,
+// and two pairs of the same step that share such a bit correlate with r <= 0.04 (measured 0.038,
+// tools/synth_quality.py) -- the price of 64 instead of 105 fresh bits per step.
 __device__ __forceinline__ uint32_t hash32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x7feb352dU;
@@ -229,20 +240,45 @@ __device__ __forceinline__ uint32_t synth_key(uint32_t seed, uint32_t env_id)
     return hash32(seed ^ hash32(env_id + 0x9E3779B9U));
 }
 
-__device__ __forceinline__ uint32_t synth_mask(uint32_t key, uint32_t t, uint32_t valid, uint32_t forced)
+__device__ __forceinline__ uint32_t mulfold(uint32_t x, uint32_t k)
 {
-    const uint32_t M21 = PAIR_BITS;
-    const uint32_t base = key + 0x85EBCA6BU + (4u * t) * 0x9E3779B9U;
-    const uint32_t w0 = hash32(base);
-    const uint32_t w1 = hash32(base + 0x9E3779B9U);
-    const uint32_t w2 = hash32(base + 2u * 0x9E3779B9U);
-    const uint32_t w3 = hash32(base + 3u * 0x9E3779B9U);
-    uint32_t acc = ((w0 >> 21) | ((w1 >> 21) << 11)) & M21;
-    acc &= w3;
-    acc |= (w2 & M21);
-    acc &= w1;
-    acc &= w0;
-    return (acc & valid) | forced;
+    const uint64_t p = (uint64_t)x * k;
+    return (uint32_t)(p >> 32) ^ (uint32_t)p;
+}
+
+// per-env part of the source, computed once per launch and kept in registers
+struct SynthLane {
+    uint32_t ka, kb, valid, forced;
+};
+
+__device__ __forceinline__ SynthLane synth_lane(const SynthConst &s, uint32_t local_env, uint32_t nobj)
+{
+    SynthLane l;
+    l.ka = synth_key(s.seed, s.env_base + local_env);
+    l.kb = hash32(l.ka ^ 0x85EBCA6BU);
+    // compare-select over the eight table rows (they sit in SGPRs): indexing the kernel-argument
+    // array with a per-lane value would be a memory load that depends on the state load
+    uint32_t valid = s.valid_by_n[0], forced = s.forced_by_n[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 8; k++) {
+        valid = nobj == k ? s.valid_by_n[k] : valid;
+        forced = nobj == k ? s.forced_by_n[k] : forced;
+    }
+    l.valid = valid;
+    l.forced = forced;
+    return l;
+}
+
+__device__ __forceinline__ uint32_t synth_mask(const SynthLane &l, uint32_t t)
+{
+    const uint32_t u = l.ka + (t + 1u) * 0x9E3779B9U;
+    uint32_t x = u, y = u ^ l.kb;
+    x ^= x >> 15;
+    y ^= y >> 15;
+    const uint32_t a = mulfold(x, 0xD6E8FEB9U), b = mulfold(y, 0xCA5A8263U);
+    const uint32_t C = (a >> 21) | ((b >> 21) << 11);
+    const uint32_t D = __builtin_amdgcn_alignbit(a, a, 25) & __builtin_amdgcn_alignbit(b, b, 19);   // rotl 7, rotl 13
+    return (a & b & (C | D) & l.valid) | l.forced;
 }
 
 __device__ __forceinline__ uint32_t nobj_of(uint32_t ever) { return (ever >> NOBJ_SHIFT) & 7u; }
@@ -339,13 +375,13 @@ k_init(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, uint3
 // ------------------------------ single step ---------------------------------
 enum { SRC_MASKS = 0, SRC_SYNTH = 1 };
 
+// the step's contact mask: read from memory, or the synthetic source at the env's elapsed step
 template <int SRC>
-__device__ __forceinline__ uint32_t fetch_mask(uint32_t m, uint32_t now, uint32_t ever, uint32_t key,
+__device__ __forceinline__ uint32_t fetch_mask(uint32_t m, uint32_t now, uint32_t ever, uint32_t local_env,
                                                const SynthConst &s)
 {
     if (SRC == SRC_MASKS) return m;
-    const uint32_t nobj = nobj_of(ever);
-    return synth_mask(key, (now >> ELAPSED_SHIFT) & ELAPSED_MAX, s.valid_by_n[nobj], s.forced_by_n[nobj]);
+    return synth_mask(synth_lane(s, local_env, nobj_of(ever)), (now >> ELAPSED_SHIFT) & ELAPSED_MAX);
 }
 
 // 4 envs per lane: 16-byte coalesced loads/stores of now / ever / masks / reward,
@@ -367,9 +403,7 @@ k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint3
         uint32_t rb[4], fl[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t key = 0;
-            if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)(4 * v + k));
-            const uint32_t mk = fetch_mask<SRC>(mm[k], an[k], ee[k], key, s);
+            const uint32_t mk = fetch_mask<SRC>(mm[k], an[k], ee[k], (uint32_t)(4 * v + k), s);
             step_core(an[k], ee[k], mk, c, rb[k], fl[k]);
         }
         reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
@@ -382,9 +416,7 @@ k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint3
     if (gtid < n - tail0) {
         const int64_t i = tail0 + gtid;
         uint32_t a = now[i], e = ever[i], rb, fl;
-        uint32_t key = 0;
-        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
-        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, (uint32_t)i, s);
         step_core(a, e, mk, c, rb, fl);
         now[i] = a; ever[i] = e;
         if (reward) reward[i] = rb;
@@ -401,9 +433,7 @@ k_step_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t a = now[i], e = ever[i], rb, fl;
-        uint32_t key = 0;
-        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
-        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, (uint32_t)i, s);
         step_core(a, e, mk, c, rb, fl);
         now[i] = a; ever[i] = e;
         if (reward) reward[i] = rb;
@@ -492,13 +522,11 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t key = synth_key(s.seed, s.env_base + (uint32_t)i);
-        const uint32_t nobj = nobj_of(ever[i]);
-        const uint32_t valid = s.valid_by_n[nobj], forced = s.forced_by_n[nobj];
+        const SynthLane l = synth_lane(s, (uint32_t)i, nobj_of(ever[i]));
         for (int t = 0; t < T; t++) {
             uint32_t tt = (uint32_t)(t0 + t);
             tt = tt > ELAPSED_MAX ? ELAPSED_MAX : tt;
-            out[(int64_t)t * n + i] = synth_mask(key, tt, valid, forced);
+            out[(int64_t)t * n + i] = synth_mask(l, tt);
         }
     }
 }
@@ -523,91 +551,179 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned lo
     }
 }
 
-// T steps in one launch, 4 envs per lane, state in registers.  Masks / rewards
-// are time-major (T, n) so every access is a 16-byte-per-lane coalesced stream.
+// T steps in one launch, EPL envs per lane, state in registers.  Masks / rewards are
+// time-major (T, n) so every access is an (EPL*4)-byte-per-lane coalesced stream.
 // Optionally resets first (rollout.py:79) and counts the final successes.
-template <int SRC, bool NT>
-__global__ void __launch_bounds__(1024)
-k_rollout_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
-               uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
-               StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
-               unsigned long long *__restrict__ zero_next)
+// EPL, the block size and the loop form are picked from n by rollout_geometry().
+template <int EPL> struct LaneVec;
+template <> struct LaneVec<4> { using vec = uint4; using fl = uint32_t; };
+template <> struct LaneVec<2> { using vec = uint2; using fl = uint16_t; };
+template <> struct LaneVec<1> { using vec = uint32_t; using fl = uint8_t; };
+
+template <int EPL> __device__ __forceinline__ void unpack(const typename LaneVec<EPL>::vec &v, uint32_t *o)
 {
-    const int64_t nvec = n >> 2;
+    if constexpr (EPL == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if constexpr (EPL == 2) { o[0] = v.x; o[1] = v.y; }
+    else o[0] = v;
+}
+template <int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec pack(const uint32_t *o)
+{
+    if constexpr (EPL == 4) return make_uint4(o[0], o[1], o[2], o[3]);
+    else if constexpr (EPL == 2) return make_uint2(o[0], o[1]);
+    else return o[0];
+}
+template <bool NT, int EPL> __device__ __forceinline__ void st_vec(typename LaneVec<EPL>::vec *p, const uint32_t *o)
+{
+    if constexpr (EPL == 4) st_u4<NT>(p, make_uint4(o[0], o[1], o[2], o[3]));
+    else if constexpr (EPL == 2) {
+        if (NT) { __builtin_nontemporal_store(o[0], &p->x); __builtin_nontemporal_store(o[1], &p->y); }
+        else *p = make_uint2(o[0], o[1]);
+    } else st_1<NT>(p, o[0]);
+}
+
+// OUT: which per-step streams are written (bit 0 reward, bit 1 flags) -- a compile-time choice,
+// because a store behind a run-time `if (pointer)` makes the compiler assume "maybe not issued"
+// when it counts outstanding memory operations, and every wait then also drains the stores.
+enum { OUT_REWARD = 1, OUT_FLAGS = 2 };
+
+// PIPE: software-pipelined mask requests (see the loop); used for the latency-bound batch sizes.
+// The plain loop (PIPE = false: UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound
+// 4-envs-per-lane shape runs: with >= 16 waves per CU other waves cover the round trips, and the
+// pipelined form of that shape needs more than the 128 VGPRs a 1024-lane block may use.
+// RESET: the launch starts with reset_all_rollouts (rollout.py:79).  Compile-time because the
+// elapsed counter is then the same for every lane (step t of the launch), so the time-limit
+// test, the saturation and the generator's Weyl term run on the scalar unit.
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL = 5, bool PIPE = (EPL < 4)>
+__global__ void __launch_bounds__(1024)
+k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
+          uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
+          StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
+          unsigned long long *__restrict__ zero_next)
+{
+    using Vec = typename LaneVec<EPL>::vec;
+    using Fl = typename LaneVec<EPL>::fl;
+    const int64_t nvec = n / EPL;               // the host guarantees n % EPL == 0
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t nsucc = 0;
     if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        uint4 a = reinterpret_cast<uint4 *>(now)[v];
-        uint4 e = reinterpret_cast<uint4 *>(ever)[v];
-        uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w};
-        uint32_t key[4] = {0, 0, 0, 0}, valid[4], forced[4];
+        uint32_t an[EPL] = {}, ee[EPL] = {};
+        // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
+        // no wave starts its episode behind a memory round trip
+        if (!(RESET && rc.is_variation)) {
+            unpack<EPL>(reinterpret_cast<const Vec *>(now)[v], an);
+            unpack<EPL>(reinterpret_cast<const Vec *>(ever)[v], ee);
+        }
+        SynthLane sl[EPL];
+        // step_core() with the state unpacked for the duration of the launch: the touching set,
+        // the ever set (+ num_objs bits, untouched), the elapsed counter and the success latch (as
+        // an all-ones / zero mask) each in a register of their own, and the two comparisons of
+        // step_core turned into sign-bit arithmetic -- 11 instead of ~20 instructions per env-step.
+        uint32_t cm[EPL], ev[EPL], el[EPL], lat[EPL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (rc.enabled) reset_core(an[k], ee[k], 4 * v + k, rc);
-            if (SRC == SRC_SYNTH) {
-                key[k] = synth_key(s.seed, s.env_base + (uint32_t)(4 * v + k));
-                valid[k] = s.valid_by_n[nobj_of(ee[k])];
-                forced[k] = s.forced_by_n[nobj_of(ee[k])];
-            }
+        for (int k = 0; k < EPL; k++) {
+            if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc);
+            if (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
+            cm[k] = an[k] & PAIR_BITS;
+            el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
+            ev[k] = ee[k] & ~SUCC_BIT;
+            lat[k] = (uint32_t)((int32_t)ee[k] >> 31);
         }
-        const uint4 *mrow = reinterpret_cast<const uint4 *>(masks) + v;
-        uint4 *rrow = reinterpret_cast<uint4 *>(reward_tb) + v;
-        uint32_t *frow = reinterpret_cast<uint32_t *>(flags_tb) + v;
-#pragma unroll 5
-        for (int t = 0; t < T; t++) {
-            uint32_t mm[4] = {0, 0, 0, 0};
-            if (SRC == SRC_MASKS) {
-                const uint4 m = mrow[(int64_t)t * nvec];
-                mm[0] = m.x; mm[1] = m.y; mm[2] = m.z; mm[3] = m.w;
-            }
-            uint32_t rb[4], fl[4];
+        const Vec *mrow = reinterpret_cast<const Vec *>(masks) + v;
+        Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + v;
+        Fl *frow = reinterpret_cast<Fl *>(flags_tb) + v;
+        auto one_step = [&](int t, const uint32_t *mt) {
+            uint32_t rb[EPL], fl[EPL];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (SRC == SRC_SYNTH)
-                    mm[k] = synth_mask(key[k], (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX, valid[k], forced[k]);
-                step_core(an[k], ee[k], mm[k], c, rb[k], fl[k]);
+            for (int k = 0; k < EPL; k++) {
+                if (RESET) el[k] = (uint32_t)t;            // uniform: elapsed == step of the launch (T <= 1023)
+                const uint32_t m = (SRC == SRC_SYNTH) ? synth_mask(sl[k], el[k]) : mt[k];
+                cm[k] = m & c.valid;
+                ev[k] |= cm[k];
+                const uint32_t bad = (c.want_touch & ~cm[k]) | (c.want_never & ev[k]);    // < 2^21
+                const uint32_t okm = (uint32_t)((int32_t)(bad - 1u) >> 31);               // ~0 iff bad == 0
+                lat[k] |= okm;
+                el[k] = min(el[k] + 1u, ELAPSED_MAX);
+                const uint32_t dn = ((c.max_steps - 1u - el[k]) >> 30) & (uint32_t)BPG_FLAG_DONE;   // el >= max_steps
+                rb[k] = RBITS_FAIL ^ (okm & (RBITS_FAIL ^ RBITS_OK));
+                fl[k] = (lat[k] & (uint32_t)BPG_FLAG_SUCCESS) | (okm & (uint32_t)BPG_FLAG_STEP_OK) | dn;
             }
-            if (reward_tb) st_u4<NT>(&rrow[(int64_t)t * nvec], make_uint4(rb[0], rb[1], rb[2], rb[3]));
-            if (flags_tb)
-                st_1<NT>(&frow[(int64_t)t * nvec], fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24));
+            if (OUT & OUT_REWARD) st_vec<NT, EPL>(&rrow[(int64_t)t * nvec], rb);
+            if (OUT & OUT_FLAGS) {
+                uint32_t f = fl[0];
+#pragma unroll
+                for (int k = 1; k < EPL; k++) f |= fl[k] << (8 * k);
+                st_1<NT>(&frow[(int64_t)t * nvec], (Fl)f);
+            }
+        };
+        // Steps run in batches of UNROLL.  The masks of batch b+1 are requested BEFORE the rewards /
+        // flags of batch b are stored: vector-memory operations retire in issue order (one vmcnt
+        // counter for loads and stores), so a load issued behind a store cannot be consumed until
+        // that store has been acknowledged by the memory side -- with the loads in front, a batch
+        // waits for one memory latency instead of a store round trip plus a load round trip.
+        const int nb = T / UNROLL;
+        if constexpr (PIPE && SRC == SRC_MASKS) {
+            Vec bufA[UNROLL], bufB[UNROLL];
+            if (nb > 0) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) bufA[u] = mrow[(int64_t)u * nvec];
+            }
+            auto batch = [&](int t0, const Vec *cur, Vec *nxt, bool prefetch) {
+                if (prefetch) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) nxt[u] = mrow[(int64_t)(t0 + UNROLL + u) * nvec];
+                    __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of this batch's stores
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    uint32_t mt[EPL];
+                    unpack<EPL>(cur[u], mt);
+                    one_step(t0 + u, mt);
+                }
+            };
+            // Two batches per trip with ping-pong register buffers (a register copy cur = nxt would
+            // have to wait for the prefetch it copies), and the tail peeled so that every batch in
+            // the loop prefetches unconditionally (a conditional prefetch makes the compiler place
+            // the wait for the merged worst case at the loop head).
+            int b = 0;
+            for (; b + 2 < nb; b += 2) {
+                batch(b * UNROLL, bufA, bufB, true);
+                batch((b + 1) * UNROLL, bufB, bufA, true);
+            }
+            if (nb - b == 2) {
+                batch(b * UNROLL, bufA, bufB, true);
+                batch((b + 1) * UNROLL, bufB, bufA, false);
+            } else if (nb - b == 1) {
+                batch(b * UNROLL, bufA, bufB, false);
+            }
+        } else {
+            for (int b = 0; b < nb; b++) {
+                Vec cur[UNROLL];
+                if (SRC == SRC_MASKS) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) cur[u] = mrow[(int64_t)(b * UNROLL + u) * nvec];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    uint32_t mt[EPL] = {};
+                    if (SRC == SRC_MASKS) unpack<EPL>(cur[u], mt);
+                    one_step(b * UNROLL + u, mt);
+                }
+            }
         }
-        reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
-        reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
-        nsucc += (ee[0] >> 31) + (ee[1] >> 31) + (ee[2] >> 31) + (ee[3] >> 31);
-    }
-    if (count) block_count_add(nsucc, count);
-}
-
-template <int SRC>
-__global__ void __launch_bounds__(1024)
-k_rollout_scalar(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
-                 uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
-                 StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
-                 unsigned long long *__restrict__ zero_next)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint32_t nsucc = 0;
-    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t a = now[i], e = ever[i];
-        if (rc.enabled) reset_core(a, e, i, rc);
-        uint32_t key = 0, valid = 0, forced = 0;
-        if (SRC == SRC_SYNTH) {
-            key = synth_key(s.seed, s.env_base + (uint32_t)i);
-            valid = s.valid_by_n[nobj_of(e)];
-            forced = s.forced_by_n[nobj_of(e)];
+        for (int t = nb * UNROLL; t < T; t++) {          // T % UNROLL leftover steps
+            uint32_t mt[EPL] = {};
+            if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * nvec], mt);
+            one_step(t, mt);
         }
-        for (int t = 0; t < T; t++) {
-            uint32_t m, rb, fl;
-            if (SRC == SRC_MASKS) m = masks[(int64_t)t * n + i];
-            else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
-            step_core(a, e, m, c, rb, fl);
-            if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
-            if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            an[k] = cm[k] | (el[k] << ELAPSED_SHIFT);
+            ee[k] = ev[k] | (lat[k] & SUCC_BIT);
+            nsucc += lat[k] & 1u;
         }
-        now[i] = a; ever[i] = e;
-        nsucc += e >> 31;
+        reinterpret_cast<Vec *>(now)[v] = pack<EPL>(an);
+        reinterpret_cast<Vec *>(ever)[v] = pack<EPL>(ee);
     }
     if (count) block_count_add(nsucc, count);
 }
@@ -737,9 +853,7 @@ k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
     if (lane < nvalid) {
         const int64_t i = base + lane;
         uint32_t a = now[i], e = ever[i], rb, fl;
-        uint32_t key = 0;
-        if (SRC == SRC_SYNTH) key = synth_key(s.seed, s.env_base + (uint32_t)i);
-        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, key, s);
+        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, (uint32_t)i, s);
         step_core(a, e, mk, c, rb, fl);
         now[i] = a; ever[i] = e;
         hist[lane] = make_uint2(a, e);
@@ -1104,15 +1218,12 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
     const bool active = lane < nvalid;
     const int64_t i = base + lane;
-    uint32_t a = 0, e = 0, key = 0, valid = 0, forced = 0;
+    uint32_t a = 0, e = 0;
+    SynthLane sl = {};
     if (active) {
         a = now[i]; e = ever[i];
         if (rc.enabled) reset_core(a, e, i, rc);
-        if (SRC == SRC_SYNTH) {
-            key = synth_key(s.seed, s.env_base + (uint32_t)i);
-            valid = s.valid_by_n[nobj_of(e)];
-            forced = s.forced_by_n[nobj_of(e)];
-        }
+        if (SRC == SRC_SYNTH) sl = synth_lane(s, (uint32_t)i, nobj_of(e));
     }
     uint2 *my = hist + lane * R;
     constexpr int EP_BATCH = 10;        // masks of 10 steps are requested together: one memory
@@ -1135,7 +1246,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                     if (t < te) {
                         uint32_t m, rb, fl;
                         if (SRC == SRC_MASKS) m = mb[u];
-                        else m = synth_mask(key, (a >> ELAPSED_SHIFT) & ELAPSED_MAX, valid, forced);
+                        else m = synth_mask(sl, (a >> ELAPSED_SHIFT) & ELAPSED_MAX);
                         step_core(a, e, m, c, rb, fl);
                         my[t + 1 - r0] = make_uint2(a, e);
                         if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
@@ -1412,6 +1523,46 @@ int fat_grid(int64_t work_items)
     if (g < 1) g = 1;
     if (g > 256) g = 256;        // one 1024-lane block per CU; <= 256 counter atomics per launch
     return (int)g;
+}
+
+// Launch shape of the fused rollout, chosen from the batch size (tools/tune_geometry.hip,
+// profiles/r02_tune_geometry.log; MI355X, T = 50, masks read cold from HBM).  The kernel is a pure
+// stream with T independent requests per lane, so what matters is (a) enough resident waves on
+// every CU to cover the HBM latency and (b), when there are not, that no wave waits for a store
+// round trip before it can consume a load (the pipelined loop).  Measured kernel time per launch:
+//     envs        plain 4/lane x 1024 (round 1)     chosen shape
+//     65 536      49 us                              10.8 us  1/lane, 256-lane blocks, pipelined
+//     131 072     45 us                              15.2 us  2/lane, 256, pipelined
+//     262 144     52 us                              24.8 us  2/lane, 256, pipelined
+//     524 288     58 us                              45.7 us  2/lane, 1024, plain
+//     1 048 576   89 us                              88.3 us  2/lane, 1024, plain
+//     4 194 304   372 us                             355 us   2/lane, 256, pipelined
+// 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
+// 4-per-lane instantiation.  One success-count atomic per block (block_count_add): <= 1024 per launch.
+struct RolloutGeometry { int epl, block, grid; bool pipe; };
+
+RolloutGeometry rollout_geometry(int64_t n, const void *masks, const void *reward, const void *flags)
+{
+    // 2 envs per lane need an even batch and 8-byte aligned mask / reward streams (2-byte flags)
+    const bool ok2 = n % 2 == 0 && ((uintptr_t)masks & 7u) == 0 && ((uintptr_t)reward & 7u) == 0 &&
+                     ((uintptr_t)flags & 1u) == 0;
+    RolloutGeometry g;
+    if (ok2 && n >= 131072) {
+        g.epl = 2;
+        const bool fat = n >= 524288 && n < 4194304;
+        g.block = fat ? 1024 : 256;
+        g.pipe = !fat;
+    } else {
+        g.epl = 1;
+        g.block = 256;
+        g.pipe = true;
+    }
+    const int64_t lanes = n / g.epl;
+    int64_t grid = (lanes + g.block - 1) / g.block;
+    if (grid < 1) grid = 1;
+    const int64_t cap = 256 * (1024 / g.block);           // at most 1024 lanes' worth of blocks per CU
+    g.grid = (int)(grid > cap ? cap : grid);
+    return g;
 }
 
 PairTable pair_table(const bpg_variant_info &info)
@@ -1926,25 +2077,37 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
     int rcode = BPG_OK;
     if (!episode) {
-        const bool vec = (b->n % 4 == 0) && aligned16(a->d_masks) && aligned16(a->d_reward_tb) &&
-                         aligned4(a->d_flags_tb);
-        if (vec) {
-            const dim3 grid(fat_grid(b->n / 4)), block(1024);
-            if (a->d_masks)
-                hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
-            else
-                hipLaunchKernelGGL((k_rollout_vec4<SRC_SYNTH, true>), grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
-        } else {
-            const dim3 grid(fat_grid(b->n)), block(1024);
-            if (a->d_masks)
-                hipLaunchKernelGGL(k_rollout_scalar<SRC_MASKS>, grid, block, 0, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
-            else
-                hipLaunchKernelGGL(k_rollout_scalar<SRC_SYNTH>, grid, block, 0, st, b->now, b->ever, a->d_masks,
-                                   rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext);
+        const RolloutGeometry geo = rollout_geometry(b->n, a->d_masks, a->d_reward_tb, a->d_flags_tb);
+        const dim3 grid(geo.grid), block(geo.block);
+#define BPG_LAUNCH_ROLLOUT(SRC, EPL, OUT, UNR, PIPE)                                                          \
+        do {                                                                                                  \
+            if (a->reset_first)                                                                               \
+                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, true, UNR, PIPE>), grid, block, 0, st, b->now, \
+                                   b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+            else                                                                                              \
+                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, false, UNR, PIPE>), grid, block, 0, st, b->now, \
+                                   b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+        } while (0)
+#define BPG_LAUNCH_ROLLOUT_OUT(SRC, EPL, UNR, PIPE)                                                           \
+        do {                                                                                                  \
+            switch (out) {                                                                                    \
+            case 0: BPG_LAUNCH_ROLLOUT(SRC, EPL, 0, UNR, PIPE); break;                                        \
+            case 1: BPG_LAUNCH_ROLLOUT(SRC, EPL, 1, UNR, PIPE); break;                                        \
+            case 2: BPG_LAUNCH_ROLLOUT(SRC, EPL, 2, UNR, PIPE); break;                                        \
+            default: BPG_LAUNCH_ROLLOUT(SRC, EPL, 3, UNR, PIPE); break;                                       \
+            }                                                                                                 \
+        } while (0)
+        const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
+        if (a->d_masks) {
+            if (geo.epl == 2 && geo.pipe) BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 2, 10, true);
+            else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 2, 5, false);
+            else BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 1, 10, true);
+        } else {                                   // nothing to request: the plain loop
+            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 2, 5, false);
+            else BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 1, 5, false);
         }
+#undef BPG_LAUNCH_ROLLOUT_OUT
+#undef BPG_LAUNCH_ROLLOUT
         rcode = check_launch("k_rollout");
     } else {
         if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||

@@ -447,20 +447,39 @@ uint32_t orc_hash32(uint32_t x)
     return x;
 }
 
+static uint32_t orc_mulfold(uint32_t x, uint32_t k)
+{
+    uint64_t p = (uint64_t)x * (uint64_t)k;
+    return (uint32_t)(p >> 32) ^ (uint32_t)p;
+}
+
+static uint32_t orc_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+/* The spec of the source, stated here independently of the kernels:
+ *   ka = h(seed ^ h(env + 0x9E3779B9)),  kb = h(ka ^ 0x85EBCA6B)            (h = lowbias32)
+ *   u  = ka + (t + 1) * 0x9E3779B9
+ *   a  = fold((u      ^ (u      >> 15)) * 0xD6E8FEB9)     fold(p) = hi32(p) ^ lo32(p) of the
+ *   b  = fold(((u^kb) ^ ((u^kb) >> 15)) * 0xCA5A8263)     64-bit product
+ *   pair j touches iff U_j < 5 for the bit-sliced 5-bit uniform U_j whose "digit is zero" bits are
+ *   A_j = a[j], B_j = b[j], C_j = (a >> 21 | (b >> 21) << 11)[j], D_j = rotl(a,7)[j] & rotl(b,13)[j]:
+ *   A & B & (C | D)  ->  exactly 5/32 per pair.                                              */
 uint32_t orc_synth_mask(uint32_t seed, uint32_t env_id, uint32_t t, int num_objs)
 {
     const uint32_t M21 = (1u << 21) - 1;
-    uint32_t key = orc_hash32(seed ^ orc_hash32(env_id + 0x9E3779B9U));
-    uint32_t w[4];
-    for (uint32_t i = 0; i < 4; i++)
-        w[i] = orc_hash32(key + (4u * t + i) * 0x9E3779B9U + 0x85EBCA6BU);
-    uint32_t f4 = ((w[0] >> 21) | ((w[1] >> 21) << 11)) & M21;
-    /* bit-sliced Bernoulli(5/32): 0.00101b, LSB first */
-    uint32_t acc = f4;
-    acc &= (w[3] & M21);
-    acc |= (w[2] & M21);
-    acc &= (w[1] & M21);
-    acc &= (w[0] & M21);
+    uint32_t ka = orc_hash32(seed ^ orc_hash32(env_id + 0x9E3779B9U));
+    uint32_t kb = orc_hash32(ka ^ 0x85EBCA6BU);
+    uint32_t u = ka + (t + 1u) * 0x9E3779B9U;
+    uint32_t x = u ^ (u >> 15);
+    uint32_t y = (u ^ kb) ^ ((u ^ kb) >> 15);
+    uint32_t a = orc_mulfold(x, 0xD6E8FEB9U), b = orc_mulfold(y, 0xCA5A8263U);
+    uint32_t acc = 0;
+    for (int j = 0; j < 21; j++) {
+        int A = (a >> j) & 1, B = (b >> j) & 1;
+        int Cj = j < 11 ? (a >> (21 + j)) & 1 : (b >> (21 + (j - 11))) & 1;
+        int Dj = ((orc_rotl(a, 7) >> j) & 1) & ((orc_rotl(b, 13) >> j) & 1);
+        if (A && B && (Cj || Dj)) acc |= 1u << j;
+    }
+    acc &= M21;
     uint32_t valid = 0, forced = 0;
     for (int i = 0; i < num_objs; i++)
         for (int j = i + 1; j < num_objs; j++)

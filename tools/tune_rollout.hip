@@ -223,8 +223,8 @@ int main(int argc, char **argv)
              hipLaunchKernelGGL(v_stream<1024>, dim3(nvec / 1024), dim3(1024), 0, 0, masks, reward, flags, B, T));
         {
             ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1; rc0.reset_counter = d_counter;
-            TIME("LIB k_rollout_vec4<masks,nt> 256x1024", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
+            TIME("LIB k_rollout<masks,nt,4> 256x1024", bytes,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
         }
@@ -233,20 +233,20 @@ int main(int argc, char **argv)
             static unsigned long long *cnt = nullptr;
             if (!cnt) { CK(hipMalloc(&cnt, 16)); CK(hipMemset(cnt, 0, 16)); }
             TIME("LIB +count 256 blocks x 1024", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
             TIME("LIB +count 512 blocks x 512", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(512), dim3(512), 0, 0, now, ever, masks,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(512), dim3(512), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
             TIME("LIB +count 1024 blocks x 256", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
             TIME("LIB nocount 1024 blocks x 256", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
             TIME("LIB +count 2048 blocks x 128", bytes,
-                 hipLaunchKernelGGL((k_rollout_vec4<SRC_MASKS, true>), dim3(2048), dim3(128), 0, 0, now, ever, masks,
+                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(2048), dim3(128), 0, 0, now, ever, masks,
                                     reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
         }
         ROLL(1024, 5, false, false, 256);
