@@ -9,11 +9,11 @@ onto this hyphenated directory).  Public surface mirrors the reference:
 """
 from . import _lib
 from .registration import make, register, registry, register_with_gym
-from .envs import (BatchedBlocksEnv, SyntheticContacts, ScriptedContacts, CallableContacts,
+from .envs import (BatchedBlocksEnv, SyntheticContacts, ScriptedContacts, CallableContacts, PhysicsError,
                    compute_reward, mat2euler, geom2objid, default_geom_names)
 from .rollout import RolloutStudent, PGRolloutStudent, configure_dims, discounted_return
 from . import distributed
 
 __all__ = ['make', 'register', 'registry', 'register_with_gym', 'BatchedBlocksEnv', 'RolloutStudent', 'PGRolloutStudent',
-           'SyntheticContacts', 'ScriptedContacts', 'CallableContacts', 'compute_reward',
+           'SyntheticContacts', 'ScriptedContacts', 'CallableContacts', 'PhysicsError', 'compute_reward',
            'configure_dims', 'discounted_return', 'mat2euler', 'geom2objid', 'default_geom_names', 'distributed']

@@ -48,7 +48,7 @@ class PlacementArgs(C.Structure):
                 ('max_obj_range', C.c_double), ('wrong_obj_range', C.c_double),
                 ('test', C.c_int32), ('challenge', C.c_int32),
                 ('d_eu', C.c_void_p), ('n_eu', C.c_int32), ('d_gz', C.c_void_p), ('n_gz', C.c_int32),
-                ('d_gu', C.c_void_p), ('n_gu', C.c_int32)]
+                ('d_gu', C.c_void_p), ('n_gu', C.c_int32), ('d_env_mask', C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/bpgym.h declares
@@ -66,6 +66,8 @@ SIGNATURES = {
     'bpg_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
     'bpg_set_id2obj': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int8), C.c_int]),
     'bpg_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_reset_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_fill_static_obs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_step_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_step_contacts': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
@@ -92,6 +94,7 @@ SIGNATURES = {
     'bpg_success_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_discounted_return': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                         C.c_int, C.c_void_p]),
+    'bpg_nan_flag_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
 }
 
 

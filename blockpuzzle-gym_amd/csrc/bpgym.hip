@@ -344,17 +344,58 @@ __device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_
     }
 }
 
+// The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607), written into a
+// float32 observation buffer by the reset launch itself: obs[0] = num_blocks, the colour one-hot
+// of every present block, zeros for the slots of absent blocks (the 15 physics entries of a
+// present block are left as they are).  obs == NULL: state only.
+struct StaticObs {
+    float *obs;
+    int64_t ld;
+    int32_t enabled, nb_max, dimo;
+    int32_t colors[BPG_MAX_OBJS];
+};
+
+// RESET = false: only the observation entries, from the state as it is (constructor / restore).
+template <bool RESET>
 __global__ void __launch_bounds__(256)
 k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, ResetConst rc,
-        const uint8_t *__restrict__ env_mask)
+        const uint8_t *__restrict__ env_mask, StaticObs so)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (env_mask && env_mask[i] == 0) continue;
-        uint32_t a = now[i], e = ever[i];
-        reset_core(a, e, i, rc);
-        now[i] = a;
-        ever[i] = e;
+    __shared__ uint8_t s_nblocks[256];              // 0xFF = env not touched by this launch
+    const int64_t nblk = (n + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t base = blk * 256, i = base + threadIdx.x;
+        uint8_t nbk = 0xFF;
+        if (i < n && !(env_mask && env_mask[i] == 0)) {
+            uint32_t e = ever[i];
+            if (RESET) {
+                uint32_t a = now[i];
+                reset_core(a, e, i, rc);
+                now[i] = a;
+                ever[i] = e;
+            }
+            nbk = (uint8_t)(nobj_of(e) - 2u);
+        }
+        if (!so.enabled) continue;                   // uniform
+        __syncthreads();                             // previous tile consumed
+        s_nblocks[threadIdx.x] = nbk;
+        __syncthreads();
+        // the block's 256 observation rows, element by element (consecutive lanes -> consecutive
+        // addresses within a row)
+        const int rows = (int)((n - base) < 256 ? (n - base) : 256);
+        const int total = rows * so.dimo;
+        for (int f = threadIdx.x; f < total; f += 256) {
+            const int e = f / so.dimo, k = f - e * so.dimo;
+            const int nb = s_nblocks[e];
+            if (nb == 0xFF) continue;
+            float *o = so.obs + (base + e) * so.ld + k;
+            if (k == 0) { *o = (float)nb; continue; }                      // :580
+            const int j = k - 11;                                          // 1 + ENV_FEATURES
+            if (j < 0) continue;
+            const int slot = j / 19, c = j - slot * 19;
+            if (slot >= nb) *o = 0.0f;                                     // zero padding :606-607
+            else if (c >= 15) *o = (so.colors[slot + 2] == c - 15) ? 1.0f : 0.0f;   // one_hot_color :599
+        }
     }
 }
 
@@ -1021,6 +1062,7 @@ struct PlaceConst {
     int32_t n_eu, n_gz, n_gu;
     uint32_t seed, env_base;
     const uint32_t *reset_counter;
+    const uint8_t *env_mask;      // partial resets: only envs with a non-zero byte are placed
 };
 
 struct Draws {
@@ -1100,6 +1142,7 @@ k_randomize_objects(const uint32_t *__restrict__ ever, int64_t n, PlaceConst pc,
     const double TABLE_X = 1.05 + 0.25, TABLE_Y = 0.40 + 0.35;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (pc.env_mask && pc.env_mask[i] == 0) continue;
         Draws d;
         d.synth = (pc.eu == nullptr);
         d.eu = pc.eu ? pc.eu + i * pc.n_eu : nullptr;
@@ -1300,12 +1343,13 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 // ------------------------------ compute_reward ------------------------------
 // fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
 // staged through LDS with coalesced loads (row stride padded odd).
-constexpr int CR_ROWS = 128;
+constexpr int CR_ROWS_MAX = 128;
 template <bool VEC4>
-__global__ void __launch_bounds__(CR_ROWS)
+__global__ void __launch_bounds__(CR_ROWS_MAX)
 k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
                      uint32_t *__restrict__ out)
 {
+    const int CR_ROWS = blockDim.x;               // 128 rows per block, 64 when the rows are long (LDS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_ag = reinterpret_cast<float *>(smem);
     float *s_g = s_ag + CR_ROWS * ldp;
@@ -1377,66 +1421,96 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
 }
 
 // ------------------------------ discounted return ---------------------------
-// policy_gradient/rollout.py:255-258.  One env per lane; G[t_] starts as r[t_]
-// and adds gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64, products
-// and sums rounded separately, so the result matches the reference's NumPy bit for
-// bit).  The 64 x T tile of a wave is transposed through LDS so G (n, T) is written
-// as contiguous 8-byte-per-lane rows.  gamma**k (C pow, as Python computes it) comes
-// in through the kernel arguments.
+// policy_gradient/rollout.py:255-258.  One env per lane; G[t_] starts as r[t_] and adds
+// gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64, products and sums rounded
+// separately, so the result matches the reference's NumPy bit for bit).  gamma**k (C pow, as
+// Python computes it) comes in through the kernel arguments.
+//
+// The loop nest is the reference's own: OUTER over the step t that brings a new reward, INNER over
+// the returns t_ < t it is added to.  All T accumulators of an env are live, and the t additions of
+// one outer step are independent of each other -- round 1 had the nest the other way round (one
+// accumulator, a serial chain of 2 * (T-1-t_) dependent f64 operations per return), which left a
+// wave waiting out the full latency of every mul and add: 0.46 of HBM peak at 255 VGPRs.  Here
+// the rewards are consumed as they arrive, the live set is T accumulators + the rewards not
+// yet used, and the 64 x T tile that turns the per-lane rows into contiguous 8-byte-per-lane
+// stores is staged through LDS in two halves (13 KB per wave instead of 26 KB).
 constexpr int DR_TMAX_REG = 64;
 struct PowTable { double v[DR_TMAX_REG]; };
 
-// T <= 64 (the registered envs use T = 50): rewards live in registers, fully unrolled
 template <int TT>
 __global__ void __launch_bounds__(64)
 k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable pw, double *__restrict__ G)
 {
-    constexpr int R = TT | 1;
+    constexpr int H = (TT + 1) / 2;           // rows per store pass
+    constexpr int R = H | 1;                  // odd row stride: conflict-free ds_write_b64
     __shared__ double tile[64 * R];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    double acc[TT];
     if (lane < nvalid) {
-        double r[TT];
+        const float *p = reward_tb + base + lane;
+        float rf[TT];
 #pragma unroll
-        for (int t = 0; t < TT; t++) r[t] = (double)reward_tb[(int64_t)t * n + base + lane];
+        for (int t = 0; t < TT; t++) rf[t] = p[(int64_t)t * n];
 #pragma unroll
-        for (int t_ = 0; t_ < TT; t_++) {
-            double acc = r[t_];
+        for (int t = 0; t < TT; t++) {
+            const double rt = (double)rf[t];
+            acc[t] = rt;
 #pragma unroll
-            for (int t = t_ + 1; t < TT; t++) acc = acc + pw.v[t - t_] * r[t];
-            tile[lane * R + t_] = acc;
+            for (int t_ = 0; t_ < t; t_++) acc[t_] = acc[t_] + pw.v[t - t_] * rt;
         }
     }
-    __syncthreads();
     double *o = G + base * (int64_t)TT;
-    const int total = nvalid * TT;
-    int e = 0, rem = lane;
-    while (rem >= TT) { rem -= TT; e++; }
-    for (int f = lane; f < total; f += 64) {
-        o[f] = tile[e * R + rem];
-        rem += 64;
-        while (rem >= TT) { rem -= TT; e++; }
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int r0 = pass * H, cnt = (TT - r0) < H ? (TT - r0) : H;
+        if (pass) __syncthreads();                       // first half streamed out
+        if (lane < nvalid) {
+#pragma unroll
+            for (int j = 0; j < H; j++)
+                if (r0 + j < TT) tile[lane * R + j] = acc[r0 + j];
+        }
+        __syncthreads();
+        const int total = nvalid * cnt;
+        int e = 0, rem = lane;
+        while (rem >= cnt) { rem -= cnt; e++; }
+        for (int f = lane; f < total; f += 64) {
+            o[(int64_t)e * TT + r0 + rem] = tile[e * R + rem];
+            rem += 64;
+            while (rem >= cnt) { rem -= cnt; e++; }
+        }
     }
 }
 
-// generic T: rewards staged in LDS
+// any T up to DR_TMAX: returns accumulate in the LDS tile (row of the lane), four at a time so
+// that independent chains overlap; the gamma**k table travels in the kernel arguments as well
+// (no allocation, no copy, nothing to wait for: the call only enqueues a launch).
+constexpr int DR_TMAX = 319;                  // 64 x (T|1) x 8 B <= 160 KB of LDS
+struct PowTableBig { double v[DR_TMAX + 1]; };
+
 __global__ void __launch_bounds__(64)
-k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R,
-                    const double *__restrict__ pw, double *__restrict__ G)
+k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R, PowTableBig pw,
+                    double *__restrict__ G)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *tile = reinterpret_cast<double *>(smem);   // [64][R] : first r, then G
+    double *tile = reinterpret_cast<double *>(smem);   // [64][R]
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
     if (lane < nvalid) {
         double *my = tile + lane * R;
-        for (int t = 0; t < T; t++) my[t] = (double)reward_tb[(int64_t)t * n + base + lane];
-        for (int t_ = 0; t_ < T; t_++) {
-            double acc = my[t_];
-            for (int t = t_ + 1; t < T; t++) acc = acc + pw[t - t_] * my[t];
-            my[t_] = acc;          // r[t_] is not needed by later (larger t_) rows
+        const float *p = reward_tb + base + lane;
+        for (int t = 0; t < T; t++) {
+            const double rt = (double)p[(int64_t)t * n];
+            my[t] = rt;
+            int t_ = 0;
+            for (; t_ + 4 <= t; t_ += 4) {
+                const double a0 = my[t_] + pw.v[t - t_] * rt, a1 = my[t_ + 1] + pw.v[t - t_ - 1] * rt;
+                const double a2 = my[t_ + 2] + pw.v[t - t_ - 2] * rt, a3 = my[t_ + 3] + pw.v[t - t_ - 3] * rt;
+                my[t_] = a0; my[t_ + 1] = a1; my[t_ + 2] = a2; my[t_ + 3] = a3;
+            }
+            for (; t_ < t; t_++) my[t_] = my[t_] + pw.v[t - t_] * rt;
         }
     }
     __syncthreads();
@@ -1449,6 +1523,22 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
         rem += 64;
         while (rem >= T) { rem -= T; e++; }
     }
+}
+
+// np.isnan(o_new).any() of the rollout worker (rollout.py:139-142) without a host round trip:
+// ORs 1 into *flag when any of rows x cols float32 values (row stride ld) is a NaN.
+__global__ void __launch_bounds__(256)
+k_nan_flag(const float *__restrict__ x, int64_t rows, int cols, int64_t ld, uint32_t *__restrict__ flag)
+{
+    const int64_t total = rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += stride) {
+        const int64_t r = f / cols;
+        const float v = x[r * ld + (f - r * cols)];
+        bad |= (v != v);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1713,9 +1803,13 @@ int64_t bpg_num_envs(const bpg_batch *b) { return b ? b->n : 0; }
 int bpg_seed(bpg_batch *b, uint64_t seed)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
-    b->seed = seed;
     DeviceGuard guard(b->device);
-    HIP_TRY(hipMemset(b->d_reset_counter, 0, 2 * sizeof(uint32_t)));   // synchronous: seeding restarts the streams
+    // Synchronous by contract: launches in flight on ANY stream (torch side streams do not order
+    // against the null stream) still read the old key and stream indices.
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(b->d_reset_counter, 0, 2 * sizeof(uint32_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    b->seed = seed;
     return BPG_OK;
 }
 
@@ -1731,20 +1825,58 @@ int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
         tab[i] = id2obj[i] < 0 ? (int8_t)-1 : id2obj[i];
     }
     DeviceGuard guard(b->device);
+    HIP_TRY(hipDeviceSynchronize());      // synchronous by contract: no launch may still be reading the table
     HIP_TRY(hipMemcpy(b->d_id2obj + model_idx * BPG_MAX_GEOMS, tab, BPG_MAX_GEOMS, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
     b->ngeom[model_idx] = ngeom;
     return BPG_OK;
 }
 
-int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream)
+static StaticObs static_obs(const bpg_batch *b, float *d_obs, int64_t ld)
+{
+    StaticObs so;
+    std::memset(&so, 0, sizeof(so));
+    so.enabled = (d_obs && b->info.is_variation) ? 1 : 0;     // only Variation has physics-free entries
+    so.obs = d_obs;
+    so.ld = ld;
+    so.nb_max = b->info.num_objs - 2;
+    so.dimo = b->info.dimo;
+    for (int i = 0; i < BPG_MAX_OBJS; i++) so.colors[i] = b->info.obj_colors[i];
+    return so;
+}
+
+int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, float *d_obs, int64_t ld,
+                  void *stream)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (d_obs && ld < b->info.dimo) return fail(BPG_ERR_ARG, "ld must be >= dimo");
+    if (!aligned4(d_obs)) return fail(BPG_ERR_ARG, "d_obs must be 4-byte aligned");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_reset, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->now, b->ever,
-                       b->n, reset_const(b, 1, d_num_grey), d_env_mask);
+    const int64_t nblk = (b->n + 255) / 256;
+    hipLaunchKernelGGL(k_reset<true>, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       b->now, b->ever, b->n, reset_const(b, 1, d_num_grey), d_env_mask, static_obs(b, d_obs, ld));
     if (b->info.is_variation && !d_num_grey)     // only generator-drawn resets consume a stream index
         hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter);
     return check_launch("k_reset");
+}
+
+int bpg_fill_static_obs(bpg_batch *b, float *d_obs, int64_t ld, void *stream)
+{
+    if (!b || !d_obs) return fail(BPG_ERR_ARG, "NULL argument");
+    if (ld < b->info.dimo) return fail(BPG_ERR_ARG, "ld must be >= dimo");
+    if (!aligned4(d_obs)) return fail(BPG_ERR_ARG, "d_obs must be 4-byte aligned");
+    if (!b->info.is_variation) return BPG_OK;
+    DeviceGuard guard(b->device);
+    const int64_t nblk = (b->n + 255) / 256;
+    hipLaunchKernelGGL(k_reset<false>, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       b->now, b->ever, b->n, reset_const(b, 0, nullptr), (const uint8_t *)nullptr,
+                       static_obs(b, d_obs, ld));
+    return check_launch("k_reset");
+}
+
+int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream)
+{
+    return bpg_reset_obs(b, d_num_grey, d_env_mask, nullptr, 0, stream);
 }
 
 static int launch_step(bpg_batch *b, int src, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
@@ -2001,6 +2133,7 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
     pc.gz = a->d_gz; pc.gu = a->d_gu;
     pc.n_eu = a->n_eu; pc.n_gz = a->n_gz; pc.n_gu = a->n_gu;
     pc.seed = s.seed; pc.env_base = s.env_base; pc.reset_counter = b->d_reset_counter + 1;
+    pc.env_mask = a->d_env_mask;
     hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        b->n, pc, d_xy, d_status);
     if (!explicit_draws)
@@ -2031,6 +2164,8 @@ int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int l
     if (n == 0) return BPG_OK;
     DeviceGuard guard(device_id);
     const int ldp = len | 1;
+    // two row tiles of CR_ROWS x ldp floats in LDS: 128 rows up to 159 floats per row, 64 rows beyond
+    const int CR_ROWS = ((size_t)2 * CR_ROWS_MAX * ldp * sizeof(float) <= 160 * 1024) ? CR_ROWS_MAX : 64;
     const size_t lds = (size_t)2 * CR_ROWS * ldp * sizeof(float);
     const bool vec = (len % 4 == 0) && (len / 4 <= CR_ROWS) && aligned16(d_ag) && aligned16(d_g);
     const void *fn = vec ? reinterpret_cast<const void *>(k_compute_reward_f32<true>)
@@ -2168,18 +2303,14 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
                           void *stream)
 {
     if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
-    if (n < 1 || T < 1 || T > 1024) return fail(BPG_ERR_ARG, "bad n/T");
+    if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
     DeviceGuard guard(device_id);
-    // gamma ** k exactly as the reference's Python float pow (C pow)
-    std::vector<double> pw((size_t)T);
-    for (int k = 0; k < T; k++) pw[(size_t)k] = std::pow(gamma, (double)k);
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     if (T == 50 || T == 25 || T == 10) {
-        // register-resident fast path for the horizons in use (T = max_episode_steps = 50);
-        // fully asynchronous: the table travels in the kernel arguments
+        // register-resident fast path for the horizons in use (T = max_episode_steps = 50)
         PowTable tab;
         std::memset(&tab, 0, sizeof(tab));
-        for (int k = 0; k < T; k++) tab.v[k] = pw[(size_t)k];
+        for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
         if (T == 50)
             hipLaunchKernelGGL(k_discounted_return_reg<50>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
         else if (T == 25)
@@ -2188,31 +2319,28 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
             hipLaunchKernelGGL(k_discounted_return_reg<10>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
         return check_launch("k_discounted_return_reg");
     }
-    double *d_pw = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_pw), sizeof(double) * (size_t)T));
-    hipError_t ce = hipMemcpyAsync(d_pw, pw.data(), sizeof(double) * (size_t)T, hipMemcpyHostToDevice,
-                                   (hipStream_t)stream);
-    if (ce == hipSuccess) ce = hipStreamSynchronize((hipStream_t)stream);   // pw is a host temporary
-    if (ce != hipSuccess) {
-        (void)hipFree(d_pw);
-        return fail(BPG_ERR_HIP, std::string("pow table upload: ") + hipGetErrorString(ce));
-    }
+    PowTableBig big;
+    std::memset(&big, 0, sizeof(big));
+    for (int k = 0; k < T; k++) big.v[k] = std::pow(gamma, (double)k);
     const int R = T | 1;
     const size_t lds = (size_t)64 * R * sizeof(double);
-    int rc = BPG_OK;
-    if (lds > 160 * 1024) rc = fail(BPG_ERR_ARG, "T too large for the LDS tile");
-    if (rc == BPG_OK && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) rc = fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    }
-    if (rc == BPG_OK) {
-        hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, T, R, d_pw,
-                           d_G);
-        rc = check_launch("k_discounted_return");
-    }
-    (void)hipFree(d_pw);      // synchronises with the kernel that reads the table
-    return rc;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, T, R, big, d_G);
+    return check_launch("k_discounted_return");
+}
+
+int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint32_t *d_flag, int device_id,
+                     void *stream)
+{
+    if (!d_x || !d_flag) return fail(BPG_ERR_ARG, "NULL argument");
+    if (rows < 0 || cols < 1 || ld < cols) return fail(BPG_ERR_ARG, "bad rows / cols / ld");
+    if (rows == 0) return BPG_OK;
+    DeviceGuard guard(device_id);
+    hipLaunchKernelGGL(k_nan_flag, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows, cols,
+                       ld, d_flag);
+    return check_launch("k_nan_flag");
 }
 
 }  // extern "C"

@@ -108,6 +108,12 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class PhysicsError(RuntimeError):
+    """What a physics backend raises when its simulation blows up: the stand-in for
+    mujoco_py.MujocoException, which the rollout worker answers by starting the rollout over
+    (rollout.py:136-137)."""
+
+
 class SyntheticContacts:
     """Build-defined physics stand-in (no reference counterpart): contacts are a
     counter-based pseudo-random function of (seed, global env id, step) evaluated
@@ -127,8 +133,9 @@ class ScriptedContacts:
         self.masks, self.pairs, self.ncon = masks, pairs, ncon
         self.t = 0
 
-    def on_reset(self, env):
-        self.t = 0                      # a full reset starts the script over
+    def on_reset(self, env, env_mask=None, **kw):
+        if env_mask is None:
+            self.t = 0                  # a full reset starts the script over
 
     def next(self, env, actions):
         t = self.t
@@ -139,11 +146,31 @@ class ScriptedContacts:
 
 
 class CallableContacts:
-    """Wraps a user physics backend: fn(env, clipped_actions) -> uint32 masks (B,)
-    or (int16 pairs (B,maxcon,2), int32 ncon (B,))."""
+    """Wraps a user physics backend.
 
-    def __init__(self, fn):
+    fn(env, actions) -> uint32 masks (B,)  or  (int16 pairs (B,maxcon,2), int32 ncon (B,)).
+        `actions` are the policy's (B, 4) actions as given; `env.set_action_vector(actions)` is
+        robot_env.py:58's clip + _set_action in one kernel and returns the control vector.
+    on_reset(env, xy, status, env_mask, test): optional; called by reset() / set_test() with the
+        freshly sampled cube positions `xy` (B, nb, 2) float64 -- _randomize_objects of the
+        reference's _reset_sim (fetch_env.py:247-255) and set_test (:365-368, :443-446) -- the
+        sampler's per-env `status` (0 = ok), the partial-reset mask (None = all envs) and whether
+        the maximum-difficulty ranges were used.  Rows of `xy` outside the mask keep their previous
+        positions.
+    writes_observation: the backend rewrites every entry of `env.observation` on each step
+        (env.assemble_observation does); the rollout workers then point `env.observation` at the
+        episode's time slot so the write lands there directly, and watch it for NaNs
+        (rollout.py:139-142)."""
+
+    def __init__(self, fn, on_reset=None, writes_observation=False):
         self.fn = fn
+        self._on_reset = on_reset
+        self.wants_positions = on_reset is not None
+        self.writes_observation = bool(writes_observation)
+
+    def on_reset(self, env, xy=None, status=None, env_mask=None, test=False):
+        if self._on_reset is not None:
+            self._on_reset(env, xy, status, env_mask, test)
 
     def next(self, env, actions):
         out = self.fn(env, actions)
@@ -201,6 +228,10 @@ class BatchedBlocksEnv:
         B, dev = self.num_envs, self.device
         self._g = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
         self.observation = torch.zeros(B, self.dimo, dtype=torch.float32, device=dev)
+        # cube xy of the current episode (_randomize_objects; filled when a contact source asks for it)
+        self.block_xy = torch.full((B, self.num_objs - 2, 2), float('nan'), dtype=torch.float64, device=dev)
+        self.placement_status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.grip_xy = (1.3419, 0.7491)            # initial_gripper_xpos[:2] of the settled Fetch arm (physics)
         _lib.check(L.bpg_get_desired_goal_f32(self._h, _ptr(self._g), self.dimg, _stream(dev)))
         now, ever = C.c_void_p(), C.c_void_p()
         _lib.check(L.bpg_state_ptrs(self._h, C.byref(now), C.byref(ever)))
@@ -293,12 +324,25 @@ class BatchedBlocksEnv:
         self.difficulty += 1
         return False
 
-    def set_test(self):
+    def set_test(self, variates=None, env_mask=None):
         if not self.info.set_test_supported:
             raise NotImplementedError()             # fetch_env.py:100-101
-        # fetch_env.py:365-368 / :443-446 re-randomise the cubes at max range (physics side,
-        # outside the boundary) and return _get_obs(); Variation :641-644 only returns it.
+        # fetch_env.py:365-368 / :443-446 re-place the cubes at the maximum ranges and return
+        # _get_obs(); Variation :641-644 only returns it (its re-placement is commented out).
+        if not self.info.is_variation:
+            self._place(test=True, env_mask=self._to_dev(env_mask, torch.uint8), variates=variates)
         return self._get_obs()
+
+    def _place(self, test, env_mask, variates=None):
+        """_randomize_objects for the envs being reset, handed to the contact source's on_reset
+        (the physics backend sets the cubes' qpos[:2] from it).  Skipped when nothing consumes it."""
+        src = self.contact_source
+        if getattr(src, 'wants_positions', False):
+            self.randomize_objects(test=test, grip_xy=self.grip_xy, variates=variates, out=self.block_xy,
+                                   status=self.placement_status, env_mask=env_mask)
+            src.on_reset(self, xy=self.block_xy, status=self.placement_status, env_mask=env_mask, test=test)
+        elif hasattr(src, 'on_reset'):
+            src.on_reset(self, env_mask=env_mask, test=test)
 
     # ------------------------------------------------------------ id2obj
     def set_geom_names(self, models):
@@ -328,24 +372,30 @@ class BatchedBlocksEnv:
             x = torch.as_tensor(np.ascontiguousarray(x))
         return x.to(device=self.device, dtype=dtype).contiguous()
 
-    def reset(self, num_grey=None, env_mask=None):
+    def reset(self, num_grey=None, env_mask=None, variates=None):
         """robot_env.py:71-82.  num_grey: optional explicit (B,) draws for Variation's
-        np_random.randint(3) (fetch_env.py:647); env_mask: optional (B,) partial reset."""
+        np_random.randint(3) (fetch_env.py:647); env_mask: optional (B,) partial reset (the
+        reference's reset_rollout(i)); variates: optional explicit placement draws (see
+        randomize_objects).  One launch resets the state and refills the physics-free observation
+        entries; when the contact source consumes positions (`wants_positions`) the cubes are
+        re-placed on the same stream and handed to its on_reset, as _reset_sim does
+        (fetch_env.py:247-255 -> _randomize_objects)."""
         ng = self._to_dev(num_grey, torch.int32)
         em = self._to_dev(env_mask, torch.uint8)
-        _lib.check(self._L.bpg_reset(self._h, _ptr(ng), _ptr(em), _stream(self.device)))
-        if self.info.is_variation:
-            self._fill_static_observation()
-        if env_mask is None and hasattr(self.contact_source, 'on_reset'):
-            self.contact_source.on_reset(self)
+        obs = self.observation
+        _lib.check(self._L.bpg_reset_obs(self._h, _ptr(ng), _ptr(em), _ptr(obs), int(obs.stride(0)),
+                                         _stream(self.device)))
+        self._place(test=False, env_mask=em, variates=variates)
         return self._get_obs()
 
-    def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None):
+    def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None):
         """Launches one env step; returns (reward, flags, achieved_goal) device tensors."""
         a = self._to_dev(action, torch.float32)
         if a is not None:
             a = a.reshape(self.num_envs, self.dimu)
-            a = torch.clamp(a, -1.0, 1.0)            # robot_env.py:58
+        # robot_env.py:58's clip happens where the action is consumed: k_set_action (set_action_vector)
+        # clips in the kernel that builds the physics control vector; nothing behind the contacts-in
+        # boundary reads the action itself
         self.last_action = a
         if contact_masks is None and contacts is None:
             nxt = self.contact_source.next(self, a)
@@ -357,7 +407,11 @@ class BatchedBlocksEnv:
         st = _stream(self.device)
         # fresh output tensors every call (the reference returns copies, fetch_env.py:225-227);
         # the kernels write straight into them, so this costs an allocation, not a copy
-        reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        if reward_out is None:
+            reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        else:
+            reward = reward_out
+            assert reward.shape == (self.num_envs,) and reward.dtype == torch.float32 and reward.is_contiguous()
         flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         if ag_out is None:
             ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
@@ -425,22 +479,10 @@ class BatchedBlocksEnv:
 
     def _fill_static_observation(self):
         """The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607):
-        obs[0] = num_blocks, colour one-hot of every present block, zero padding.
-        Pure device-tensor ops (capturable into a hipGraph)."""
-        if not self.info.is_variation:
-            return
-        if not hasattr(self, '_color_onehot'):
-            oh = torch.zeros(self.max_num_blocks, COLOR_FEATURES)
-            for i in range(self.max_num_blocks):
-                oh[i, self.info.obj_colors[i + 2]] = 1.0
-            self._color_onehot = oh.to(self.device)
-            self._blk_idx = torch.arange(self.max_num_blocks, device=self.device)
-        nblocks = ((self.state_ever >> 21) & 7) - 2
-        self.observation[:, 0] = nblocks.to(torch.float32)
-        blk = self.observation[:, 1 + ENV_FEATURES:].view(self.num_envs, self.max_num_blocks, BLOCK_FEATURES)
-        present = (self._blk_idx[None, :] < nblocks[:, None]).to(torch.float32)
-        blk *= present[:, :, None]
-        blk[:, :, BLOCK_BASE_FEATURES:] = self._color_onehot[None] * present[:, :, None]
+        obs[0] = num_blocks, colour one-hot of every present block, zero padding -- from the
+        state as it stands (reset() does the same inside its own launch)."""
+        obs = self.observation
+        _lib.check(self._L.bpg_fill_static_obs(self._h, _ptr(obs), int(obs.stride(0)), _stream(self.device)))
 
     def set_action_vector(self, action):
         """robot_env.py:58 + fetch_env.py:170-185: (B,4) actions -> the (B,9) float64 vector
@@ -476,22 +518,28 @@ class BatchedBlocksEnv:
         _lib.check(fn(self._h, C.byref(ph), _ptr(out), int(out.stride(0)), _stream(self.device)))
         return out
 
-    def randomize_objects(self, test=False, grip_xy=(1.3419, 0.7491), variates=None, out=None):
+    def randomize_objects(self, test=False, grip_xy=(1.3419, 0.7491), variates=None, out=None, status=None,
+                          env_mask=None):
         """_randomize_objects for the whole batch (fetch_env.py:328-336, 370-399, 448-517,
         697-764, 777-787): (B, nb, 2) float64 cube positions for the physics backend, using the
         env's current curriculum state (obj_range, ...).  grip_xy = initial_gripper_xpos[:2]
         (a physics output; the default is the settled Fetch gripper position).  variates:
         optional dict eu (B,n_eu), gz (B,n_gz), gu (B,n_gu) of explicit standard draws in the
-        reference's order; default = the counter-based generator.  Returns (xy, status)."""
+        reference's order; default = the counter-based generator.  env_mask: optional (B,) uint8,
+        only those envs are placed (rows of `out` elsewhere keep their values).
+        Returns (xy, status)."""
         nb = self.num_objs - 2
         if out is None:
             out = torch.full((self.num_envs, nb, 2), float('nan'), dtype=torch.float64, device=self.device)
-        status = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        em = self._to_dev(env_mask, torch.uint8)
         a = _lib.PlacementArgs(grip_x=float(grip_xy[0]), grip_y=float(grip_xy[1]), obj_range=float(self.obj_range),
                                max_obj_range=float(getattr(self, 'max_obj_range', 0.0)),
                                wrong_obj_range=float(getattr(self, 'wrong_obj_range', 0.0)),
-                               test=int(bool(test)), challenge=int(bool(getattr(self, 'challenge', False))))
-        keep = []
+                               test=int(bool(test)), challenge=int(bool(getattr(self, 'challenge', False))),
+                               d_env_mask=None if em is None else em.data_ptr())
+        keep = [em]
         if variates is not None:
             for k in ('eu', 'gz', 'gu'):
                 t = self._to_dev(variates[k], torch.float64)
@@ -529,6 +577,7 @@ class BatchedBlocksEnv:
         self.state_ever.copy_(sd['ever'])
         if 'counters' in sd:
             self.state_counters.copy_(sd['counters'])
+        self._fill_static_observation()
 
 
 def mat2euler(mat, device=None):

@@ -12,13 +12,16 @@ batch-major float32 episode arrays the reference returns (rollout.py:155-172).
 """
 import ctypes as C
 import pickle
+import warnings
 from collections import deque
 
 import numpy as np
 import torch
 
 from . import _lib
-from .envs import _ptr, _stream
+from .envs import PhysicsError, _ptr, _stream
+
+MAX_ROLLOUT_RESTARTS = 10      # the reference retries without bound (rollout.py:136-142)
 
 
 def configure_dims(env):
@@ -81,6 +84,7 @@ class RolloutStudent:
         self.success_history = deque(maxlen=history_len)
         self.Q_history = deque(maxlen=history_len)
         self.n_episodes = 0
+        self._watch_o, self._nan_flag = False, None
         f32 = dict(dtype=torch.float32, device=self.device)
         self.g = torch.empty((B, dims['g']), **f32)
         self.initial_o = torch.empty((B, dims['o']), **f32)
@@ -102,7 +106,7 @@ class RolloutStudent:
         mask[i] = 1
         obs = self.env.reset(env_mask=mask)
         if test:
-            obs = self.env.unwrapped.set_test()
+            obs = self.env.unwrapped.set_test(env_mask=mask)
         self.initial_o[i] = obs['observation'][i]
         self.initial_ag[i] = obs['achieved_goal'][i]
         self.g[i] = obs['desired_goal'][i]
@@ -153,9 +157,71 @@ class RolloutStudent:
 
     def generate_rollouts(self, render=False, test=False, compute_Attention=False, num_grey=None):
         """rollout.py:75-172 with the policy in the loop: one HIP step launch
-        for the whole batch per time step.  Returns the batch-major episode."""
-        ep, Qs = self._rollout_body(test, num_grey, compute_Attention)
-        return self._finish(ep, Qs)
+        for the whole batch per time step.  Returns the batch-major episode.
+        A backend failure (PhysicsError, the stand-in for MujocoException) restarts the rollout
+        (rollout.py:136-137); a NaN in the observations a backend wrote is detected on the device,
+        and the rollout is thrown away, everything reset and generated again (rollout.py:139-142)."""
+        for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
+            try:
+                ep, Qs = self._rollout_body(test, num_grey, compute_Attention)
+            except PhysicsError as e:
+                self._log('warning', 'physics backend failed during rollout generation (%s). Trying again...' % e)
+                continue
+            if self._nan_caught():
+                self._log('warning', 'NaN caught during rollout generation. Trying again...')
+                self.reset_all_rollouts(test, num_grey=num_grey)
+                continue
+            return self._finish(ep, Qs)
+        raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
+
+    def _log(self, level, msg):
+        fn = getattr(self.logger, level, None) or getattr(self.logger, 'info', None)
+        if fn is not None:
+            fn(msg)
+        else:
+            warnings.warn(msg)
+
+    def _nan_caught(self):
+        """One read of the device-side flag per rollout (the step loop never synchronises)."""
+        flag = getattr(self, '_nan_flag', None)
+        return flag is not None and self._watch_o and bool(flag.item())
+
+    def _episode_o(self, ep):
+        """Where the T+1 observations of the episode live.  A backend that rewrites the whole
+        observation every step gets the episode's time slot as its target (env.observation points
+        at it during the step); otherwise nothing changes the observation between resets and the
+        episode's `o` is the initial observation, expanded (stride 0) -- rollout.py:144 appends T+1
+        copies of an array nobody wrote to."""
+        B, T = self.rollout_batch_size, self.T
+        self._watch_o = bool(getattr(self.env.contact_source, 'writes_observation', False))
+        if self._watch_o:
+            if getattr(self, '_nan_flag', None) is None:
+                self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._nan_flag.zero_()
+            o = torch.empty((T + 1, B, self.dims['o']), dtype=torch.float32, device=self.device)
+            o[0] = self.initial_o
+            return o
+        return self.initial_o.clone()[None].expand(T + 1, B, self.dims['o'])
+
+    def _step_into(self, u, ep, t, reward_out=None):
+        """One env step that writes obs['achieved_goal'] / info['is_success'] (and, through the
+        backend, obs['observation']; optionally the step reward) straight into time slot t+1 / t
+        of the episode."""
+        env = self.env
+        if self._watch_o:
+            own, env.observation = env.observation, ep['o'][t + 1]
+            try:
+                r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
+                                         reward_out=reward_out)
+            finally:
+                env.observation = own
+            slot = ep['o'][t + 1]
+            _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
+                                                   _ptr(self._nan_flag), self.device.index, _stream(self.device)))
+        else:
+            r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
+                                     reward_out=reward_out)
+        return r
 
     def _rollout_body(self, test, num_grey, compute_Attention=False):
         env, B, T = self.env, self.rollout_batch_size, self.T
@@ -163,8 +229,8 @@ class RolloutStudent:
         # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
         # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
         # the next achieved_goal straight into slot t+1
-        ep = self._alloc_episode(time_major=True, g=False)
-        ep['o'][0] = self.initial_o
+        ep = self._alloc_episode(time_major=True, g=False, o=False)
+        ep['o'] = self._episode_o(ep)
         ep['ag'][0] = self.initial_ag
         Qs = []
         for t in range(T):
@@ -182,11 +248,10 @@ class RolloutStudent:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
             ep['u'][t] = u
-            # reward ignored: recomputed for HER (rollout.py:123-125); the step kernel writes the
-            # next achieved_goal and the float is_success column straight into their slots
-            env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t])
-            ep['o'][t + 1] = env.observation
-        self.initial_o.copy_(ep['o'][T])
+            # reward ignored: recomputed for HER (rollout.py:123-125)
+            self._step_into(u, ep, t)
+        if self._watch_o:
+            self.initial_o.copy_(ep['o'][T])                       # rollout.py:153 `self.initial_o[:] = o`
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
         # the goal is constant over the episode (rollout.py:151 appends the same array T times)
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
@@ -227,6 +292,9 @@ class RolloutStudent:
         if explicit:
             self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
         self._graph.replay()
+        if self._nan_caught():
+            raise FloatingPointError('NaN in the observations of a graph-replayed rollout (the replay cannot be '
+                                     'restarted from the host: use generate_rollouts)')
         return self._finish(dict(self._graph_ep), self._graph_Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
@@ -315,13 +383,25 @@ class PGRolloutStudent(RolloutStudent):
         self.time += 1.0
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None):
+        """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference
+        (`assert(False)`, :237-241); NaN observations restart the rollout (:243-246)."""
+        for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
+            ep = self._pg_body(test, exploit, num_grey)
+            if self._nan_caught():
+                self._log('info', 'NaN caught during rollout generation. Trying again...')
+                self.reset_all_rollouts(test, num_grey=num_grey)
+                continue
+            return self._finish(ep)
+        raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
+
+    def _pg_body(self, test, exploit, num_grey):
         env, B, T = self.env, self.rollout_batch_size, self.T
         self.reset_all_rollouts(test, num_grey=num_grey)
         beta = self.beta() if self.expert is not None else 0
-        ep = self._alloc_episode(time_major=True, g=False)
+        ep = self._alloc_episode(time_major=True, g=False, o=False)
+        ep['o'] = self._episode_o(ep)
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device)
-        ep['o'][0] = self.initial_o
         ep['ag'][0] = self.initial_ag
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]
@@ -338,11 +418,10 @@ class PGRolloutStudent(RolloutStudent):
             ep['u'][t] = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
             if sigma is not None:
                 ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
-            r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t])
-            reward[t] = r
-            ep['o'][t + 1] = env.observation
-        self.initial_o.copy_(ep['o'][T])
+            self._step_into(u, ep, t, reward_out=reward[t])
+        if self._watch_o:
+            self.initial_o.copy_(ep['o'][T])
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         ep['G'] = discounted_return(reward, self.gamma)
-        return self._finish(ep)
+        return ep

@@ -109,12 +109,14 @@ int bpg_destroy(bpg_batch *b);
 int64_t bpg_num_envs(const bpg_batch *b);
 
 /* RobotEnv.seed (robot_env.py:53-55) / RolloutStudent.seed (rollout.py:206-210):
- * re-keys the counter-based generator (synthetic contacts, num_grey draw). */
+ * re-keys the counter-based generator (synthetic contacts, num_grey draw) and restarts its
+ * stream indices.  SYNCHRONOUS (device-wide): work already enqueued on any stream keeps the old key. */
 int bpg_seed(bpg_batch *b, uint64_t seed);
 
 /* id2obj table of one model (fetch_env.py:284, Variation :651): host array of
  * `ngeom` object ids (-1 = None).  model_idx 0 except Variation (0..2 =
- * 2/3/4-block models, chosen per episode by num_objs-4). */
+ * 2/3/4-block models, chosen per episode by num_objs-4).  SYNCHRONOUS (device-wide), like
+ * bpg_seed: a setup call, not part of the step path. */
 int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom);
 
 /* RobotEnv.reset (robot_env.py:71-82) + _reset_sim (fetch_env.py:247-255;
@@ -124,6 +126,15 @@ int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
  * d_num_grey[b] (explicit variate for np_random.randint(3), :647) or, when
  * NULL, from the handle's counter-based generator. */
 int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream);
+/* The same reset, and in the SAME launch the part of the observation the reference fills without
+ * physics (Variation _get_obs, fetch_env.py:579-607: obs[0] = num_blocks, colour one-hot of every
+ * present block, zeros in the slots of absent blocks) written into d_obs (n_envs rows of dimo
+ * float32, row stride ld) for the envs being reset.  No-op on d_obs for the other variants. */
+int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, float *d_obs,
+                  int64_t ld, void *stream);
+/* Only those observation entries, from the state as it stands (after construction or a restored
+ * checkpoint), for every env. */
+int bpg_fill_static_obs(bpg_batch *b, float *d_obs, int64_t ld, void *stream);
 
 /* RobotEnv.step (robot_env.py:57-69) after the physics: _step_callback
  * (fetch_env.py:154-167) + _is_success latch (:275-281) + compute_reward
@@ -216,6 +227,8 @@ typedef struct {
     const double *d_eu; int32_t n_eu;
     const double *d_gz; int32_t n_gz;
     const double *d_gu; int32_t n_gu;
+    const uint8_t *d_env_mask;   /* partial resets (reset_rollout(i), rollout.py:47-58): only envs with a
+                                    non-zero byte are placed, the other rows of d_xy stay; NULL = all */
 } bpg_placement_args;
 int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_xy, int32_t *d_status,
                           void *stream);
@@ -228,7 +241,7 @@ int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);
 int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters);
 
 /* BlocksEnv.compute_reward (fetch_env.py:135-143), stateless and vectorised as
- * HER calls it (config.py:110-111): n rows of `len` floats each. */
+ * HER calls it (config.py:110-111): n rows of `len` floats each, len in 1..256. */
 int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len,
                            float *d_out, int device_id, void *stream);
 /* Same on packed states against packed goal planes. */
@@ -261,9 +274,17 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream);
 
 /* policy_gradient/rollout.py:255-258: G[b][t_] = r[t_] + sum_{t>t_}
  * gamma**(t-t_) * r[t], float64, accumulated in the reference's order.
- * d_reward_tb (T, n) float32 time-major in, d_G (n, T) float64 batch-major out. */
+ * d_reward_tb (T, n) float32 time-major in, d_G (n, T) float64 batch-major out.
+ * T in 1..319 (the 64-env tile of returns has to fit the 160 KB LDS); the gamma**k table travels
+ * in the kernel arguments, so the call only enqueues a launch (hipGraph-capturable). */
 int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma,
                           double *d_G, int device_id, void *stream);
+
+/* `np.isnan(o_new).any()` of the rollout worker (rollout.py:139-142) as a device-side flag:
+ * *d_flag |= 1 when any of the rows x cols float32 values at d_x (row stride ld) is a NaN.  The
+ * worker reads the flag once per rollout instead of synchronising every step. */
+int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint32_t *d_flag,
+                     int device_id, void *stream);
 
 #ifdef __cplusplus
 }

@@ -893,8 +893,8 @@ def test_callable_contact_source_with_observation():
     calls = []
 
     def physics(env, actions):
-        assert actions.shape == (B, 4) and float(actions.abs().max()) <= 1.0     # clipped (robot_env.py:58)
-        calls.append(env.set_action_vector(actions))
+        assert actions.shape == (B, 4) and float(actions.abs().max()) == 3.0     # as the policy gave them
+        calls.append(env.set_action_vector(actions))                            # robot_env.py:58's clip happens here
         env.assemble_observation(phys, dt=float(d['dt']))
         if len(calls) % 2:
             pairs = torch.tensor([[cube0, cube1], [finger, cube0]], dtype=torch.int16, device=DEV).expand(B, 2, 2)
@@ -908,7 +908,7 @@ def test_callable_contact_source_with_observation():
             return torch.full((B, 4), 3.0, device=DEV)                           # beyond the clip range
 
     w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV,
-                                                     contact_source=bpg.CallableContacts(physics)),
+                                                     contact_source=bpg.CallableContacts(physics, writes_observation=True)),
                            Pol(), dims_of(env_id), None, T, rollout_batch_size=B)
     ep = w.generate_rollouts()
     assert len(calls) == T and torch.equal(calls[0][:, :3], torch.full((B, 3), float(np.float32(0.05)), device=DEV).double())

@@ -1,0 +1,530 @@
+"""GPU tests for the reset -> placement -> backend wiring, the backend-failure / NaN restart of the
+rollout workers, the policy-in-the-loop path at 1 048 576 envs, the launch shapes of the fused
+rollout at BASELINE.json's other batch sizes, and the stateless kernels' argument ranges.
+Bit-exact against the oracle / golden fixtures unless a test says otherwise."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import blockpuzzle_gym_amd as bpg
+from oracle import bpg_oracle as O
+from util import GOLDEN, VARIANTS, ENV_IDS, short, legal_masks
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dims_of(env_id):
+    v = VARIANTS[env_id]
+    return dict(o=v['dimo'], u=4, g=v['dimg'], info_is_success=1)
+
+
+def bits(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+# --------------------------------------------------------------------------
+# reset() / set_test() place the cubes and hand them to the backend
+# --------------------------------------------------------------------------
+def _placement_group(env_id, want_test):
+    """Rows of the placement fixture that share launch constants (one kernel launch)."""
+    d = np.load(os.path.join(GOLDEN, 'placement_%s.npz' % short(env_id)))
+    keys = np.stack([d['grip_xy'][:, 0], d['grip_xy'][:, 1], d['obj_range'], np.nan_to_num(d['max_obj_range']),
+                     np.nan_to_num(d['wrong_obj_range']), d['test'].astype(float), d['challenge'].astype(float)], 1)
+    groups = {}
+    for k, row in enumerate(map(tuple, keys)):
+        groups.setdefault(row, []).append(k)
+    for row, idx in groups.items():
+        if bool(row[5]) == want_test and not row[6]:
+            return d, row, np.asarray(idx)
+    return d, None, None
+
+
+def _variates(d, idx):
+    var = {k: np.nan_to_num(d[k][idx], nan=0.5) for k in ('eu', 'gz', 'gu')}
+    for k in var:
+        if var[k].shape[1] < 2:
+            var[k] = np.concatenate([var[k], np.full((len(idx), 2), 0.5)], 1)
+    return var
+
+
+@pytest.mark.parametrize('env_id', ['BlocksTouchCurriculum-v0', 'BlocksTouchChooseCurriculum-v0',
+                                    'BlocksTouchVariation-v0', 'GripperTouch-v0'])
+def test_reset_hands_the_golden_placement_to_the_backend(env_id):
+    """fetch_env.py:247-255: reset() -> _reset_sim -> _randomize_objects.  With the recorded
+    standard variates the positions a CallableContacts backend receives in on_reset are the
+    reference's, bit for bit; set_test() (fetch_env.py:365-368, :443-446) re-places at the
+    maximum ranges (Variation's set_test does not, :641-644)."""
+    seen = []
+
+    def on_reset(env, xy, status, env_mask, test):
+        assert xy is env.block_xy and status is env.placement_status      # the env's own buffers, no copies
+        seen.append((xy.clone(), status.clone(), None if env_mask is None else env_mask.clone(), test))
+
+    for want_test in (False, True):
+        d, row, idx = _placement_group(env_id, want_test)
+        if row is None:
+            continue
+        env = bpg.make(env_id, num_envs=len(idx), device=DEV,
+                       contact_source=bpg.CallableContacts(lambda e, a: None, on_reset=on_reset))
+        env.obj_range, env.max_obj_range, env.wrong_obj_range = row[2], row[3], row[4]
+        env.grip_xy = row[:2]
+        seen.clear()
+        if not want_test:
+            env.reset(num_grey=d['num_objs'][idx] - 4, variates=_variates(d, idx))
+        else:
+            env.reset(num_grey=d['num_objs'][idx] - 4)              # generator-drawn placement first
+            if not env.info.set_test_supported:
+                with pytest.raises(NotImplementedError):
+                    env.set_test()
+                continue
+            env.set_test(variates=_variates(d, idx))
+            if env.info.is_variation:                               # :641-644 returns _get_obs() only
+                assert len(seen) == 1
+                continue
+            assert len(seen) == 2 and seen[0][3] is False
+        xy, status, em, test = seen[-1]
+        assert test is want_test and em is None and (status == 0).all()
+        got, exp = xy.cpu().numpy(), d['xy'][idx]
+        for j, k in enumerate(idx):
+            nb = int(d['num_objs'][k]) - 2
+            np.testing.assert_array_equal(got[j, :nb].view(np.uint64), exp[j, :nb].view(np.uint64))
+
+
+def test_partial_reset_places_only_the_masked_envs():
+    """reset_rollout(i) (rollout.py:47-58): only env i is re-placed, the hook sees the mask."""
+    B = 64
+    seen = []
+    env = bpg.make('BlocksTouchChooseCurriculum-v0', num_envs=B, device=DEV, seed=3,
+                   contact_source=bpg.CallableContacts(lambda e, a: None,
+                                                       on_reset=lambda e, xy, st, em, test: seen.append((em, test))))
+    env.reset()
+    first = env.block_xy.clone()
+    assert not torch.isnan(first).any() and seen[-1] == (None, False)
+    mask = torch.zeros(B, dtype=torch.uint8, device=DEV)
+    mask[[3, 40]] = 1
+    env.reset(env_mask=mask)
+    changed = (env.block_xy != first).flatten(1).any(1).cpu().numpy()
+    assert changed[[3, 40]].all() and changed.sum() == 2
+    assert torch.equal(seen[-1][0], mask) and seen[-1][1] is False
+    # the rollout worker's reset_rollout goes through the same path (test mode: set_test for env i only)
+    w = bpg.RolloutStudent(lambda num_envs: env.with_num_envs(num_envs), None, dims_of(env.env_id), None, 5,
+                           rollout_batch_size=B)
+    before = w.env.block_xy.clone()
+    n_calls = len(seen)
+    w.reset_rollout(7, test=True)
+    moved = (w.env.block_xy != before).flatten(1).any(1).cpu().numpy()
+    assert moved[7] and moved.sum() == 1
+    assert len(seen) == n_calls + 2 and seen[-1][1] is True and int(seen[-1][0].sum()) == 1
+
+
+def test_sources_that_need_no_positions_skip_the_sampler():
+    env = bpg.make('BlocksTouch-v0', num_envs=32, device=DEV)
+    env.reset()
+    assert torch.isnan(env.block_xy).all()                          # nothing consumed them: not sampled
+    s = bpg.ScriptedContacts(masks=torch.zeros((3, 32), dtype=torch.int32, device=DEV))
+    env = bpg.make('BlocksTouch-v0', num_envs=32, device=DEV, contact_source=s)
+    env.reset(); env.step(None); env.step(None)
+    assert s.t == 2
+    env.reset(env_mask=np.ones(32, np.uint8))                       # a partial reset does not rewind the script
+    assert s.t == 2
+    env.reset()
+    assert s.t == 0
+
+
+def test_variation_static_observation_is_written_by_the_reset_launch():
+    """fetch_env.py:579-607 without physics: obs[0] = num_blocks, one-hot colours of present
+    blocks, zero padding -- and entries of present blocks that physics owns are left alone."""
+    B = 1000
+    env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV)
+    assert (env.observation[:, 0] == 4).all()                       # constructor state: all four blocks
+    env.observation.fill_(7.0)
+    ng = np.random.RandomState(0).randint(3, size=B).astype(np.int32)
+    env.reset(num_grey=ng)
+    o = env.observation.cpu().numpy()
+    nb = ng + 2
+    colors = VARIANTS['BlocksTouchVariation-v0']['obj_colors']
+    exp = np.full((B, 87), 7.0, np.float32)
+    exp[:, 0] = nb
+    for s in range(4):
+        sl = slice(11 + 19 * s, 11 + 19 * (s + 1))
+        present = nb > s
+        blk = exp[:, sl]
+        blk[~present] = 0.0
+        onehot = np.zeros(4, np.float32)
+        onehot[colors[s + 2]] = 1.0
+        blk[present, 15:] = onehot
+        exp[:, sl] = blk
+    np.testing.assert_array_equal(o, exp)
+    # partial reset: only masked rows are rewritten
+    env.observation.fill_(-3.0)
+    mask = np.zeros(B, np.uint8); mask[::10] = 1
+    env.reset(num_grey=ng, env_mask=mask)
+    o = env.observation.cpu().numpy()
+    assert (o[mask == 0] == -3.0).all() and (o[mask == 1, 0] == nb[mask == 1]).all()
+    # a restored checkpoint refreshes the entries from the state
+    sd = env.state_dict()
+    env.reset(num_grey=(ng + 1) % 3)
+    env.load_state_dict(sd)
+    assert (env.observation[:, 0].cpu().numpy() == nb).all()
+
+
+# --------------------------------------------------------------------------
+# backend failures restart the rollout (rollout.py:136-142)
+# --------------------------------------------------------------------------
+class _Logger:
+    def __init__(self):
+        self.lines = []
+
+    def warning(self, m):
+        self.lines.append(m)
+
+    info = warning
+
+
+def _flaky_worker(env_id, B, T, fail_at, mode, cls=bpg.RolloutStudent, **kw):
+    d = np.load(os.path.join(GOLDEN, 'obs_%s.npz' % short(env_id)))
+    phys = {k: np.repeat(d[k][:1], B, 0) for k in bpg.BatchedBlocksEnv.PHYS_FIELDS}
+    state = dict(calls=0, resets=0)
+
+    def physics(env, actions):
+        state['calls'] += 1
+        if state['calls'] == fail_at and mode == 'raise':
+            raise bpg.PhysicsError('simulation unstable')
+        env.assemble_observation(phys, dt=float(d['dt']))
+        if state['calls'] == fail_at and mode == 'nan':
+            env.observation[5, 3] = float('nan')
+        return torch.zeros(B, dtype=torch.int32, device=DEV)
+
+    def on_reset(env, xy, status, env_mask, test):
+        state['resets'] += 1
+
+    class Pol:
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            z = torch.zeros((B, 4), device=DEV)
+            return (z, z, z) if cls is bpg.PGRolloutStudent else z
+
+    log = _Logger()
+    src = bpg.CallableContacts(physics, on_reset=on_reset, writes_observation=True)
+    make = lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, contact_source=src)
+    if cls is bpg.PGRolloutStudent:
+        w = cls(make, Pol(), None, dims_of(env_id), log, T, rollout_batch_size=B, gamma=0.98, **kw)
+    else:
+        w = cls(make, Pol(), dims_of(env_id), log, T, rollout_batch_size=B, **kw)
+    exp_obs = torch.as_tensor(d['obs'][0].astype(np.float32), device=DEV)
+    return w, state, log, exp_obs
+
+
+@pytest.mark.parametrize('mode', ['raise', 'nan'])
+def test_rollout_restarts_after_a_backend_failure(mode):
+    env_id, B, T = 'BlocksTouchChoose-v0', 64, 6
+    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=4, mode=mode)
+    resets0 = state['resets']
+    ep = w.generate_rollouts()
+    # the failed attempt consumed 4 (raise) or all 6 (NaN found at the end) backend calls, then a clean rollout
+    assert state['calls'] == (4 if mode == 'raise' else T) + T
+    assert len(log.lines) == 1 and ('NaN caught' in log.lines[0]) == (mode == 'nan')
+    assert state['resets'] - resets0 == (2 if mode == 'raise' else 3)   # NaN: reset_all_rollouts + the restart's own reset
+    assert not torch.isnan(ep['o']).any()
+    assert torch.equal(ep['o'][:, 1:], exp_obs.expand(B, T, -1))
+    assert w.n_episodes == B and len(w.success_history) == 1            # the failed attempt is not counted
+
+
+def test_pg_rollout_restarts_on_nan_and_keeps_backend_errors_fatal():
+    env_id, B, T = 'BlocksTouch-v0', 32, 5
+    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=2, mode='nan', cls=bpg.PGRolloutStudent)
+    ep = w.generate_rollouts()
+    assert state['calls'] == 2 * T and len(log.lines) == 1 and not torch.isnan(ep['o']).any()
+    assert ep['G'].shape == (B, T)
+    w, state, log, _ = _flaky_worker(env_id, B, T, fail_at=2, mode='raise', cls=bpg.PGRolloutStudent)
+    with pytest.raises(bpg.PhysicsError):                               # policy_gradient/rollout.py:237-241 asserts
+        w.generate_rollouts()
+
+
+def test_a_backend_that_keeps_failing_gives_up():
+    env_id, B, T = 'BlocksTouch-v0', 8, 3
+
+    def physics(env, actions):
+        raise bpg.PhysicsError('always')
+
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV,
+                                                     contact_source=bpg.CallableContacts(physics)),
+                           type('P', (), {'device_tensors': True,
+                                          'get_actions': lambda self, o, ag, g, **kw: torch.zeros((B, 4), device=DEV)})(),
+                           dims_of(env_id), None, T, rollout_batch_size=B)
+    with pytest.warns(UserWarning), pytest.raises(RuntimeError):
+        w.generate_rollouts()
+
+
+def test_nan_flag_kernel():
+    L = bpg._lib.lib()
+    x = torch.randn(1000, 87, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def run(t):
+        bpg._lib.check(L.bpg_nan_flag_f32(C.c_void_p(t.data_ptr()), t.shape[0], t.shape[1], int(t.stride(0)),
+                                          C.c_void_p(flag.data_ptr()), 0, None))
+        return int(flag.item())
+    assert run(x) == 0
+    x[999, 86] = float('inf')
+    assert run(x) == 0
+    wide = torch.randn(1000, 100, device=DEV)
+    wide[:, 87:] = float('nan')                                     # beyond cols: not looked at
+    assert run(wide[:, :87]) == 0
+    x[500, 3] = float('nan')
+    assert run(x) == 1 and run(torch.zeros(4, 4, device=DEV)) == 1  # sticky until the caller clears it
+
+
+# --------------------------------------------------------------------------
+# policy in the loop at BASELINE config 5's size
+# --------------------------------------------------------------------------
+def test_per_step_worker_matches_fused_kernel_at_1m_envs():
+    """1 048 576 envs, T = 50: RolloutStudent.generate_rollouts (one step launch per t, a
+    device-resident policy between the steps) produces the same episode as the single fused
+    launch on the same contacts -- achieved_goal rows, success flags, success rate."""
+    env_id, B, T = 'BlocksTouchVariation-v0', 1 << 20, 50
+    L = bpg._lib.lib()
+    gen = bpg.make(env_id, num_envs=B, device=DEV, seed=5)
+    num_grey = (torch.arange(B, device=DEV, dtype=torch.int32) * 5) % 3
+    gen.reset(num_grey=num_grey)
+    masks = torch.empty((T, B), dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks(gen._h, 0, T, C.c_void_p(masks.data_ptr()), None))
+    del gen
+
+    class Pol:
+        device_tensors = True
+        calls = 0
+
+        def get_actions(self, o, ag, g, **kw):
+            assert o.shape == (B, 87) and ag.shape == (B, 36) and g.shape == (B, 36)
+            Pol.calls += 1
+            return ag[:, :4] * 0.25                                  # reads the observation slot, no copies
+
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV,
+                                                     contact_source=bpg.ScriptedContacts(masks=masks)),
+                           Pol(), dims_of(env_id), None, T, rollout_batch_size=B)
+    ep = w.generate_rollouts(num_grey=num_grey)
+    assert Pol.calls == T
+    assert ep['o'].shape == (B, T + 1, 87) and ep['o'].stride(1) == 0      # nothing wrote observations: a view
+    rate_step = w.success_history[-1]
+    ag_step = ep['ag']
+    succ_step = ep['info_is_success']
+    f = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
+                           dims_of(env_id), None, T, rollout_batch_size=B, output='torch')
+    ep2 = f.generate_rollouts_fused(masks=masks, num_grey=num_grey)
+    assert torch.equal(ag_step, ep2['ag'])
+    assert torch.equal(succ_step, ep2['info_is_success'])
+    assert torch.equal(ep['u'][:, 1], ep2['ag'][:, 1, :4] * 0.25)
+    assert rate_step == f.success_history[-1]
+
+
+# --------------------------------------------------------------------------
+# fused rollout at the other batch sizes of BASELINE.json (launch shapes)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('B', [65536, 131072 + 2, 524288, 65537])
+@pytest.mark.parametrize('reset_first', [1, 0])
+def test_fused_rollout_shapes_agree_with_single_steps(B, reset_first):
+    """Every launch shape rollout_geometry() picks (1 / 2 envs per lane, pipelined / plain loop,
+    odd batch -> 1 per lane) == T single-step launches: rewards, flags, final state, count."""
+    env_id, T = 'BlocksTouchVariation-v0', 23            # 23 = 2 pipelined batches of 10 + 3 leftover steps
+    L = bpg._lib.lib()
+    rng = np.random.RandomState(B % 1000)
+    ng = torch.as_tensor(rng.randint(3, size=B).astype(np.int32), device=DEV)
+    a, b = (bpg.make(env_id, num_envs=B, device=DEV, seed=9) for _ in range(2))
+    masks = torch.empty((T, B), dtype=torch.int32, device=DEV)
+    for e in (a, b):
+        e.reset(num_grey=ng)
+    if not reset_first:                                  # continue an episode: per-lane elapsed counters
+        for e in (a, b):
+            e.step(None)
+        part = torch.zeros(B, dtype=torch.uint8, device=DEV); part[::3] = 1
+        for e in (a, b):
+            e.reset(num_grey=ng, env_mask=part)
+    bpg._lib.check(L.bpg_synth_masks(a._h, 3, T, C.c_void_p(masks.data_ptr()), None))
+    reward = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    flags = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
+                                d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr(),
+                                d_success_count=cnt.data_ptr())
+    bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+    if reset_first:
+        b.reset(num_grey=ng)
+    for t in range(T):
+        _, r, done, info = b.step(None, contact_masks=masks[t])
+        assert torch.equal(r.view(torch.int32), reward[t].view(torch.int32))
+        assert torch.equal((flags[t] & 1) != 0, info['is_success']) and torch.equal((flags[t] & 2) != 0, done)
+    assert torch.equal(a.state_now, b.state_now) and torch.equal(a.state_ever, b.state_ever)
+    assert int(cnt[0]) == int(b.success_count()) and int(cnt[0]) > 0
+    # reward-only and flags-only instantiations write the same streams
+    for kw in (dict(d_reward_tb=reward.data_ptr()), dict(d_flags_tb=flags.data_ptr()), dict()):
+        r0, f0 = reward.clone(), flags.clone()
+        c, c2 = (bpg.make(env_id, num_envs=B, device=DEV, seed=9) for _ in range(2))
+        for e in (c, c2):                                   # both continue from the same (post-rollout) state
+            e.load_state_dict(a.state_dict())
+        args = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), **kw)
+        bpg._lib.check(L.bpg_rollout(c._h, C.byref(args), None))
+        full = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
+                                    d_reward_tb=r0.data_ptr(), d_flags_tb=f0.data_ptr())
+        bpg._lib.check(L.bpg_rollout(c2._h, C.byref(full), None))
+        assert torch.equal(c.state_now, c2.state_now) and torch.equal(c.state_ever, c2.state_ever)
+        if 'd_reward_tb' in kw:
+            assert torch.equal(reward.view(torch.int32), r0.view(torch.int32))
+        if 'd_flags_tb' in kw:
+            assert torch.equal(flags, f0)
+
+
+@pytest.mark.parametrize('B', [65536, 524288])
+def test_synthetic_rollout_shapes_vs_oracle_spec(B):
+    """In-kernel contacts at both envs-per-lane shapes: the reward stream equals stepping the
+    oracle's statement of the source (spot-checked envs), with and without the in-launch reset."""
+    env_id, T, seed, base = 'BlocksTouchVariation-v0', 12, 77, 1000
+    L = bpg._lib.lib()
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=seed, env_id_base=base)
+    ng = torch.as_tensor(np.random.RandomState(1).randint(3, size=B).astype(np.int32), device=DEV)
+    reward = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    flags = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_reward_tb=reward.data_ptr(),
+                                d_flags_tb=flags.data_ptr())
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+    pick = np.r_[0:64, B // 2:B // 2 + 64, B - 64:B]
+    exp_masks = O.synth_masks(seed, base + pick, T, 4 + ng.cpu().numpy()[pick])
+    r = reward.cpu().numpy()[:, pick]
+    # reward is -0.0 exactly when the goal pair (2,3) touches in that step's mask
+    p23 = O.lib().orc_pair_index(2, 3)
+    np.testing.assert_array_equal(r.view(np.uint32) == 0x80000000, ((exp_masks >> p23) & 1) == 1)
+    # continuing WITHOUT reset uses the per-lane elapsed counters: steps T .. 2T-1 of the same source
+    args2 = bpg._lib.RolloutArgs(T=T, reset_first=0, d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr())
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args2), None))
+    exp2 = O.synth_masks(seed, base + pick, 2 * T, 4 + ng.cpu().numpy()[pick])[T:]
+    np.testing.assert_array_equal(reward.cpu().numpy()[:, pick].view(np.uint32) == 0x80000000, ((exp2 >> p23) & 1) == 1)
+
+
+def test_synthetic_source_rates_and_independence_on_the_gpu():
+    """1 048 576 envs x 8 steps of the in-kernel source: every free pair is Bernoulli(5/32) to 4
+    sigma, consecutive steps are uncorrelated, pairs of one step correlate by at most the 0.04 the
+    shared low-order digit introduces, table-block pairs are forced, the diagonal
+    and absent objects never appear."""
+    B, T = 1 << 20, 8
+    L = bpg._lib.lib()
+    env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=2024)
+    env.reset(num_grey=torch.full((B,), 2, dtype=torch.int32, device=DEV))
+    m = torch.empty((T, B), dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(m.data_ptr()), None))
+    idx = O.lib().orc_pair_index
+    forced = [idx(1, k) for k in range(2, 6)]
+    free = [idx(i, j) for i in range(6) for j in range(i + 1, 6) if not (i == 1 and j >= 2)]
+    diag = [idx(i, i) for i in range(6)]
+    b = torch.stack([(m >> p) & 1 for p in range(21)], -1).to(torch.float32)          # (T, B, 21)
+    rate = b.mean((0, 1)).cpu().numpy()
+    assert (rate[forced] == 1).all() and (rate[diag] == 0).all()
+    p, n = 5 / 32, T * B
+    assert np.abs(rate[free] - p).max() < 4 * np.sqrt(p * (1 - p) / n)
+    z = (b[..., free] - p) / np.sqrt(p * (1 - p))
+    same = (z.reshape(-1, len(free)).T @ z.reshape(-1, len(free)) / n).cpu().numpy()
+    off = same - np.diag(np.diag(same))
+    assert np.abs(off).max() < 0.045 and np.abs(np.diag(same) - 1).max() < 0.01
+    lag = (z[:-1].reshape(-1, len(free)).T @ z[1:].reshape(-1, len(free)) / ((T - 1) * B)).cpu().numpy()
+    assert np.abs(lag).max() < 6 / np.sqrt((T - 1) * B)
+    # neighbouring envs are independent too
+    nb = (z[:, :-1].reshape(-1, len(free)) * z[:, 1:].reshape(-1, len(free))).mean(0).cpu().numpy()
+    assert np.abs(nb).max() < 6 / np.sqrt(T * (B - 1))
+
+
+# --------------------------------------------------------------------------
+# stateless kernels: argument ranges, capture
+# --------------------------------------------------------------------------
+def test_discounted_return_any_horizon_and_graph_capture():
+    """Generic horizons (LDS path) are bit-exact too, T > 319 is an argument error, and the
+    call only enqueues work: it can be captured into a hipGraph and replayed."""
+    rng = np.random.RandomState(4)
+    gamma = 0.97
+    for T, B in [(13, 70), (64, 65), (51, 130), (200, 64), (319, 5)]:
+        r = rng.normal(size=(T, B)).astype(np.float32)
+        G = bpg.discounted_return(torch.as_tensor(r, device=DEV), gamma).cpu().numpy()
+        for b in range(0, B, 7):
+            np.testing.assert_array_equal(G[b].view(np.uint64),
+                                          O.discounted_return(r[:, b].astype(np.float64), gamma).view(np.uint64))
+    with pytest.raises(bpg._lib.BpgError):
+        bpg.discounted_return(torch.zeros((320, 4), device=DEV), gamma)
+    for T in (50, 33):
+        r = torch.as_tensor(rng.normal(size=(T, 256)).astype(np.float32), device=DEV)
+        out = torch.empty((256, T), dtype=torch.float64, device=DEV)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            bpg.discounted_return(r, gamma, out=out)                # warm-up outside the capture
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        expect = out.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            bpg.discounted_return(r, gamma, out=out)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, expect)
+
+
+def test_compute_reward_long_rows():
+    """len up to 256 (the header's range): rows longer than 159 floats use 64-row tiles."""
+    rng = np.random.RandomState(8)
+    for n, ln in [(300, 159), (300, 160), (257, 200), (130, 256), (64, 255)]:
+        ag = rng.randint(-1, 2, size=(n, ln)).astype(np.float32)
+        g = (rng.randint(-1, 2, size=(n, ln)) * (rng.rand(n, ln) < 0.1)).astype(np.float32)
+        ag[::2] = np.where(g[::2] != 0, g[::2], ag[::2])
+        got = bpg.compute_reward(torch.as_tensor(ag, device=DEV), torch.as_tensor(g, device=DEV))
+        np.testing.assert_array_equal(bits(got), O.compute_reward(ag, g).view(np.uint32))
+    with pytest.raises(bpg._lib.BpgError):
+        bpg.compute_reward(torch.zeros((4, 257), device=DEV), torch.zeros((4, 257), device=DEV))
+
+
+# --------------------------------------------------------------------------
+# seeding contract (build-defined replacement of seed + 1000 * idx)
+# --------------------------------------------------------------------------
+def test_seeding_contract():
+    """robot_env.py:53-55 / rollout.py:206-210 give env idx the stream seed + 1000*idx of gym's
+    hashed MT19937 (third-party).  The replacement contract: every generator-drawn quantity is a
+    pure function of (seed, GLOBAL env index, stream index, step) --
+      * seed() returns [seed] and restarts the stream indices: same seed => same draws again;
+      * different seeds / different env indices give different, uncorrelated draws;
+      * each generator-drawn reset / placement advances its stream index by one: consecutive
+        episodes differ, and a state_dict round trip resumes the streams;
+      * how the batch is split over handles (shards) does not matter."""
+    env_id, B = 'BlocksTouchVariation-v0', 4096
+    L = bpg._lib.lib()
+
+    def draws(env):
+        env.reset()
+        ng = env.num_objs_per_env().clone()
+        m = torch.empty((4, env.num_envs), dtype=torch.int32, device=DEV)
+        bpg._lib.check(L.bpg_synth_masks(env._h, 0, 4, C.c_void_p(m.data_ptr()), None))
+        xy, _ = env.randomize_objects()
+        return ng, m, xy.nan_to_num()
+
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=42)
+    assert env.seed(42) == [42]
+    first = draws(env)
+    second = draws(env)                                              # next episode: stream indices advanced
+    assert not torch.equal(first[0], second[0]) and not torch.equal(first[2], second[2])
+    assert int(env.state_counters[0]) == 2 and int(env.state_counters[1]) == 2
+    sd = env.state_dict()
+    third = draws(env)
+    env.load_state_dict(sd)
+    again = draws(env)
+    assert all(torch.equal(x, y) for x, y in zip(third, again))      # checkpoint resumes the streams
+    env.seed(42)
+    assert int(env.state_counters[0]) == 0
+    replay = draws(env)
+    assert all(torch.equal(x, y) for x, y in zip(first, replay))     # same seed: same draws
+    other = draws(bpg.make(env_id, num_envs=B, device=DEV, seed=43))
+    assert (first[0] != other[0]).float().mean() > 0.5 and (first[1] != other[1]).float().mean() > 0.9
+    lo = draws(bpg.make(env_id, num_envs=B // 2, device=DEV, seed=42))
+    hi = draws(bpg.make(env_id, num_envs=B // 2, device=DEV, seed=42, env_id_base=B // 2))
+    for k in range(3):
+        assert torch.equal(torch.cat([lo[k], hi[k]], 0 if k != 1 else 1), first[k])
