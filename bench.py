@@ -7,9 +7,11 @@ all envs, T=50 fused env steps (contacts read as packed masks resident in HBM --
 the contacts-in boundary -- rewards + success/done flags written per env-step)
 and the success-count reduction; with N>1 GPUs the (successes, envs) rows are
 all-reduced over RCCL in slabs of `--reduce-every` rollouts (default 8), asynchronously.
-Weak scaling: every GPU holds `--envs` envs.
+Weak scaling by default: every GPU holds `--envs` envs (BASELINE configs[2] per GPU).
+`--total-envs E` fixes the JOB size instead and shards it over the ranks (strong scaling):
+`--gpus 8 --total-envs 4194304` is BASELINE configs[3] as written (524 288 envs per GPU).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--total-envs E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -32,7 +34,9 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=100)
     p.add_argument('--warmup', type=int, default=10)
-    p.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU')
+    p.add_argument('--envs', type=int, default=1 << 20, help='envs per GPU (weak scaling)')
+    p.add_argument('--total-envs', type=int, default=0,
+                   help='total envs of the job, sharded over the ranks (strong scaling); overrides --envs')
     p.add_argument('--T', type=int, default=50)
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--buffers', type=int, default=4, help='independent mask/output buffer sets used round-robin')
@@ -120,8 +124,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     L = _lib.lib()
-    B, T = a.envs, a.T
-    total = B * world
+    T = a.T
+    if a.total_envs:
+        total = a.total_envs
+        lo, hi = D.shard_range(total, rank, world)
+        B = hi - lo
+    else:
+        B = a.envs
+        total = B * world
     env = D.make_sharded(ENV_ID, total, rank, world, device=dev, seed=a.seed)
     assert env.num_envs == B
     if not a.default_stream:
@@ -133,11 +143,12 @@ def main():
     # synthetic source (global env index keyed), outputs preallocated
     # Variation draws num_grey per episode (fetch_env.py:647); fixed explicit draws keep every
     # rollout's episode consistent with the pre-generated contact masks
-    num_grey = (torch.arange(B, device=dev, dtype=torch.int32) * 7 + rank) % 3
+    num_grey = ((torch.arange(B, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
     env.reset(num_grey=num_grey)
     # NBUF independent input/output buffer sets, used round-robin, so that no launch finds its
     # contact masks in the 256 MiB Infinity Cache from a previous launch: inputs come from HBM
-    NBUF = a.buffers
+    # (a set is B * 450 bytes: enough sets that two consecutive uses of one are > 2 x 256 MiB apart)
+    NBUF = max(a.buffers, int(2.5 * 256 * 2**20 // (B * T * 9)) + 1)
     masks, reward, flags = [], [], []
     for k in range(NBUF):
         env.seed(a.seed + k)
@@ -214,14 +225,15 @@ def main():
         last = stats[-1].tolist()
         succ_rate = last[0] / last[1]        # global: the row was all-reduced when world > 1
 
-    # algorithmic bytes of the fused rollout launch (DESIGN.md): per env-step mask 4 B in,
-    # reward 4 B + flags 1 B out; per env packed state 8 B in + 8 B out
-    bytes_per_launch = B * (T * 9 + 16)
+    # algorithmic bytes of the fused rollout launch (DESIGN.md 4): per env-step mask 4 B in,
+    # reward 4 B + flags 1 B out; per env the packed state 8 B out (the in-launch Variation reset
+    # overwrites the whole state, so the old state is not an input) + the explicit num_grey draw 4 B in
+    bytes_per_launch = B * (T * 9 + 8 + 4)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tf):
-        t = json.load(open(tf)).get('k_rollout_vec4_masks')
+        t = json.load(open(tf)).get('k_rollout_masks')
         if t and t.get('envs') == B and t.get('T') == T:
             traffic = t['hbm_bytes_per_launch']
 
@@ -229,7 +241,7 @@ def main():
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
         'host_enqueue_ms_per_step': host_dt / a.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
+        'higher_is_better': True, 'scaling': 'strong' if a.total_envs else 'weak', 'vs_baseline': None, 'dtype': 'u32',
         'data': 'synthetic',
         'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
                                'resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
@@ -238,7 +250,7 @@ def main():
                    'buffer_sets': NBUF, 'collective': (a.collective if world > 1 else None),
                    'rollouts_per_collective': (R if world > 1 else None),
                    'success_rate': succ_rate},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_rollout_vec4<masks>', 'achieved': achieved,
+        'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, 2 envs/lane, reward+flags, reset>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms},
@@ -248,13 +260,15 @@ def main():
         out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
         # SURVEY 8(d)'s per-step accounting (25 B/env-step: state read+written every step) for the
         # one-launch-per-step form of the same path, next to the fused headline above
-        one = out['extra'].get('step_masks_single_launch', {})
+        one = out['extra'].get('step_masks_single_launch_hbm_cold', {})
         grp = out['extra'].get('step_masks_graph_T_launches', {})
         if 'GB/s' in one:
             out['roofline_per_step_launch'] = {
                 'bound': 'hbm', 'kernel': 'k_step_vec4<masks>', 'bytes_per_env_step': 25,
                 'achieved': one['GB/s'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': one['GB/s'] / HBM_PEAK_GBS, 'kernel_ms': one['ms'],
+                'how': '13 independent 1 M-env batches stepped round-robin (HBM-cold), events around a train of '
+                       'launches; the rocprofv3 mean of the same kernel is in profiles/',
                 'graph_replay_of_T_launches': {k: grp.get(k) for k in ('ms', 'GB/s', 'frac_hbm_peak',
                                                                       'env_steps_per_sec')}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -284,20 +298,63 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
-    def line(ms, nbytes, env_steps):
+    def line(ms, nbytes, env_steps, cache_resident=False):
         gbs = nbytes / (ms * 1e-3) / 1e9
-        return {'ms': ms, 'GB/s': gbs, 'frac_hbm_peak': gbs / HBM_PEAK_GBS, 'bytes': nbytes,
-                'env_steps_per_sec': env_steps / (ms * 1e-3)}
+        out = {'ms': ms, 'GB/s': gbs, 'bytes': nbytes, 'env_steps_per_sec': env_steps / (ms * 1e-3)}
+        if cache_resident:      # working set stays in the 256 MiB Infinity Cache: NOT an HBM figure
+            out['infinity_cache_resident'] = True
+        else:
+            out['frac_hbm_peak'] = gbs / HBM_PEAK_GBS
+        return out
+
+    # launch floor of this method (events around a train of back-to-back launches): the library's
+    # smallest kernel, a reset of a 1-env batch
+    tiny = bpg.make(ENV_ID, num_envs=1, device=dev)
+    res['launch_floor_smallest_kernel'] = {'ms': timed(lambda: _lib.check(L.bpg_reset(tiny._h, None, None, stream)), 200)}
+    del tiny
 
     # (0) on-box streaming ceiling: device-to-device copy of one (T,B) u32 array (read + write)
     src, dst = masks, reward.view(torch.int32)
     res['copy_ceiling_torch_d2d'] = line(timed(lambda: dst.copy_(src), 20), 2 * masks.numel() * 4, 0)
 
+    # (0a) the headline kernel at BASELINE.json's other batch sizes (configs[1]: 65 536 envs;
+    # configs[3]: 4 194 304 over 8 GPUs = 524 288 per GPU), masks read cold from HBM
+    for Bx in (65536, 524288):
+        try:
+            res['rollout_masks_%d_envs' % Bx] = rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line)
+        except Exception as e:  # noqa: BLE001
+            res['rollout_masks_%d_envs' % Bx] = {'error': repr(e)[:200]}
+
     # (1) one env.step launch: 12 B in (now, ever, mask) + 13 B out (now, ever, reward, flags) = 25 B/env-step
+    # (SURVEY 8d's per-step form).  One batch stepped over and over keeps its 26 MB in the Infinity Cache ...
     def step_once():
         _lib.check(L.bpg_step_masks(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
                                     C.c_void_p(flags.data_ptr()), stream))
-    res['step_masks_single_launch'] = line(timed(step_once, 200), 25 * B, B)
+    res['step_masks_single_launch'] = line(timed(step_once, 200), 25 * B, B, cache_resident=True)
+    # ... so the HBM figure steps 13 independent batches round-robin (13 x 26 MB of state + streams
+    # between two visits of the same batch: nothing survives in the 256 MiB cache)
+    try:
+        NSET = 13
+        sets = []
+        for k in range(NSET):
+            e = bpg.make(ENV_ID, num_envs=B, device=dev, seed=100 + k)
+            e.reset()
+            m = torch.empty(B, dtype=torch.int32, device=dev)
+            _lib.check(L.bpg_synth_masks(e._h, 0, 1, C.c_void_p(m.data_ptr()), stream))
+            sets.append((e, m, torch.empty(B, dtype=torch.float32, device=dev),
+                         torch.empty(B, dtype=torch.uint8, device=dev)))
+        it = [0]
+
+        def step_cold():
+            e, m, r, f = sets[it[0] % NSET]
+            it[0] += 1
+            _lib.check(L.bpg_step_masks(e._h, C.c_void_p(m.data_ptr()), C.c_void_p(r.data_ptr()),
+                                        C.c_void_p(f.data_ptr()), stream))
+        res['step_masks_single_launch_hbm_cold'] = line(timed(step_cold, 20 * NSET), 25 * B, B)
+        res['step_masks_single_launch_hbm_cold']['batches_round_robin'] = NSET
+        del sets
+    except Exception as e:  # noqa: BLE001
+        res['step_masks_single_launch_hbm_cold'] = {'error': repr(e)[:200]}
 
     # (1a) the rollout worker's step: step + float32 achieved_goal row + float32 is_success in one launch:
     # 12 B in, 13 + 4 + 144 B out = 173 B/env-step
@@ -326,12 +383,13 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
             _lib.check(L.bpg_step_contacts(env._h, C.c_void_p(pairs.data_ptr()), C.c_void_p(ncon.data_ptr()),
                                            maxcon, C.c_void_p(reward.data_ptr()), C.c_void_p(flags.data_ptr()),
                                            stream))
-        res['step_contacts_single_launch'] = line(timed(step_contacts, 100), 89 * B, B)
+        res['step_contacts_single_launch'] = line(timed(step_contacts, 100), 89 * B, B, cache_resident=True)
         del pairs, ncon, idx
     except Exception as e:  # noqa: BLE001
         res['step_contacts_single_launch'] = {'error': repr(e)[:200]}
 
-    # (2) the same T steps as T launches replayed from a hipGraph
+    # (2) the same T steps as T launches replayed from a hipGraph (25 B/env-step, streams from HBM,
+    # the 8 MB of state cache-resident between the launches)
     try:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream(dev)
@@ -346,20 +404,21 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     except Exception as e:  # noqa: BLE001
         res['step_masks_graph_T_launches'] = {'error': repr(e)[:200]}
 
-    # (3) fused rollout with in-kernel synthetic contacts: reward 4 + flags 1 per env-step + 16 B state
+    # (3) fused rollout with in-kernel synthetic contacts (SURVEY 8d's "contacts generated in-kernel"):
+    # reward 4 + flags 1 written per env-step + 8 B of state per env (the in-launch reset reads nothing)
     a2 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=None, d_reward_tb=reward.data_ptr(),
                           d_flags_tb=flags.data_ptr())
 
     def synth():
         _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
-    res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 16), B * T)
+    res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 8), B * T)
 
     # (3b) compact outputs: flags alone (bit2 encodes the reward) -> mask 4 in + flags 1 out per env-step
     a2c = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_flags_tb=flags.data_ptr())
 
     def compact():
         _lib.check(L.bpg_rollout(env._h, C.byref(a2c), stream))
-    res['rollout_masks_flags_only'] = line(timed(compact, 20), B * (T * 5 + 16), B * T)
+    res['rollout_masks_flags_only'] = line(timed(compact, 20), B * (T * 5 + 8), B * T)
 
     # (3c) float view of the packed state: obs['achieved_goal'] (B, 36) f32
     agv = torch.empty((B, env.dimg), dtype=torch.float32, device=dev)
@@ -405,7 +464,100 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         del ag, gg, sc
     except Exception as e:  # noqa: BLE001
         res['episode_writer_f32'] = {'error': repr(e)[:200]}
+
+    # (5) BASELINE configs[4]: the rollout worker with a policy in the loop
+    for Bx in (65536, B):
+        try:
+            res['rollout_policy_in_loop_%d_envs' % Bx] = policy_in_loop(torch, bpg, Bx, T, dev)
+        except Exception as e:  # noqa: BLE001
+            res['rollout_policy_in_loop_%d_envs' % Bx] = {'error': repr(e)[:300]}
     return res
+
+
+def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line):
+    """The bench headline (one fused reset + T-step + success-count launch, masks from HBM) at
+    another batch size."""
+    L = _lib.lib()
+    e = bpg.make(ENV_ID, num_envs=Bx, device=dev, seed=7)
+    ng = (torch.arange(Bx, device=dev, dtype=torch.int32) * 7) % 3
+    e.reset(num_grey=ng)
+    nset = int(2.5 * 256 * 2**20 // (Bx * T * 9)) + 1
+    sets = []
+    for k in range(nset):
+        e.seed(7 + k)
+        m = torch.empty((T, Bx), dtype=torch.int32, device=dev)
+        _lib.check(L.bpg_synth_masks(e._h, 0, T, C.c_void_p(m.data_ptr()), stream))
+        sets.append((m, torch.empty((T, Bx), dtype=torch.float32, device=dev),
+                     torch.empty((T, Bx), dtype=torch.uint8, device=dev)))
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(),
+                             d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
+            for m, r, f in sets]
+    it = [0]
+
+    def go():
+        _lib.check(L.bpg_rollout(e._h, C.byref(args[it[0] % nset]), stream))
+        it[0] += 1
+    out = line(timed(go, max(40, 2 * nset)), Bx * (T * 9 + 12), Bx * T)
+    out['buffer_sets'] = nset
+    out['note'] = 'ms = events around a train of back-to-back launches (includes the launch gaps; see launch_floor_smallest_kernel)'
+    return out
+
+
+def policy_in_loop(torch, bpg, Bx, T, dev):
+    """RolloutStudent.generate_rollouts with a device-resident policy between the env steps
+    (rollout.py:75-172): eager (one step launch + policy per t) vs the whole loop replayed from a
+    hipGraph.  Two policies: a trivial one (isolates the env side: step kernel writing straight
+    into the episode slots + the action copy) and a 3 x 256 MLP on the observation with the input
+    contract of the reference's ActorCritic (actor_critic.py:213-255: normalised, clipped `o` ->
+    3 hidden layers of 256 -> tanh * max_u), bf16 weights -- torch is only the policy here."""
+    dimo, dimg = 87, 36
+
+    class Trivial:
+        device_tensors = True
+
+        def __init__(self):
+            self.u = torch.zeros((Bx, 4), device=dev)
+
+        def get_actions(self, o, ag, g, **kw):
+            return self.u
+
+    class MLP:
+        device_tensors = True
+
+        def __init__(self):
+            gen = torch.Generator(device=dev).manual_seed(0)
+            dims = [dimo, 256, 256, 256, 4]
+            self.w = [(torch.randn((dims[i], dims[i + 1]), device=dev, generator=gen) / dims[i] ** 0.5).to(torch.bfloat16)
+                      for i in range(4)]
+            self.mean = torch.zeros(dimo, device=dev)
+            self.inv_std = torch.ones(dimo, device=dev)
+
+        def get_actions(self, o, ag, g, **kw):
+            x = torch.clamp((o - self.mean) * self.inv_std, -5.0, 5.0).to(torch.bfloat16)   # Normalizer.normalize
+            for w in self.w[:-1]:
+                x = torch.relu(x @ w)
+            return torch.tanh((x @ self.w[-1]).float())
+
+    out = {'env_side_bytes_per_env_step': 12 + 13 + 4 + 4 * dimg + 16,
+           'note': 'ms per T=%d rollout of %d envs, reset included; env side = step + f32 achieved_goal row + f32 '
+                   'is_success written into the episode slots, actions stored; o is an expanded view (no backend '
+                   'writes observations)' % (T, Bx)}
+    for name, pol, reps in (('trivial_policy', Trivial(), 5), ('mlp_3x256_bf16', MLP(), 2)):
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=dev), pol,
+                               dict(o=dimo, u=4, g=dimg, info_is_success=1), None, T, rollout_batch_size=Bx)
+        for mode, fn in (('eager', w.generate_rollouts), ('hipgraph', w.generate_rollouts_graphed)):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            out['%s_%s' % (name, mode)] = {'ms': ms, 'env_steps_per_sec': Bx * T / (ms * 1e-3)}
+        del w
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == '__main__':

@@ -380,21 +380,24 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
         __syncthreads();                             // previous tile consumed
         s_nblocks[threadIdx.x] = nbk;
         __syncthreads();
-        // the block's 256 observation rows, element by element (consecutive lanes -> consecutive
-        // addresses within a row)
+        // each wave walks 64 of the block's rows; lane = entry of the row (two trips cover the 87
+        // entries), so what an entry is (num_blocks / slot / colour) is worked out once per lane and
+        // the stores of a row are consecutive addresses
         const int rows = (int)((n - base) < 256 ? (n - base) : 256);
-        const int total = rows * so.dimo;
-        for (int f = threadIdx.x; f < total; f += 256) {
-            const int e = f / so.dimo, k = f - e * so.dimo;
-            const int nb = s_nblocks[e];
-            if (nb == 0xFF) continue;
-            float *o = so.obs + (base + e) * so.ld + k;
-            if (k == 0) { *o = (float)nb; continue; }                      // :580
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int k = lane; k < so.dimo; k += 64) {
             const int j = k - 11;                                          // 1 + ENV_FEATURES
-            if (j < 0) continue;
-            const int slot = j / 19, c = j - slot * 19;
-            if (slot >= nb) *o = 0.0f;                                     // zero padding :606-607
-            else if (c >= 15) *o = (so.colors[slot + 2] == c - 15) ? 1.0f : 0.0f;   // one_hot_color :599
+            const int slot = j >= 0 ? j / 19 : -1, c = j >= 0 ? j - slot * 19 : 0;
+            const float hot = (slot >= 0 && c >= 15 && so.colors[slot + 2] == c - 15) ? 1.0f : 0.0f;
+            if (k != 0 && slot < 0) continue;                              // physics-owned gripper entries
+            for (int e = wave * 64; e < rows && e < wave * 64 + 64; e++) {
+                const int nb = s_nblocks[e];
+                if (nb == 0xFF) continue;
+                float *o = so.obs + (base + e) * so.ld + k;
+                if (k == 0) *o = (float)nb;                                // :580
+                else if (slot >= nb) *o = 0.0f;                            // zero padding :606-607
+                else if (c >= 15) *o = hot;                                // one_hot_color :599
+            }
         }
     }
 }
@@ -1435,7 +1438,16 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
 // yet used, and the 64 x T tile that turns the per-lane rows into contiguous 8-byte-per-lane
 // stores is staged through LDS in two halves (13 KB per wave instead of 26 KB).
 constexpr int DR_TMAX_REG = 64;
+constexpr int DR_W = 16;
 struct PowTable { double v[DR_TMAX_REG]; };
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
 
 template <int TT>
 __global__ void __launch_bounds__(64)
@@ -1445,41 +1457,80 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable
     constexpr int R = H | 1;                  // odd row stride: conflict-free ds_write_b64
     __shared__ double tile[64 * R];
     const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * 64;
-    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-    double acc[TT];
-    if (lane < nvalid) {
-        const float *p = reward_tb + base + lane;
-        float rf[TT];
-#pragma unroll
-        for (int t = 0; t < TT; t++) rf[t] = p[(int64_t)t * n];
-#pragma unroll
-        for (int t = 0; t < TT; t++) {
-            const double rt = (double)rf[t];
+    const int64_t ntiles = (n + 63) / 64;
+    // Persistent one-wave blocks walk the 64-env tiles; the rewards of the NEXT tile are requested
+    // before the ~2 450 f64 operations of the current one, so no wave ever sits out a memory round
+    // trip (with one tile per block, 2.9 resident waves per SIMD left the VALU idle half the time).
+    // The last trip re-requests its own tile: an unconditional prefetch keeps the wait counts exact.
+    auto request = [&](int64_t tl, float *rf) {
+        // one per-lane pointer walked down the rows (the empty asm keeps it ONE register pair: the
+        // gamma**k table fills the SGPR file, so per-row bases would otherwise become 50 VGPR pairs
+        // that stay alive across the tile loop)
+        const int64_t base = tl * 64;
+        const bool ok = base + lane < n;
+        typedef const float __attribute__((address_space(1))) *gptr;      // stays a global_load behind the asm
+        gptr p = (gptr)(reward_tb + base + (ok ? lane : 0));
+        static_for<0, TT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            rf[t] = *p;
+            p += n;
+            asm volatile("" : "+v"(p));
+        });
+    };
+    float cur[TT], nxt[TT];
+    int64_t tl = blockIdx.x;
+    if (tl < ntiles) request(tl, cur);
+    for (; tl < ntiles; tl += gridDim.x) {
+        const int64_t tn = tl + gridDim.x < ntiles ? tl + gridDim.x : tl;
+        request(tn, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t base = tl * 64;
+        const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+        double acc[TT];
+        // products eight at a time into their own registers, then the eight additions (an f64
+        // result is ~20 cycles away; eight independent products cover that for a wave on its own)
+        static_for<0, TT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const double rt = (double)cur[t];
             acc[t] = rt;
+            static_for<0, (t + DR_W - 1) / DR_W>([&](auto gc) {
+                constexpr int t0 = decltype(gc)::value * DR_W;
+                constexpr int cnt = (t - t0) < DR_W ? (t - t0) : DR_W;
+                double prod[DR_W];
+                static_for<0, cnt>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    prod[j] = pw.v[t - t0 - j] * rt;
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, cnt>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    acc[t0 + j] = acc[t0 + j] + prod[j];
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        double *o = G + base * (int64_t)TT;
 #pragma unroll
-            for (int t_ = 0; t_ < t; t_++) acc[t_] = acc[t_] + pw.v[t - t_] * rt;
-        }
-    }
-    double *o = G + base * (int64_t)TT;
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int r0 = pass * H, cnt = (TT - r0) < H ? (TT - r0) : H;
-        if (pass) __syncthreads();                       // first half streamed out
-        if (lane < nvalid) {
-#pragma unroll
-            for (int j = 0; j < H; j++)
-                if (r0 + j < TT) tile[lane * R + j] = acc[r0 + j];
-        }
-        __syncthreads();
-        const int total = nvalid * cnt;
-        int e = 0, rem = lane;
-        while (rem >= cnt) { rem -= cnt; e++; }
-        for (int f = lane; f < total; f += 64) {
-            o[(int64_t)e * TT + r0 + rem] = tile[e * R + rem];
-            rem += 64;
+        for (int pass = 0; pass < 2; pass++) {
+            const int r0 = pass * H, cnt = (TT - r0) < H ? (TT - r0) : H;
+            __syncthreads();                                 // the tile's previous contents streamed out
+            if (lane < nvalid) {
+                static_for<0, H>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if (r0 + j < TT) tile[lane * R + j] = acc[pass ? (H + j < TT ? H + j : 0) : j];
+                });
+            }
+            __syncthreads();
+            const int total = nvalid * cnt;
+            int e = 0, rem = lane;
             while (rem >= cnt) { rem -= cnt; e++; }
+            for (int f = lane; f < total; f += 64) {
+                o[(int64_t)e * TT + r0 + rem] = tile[e * R + rem];
+                rem += 64;
+                while (rem >= cnt) { rem -= cnt; e++; }
+            }
         }
+        static_for<0, TT>([&](auto tc) { cur[decltype(tc)::value] = nxt[decltype(tc)::value]; });
     }
 }
 
@@ -1506,9 +1557,11 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
             my[t] = rt;
             int t_ = 0;
             for (; t_ + 4 <= t; t_ += 4) {
-                const double a0 = my[t_] + pw.v[t - t_] * rt, a1 = my[t_ + 1] + pw.v[t - t_ - 1] * rt;
-                const double a2 = my[t_ + 2] + pw.v[t - t_ - 2] * rt, a3 = my[t_ + 3] + pw.v[t - t_ - 3] * rt;
-                my[t_] = a0; my[t_ + 1] = a1; my[t_ + 2] = a2; my[t_ + 3] = a3;
+                const double p0 = pw.v[t - t_] * rt, p1 = pw.v[t - t_ - 1] * rt, p2 = pw.v[t - t_ - 2] * rt,
+                             p3 = pw.v[t - t_ - 3] * rt;
+                const double m0 = my[t_], m1 = my[t_ + 1], m2 = my[t_ + 2], m3 = my[t_ + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                my[t_] = m0 + p0; my[t_ + 1] = m1 + p1; my[t_ + 2] = m2 + p2; my[t_ + 3] = m3 + p3;
             }
             for (; t_ < t; t_++) my[t_] = my[t_] + pw.v[t - t_] * rt;
         }
@@ -2305,18 +2358,21 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
     if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
     DeviceGuard guard(device_id);
-    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    const int64_t ntiles = (n + 63) / 64;
+    const dim3 grid((unsigned)ntiles), block(64);
     if (T == 50 || T == 25 || T == 10) {
+        // persistent one-wave blocks, 8 per CU (two waves per SIMD: ~200 VGPRs each)
+        const dim3 pgrid((unsigned)(ntiles < 2048 ? ntiles : 2048));
         // register-resident fast path for the horizons in use (T = max_episode_steps = 50)
         PowTable tab;
         std::memset(&tab, 0, sizeof(tab));
         for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
         if (T == 50)
-            hipLaunchKernelGGL(k_discounted_return_reg<50>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
         else if (T == 25)
-            hipLaunchKernelGGL(k_discounted_return_reg<25>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
         else
-            hipLaunchKernelGGL(k_discounted_return_reg<10>, grid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
         return check_launch("k_discounted_return_reg");
     }
     PowTableBig big;

@@ -97,9 +97,11 @@ class RolloutStudent:
         obs = self.env.reset(num_grey=num_grey)
         if test:
             obs = self.env.unwrapped.set_test()      # maximum difficulty (rollout.py:53-55)
-        self.initial_o.copy_(obs['observation'])
-        self.initial_ag.copy_(obs['achieved_goal'])
-        self.g.copy_(obs['desired_goal'])
+        # the env hands out its observation / goal buffers and a fresh achieved_goal tensor: no copies here
+        # (the episode takes its own copy of the first observation, _episode_o)
+        self.initial_o = obs['observation']
+        self.initial_ag = obs['achieved_goal']
+        self.g = obs['desired_goal']
 
     def reset_rollout(self, i, test=False):
         mask = torch.zeros(self.rollout_batch_size, dtype=torch.uint8, device=self.device)

@@ -366,6 +366,11 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
         env = H.make(env_id)
         log = []
         attach_scripts(env, seed + 1000 * len(logs), log, p_pair=0.012)
+        # RolloutStudent.__init__ resets every env BEFORE worker.seed() runs (rollout.py:33-45):
+        # with the per-env stream still seeded from OS entropy the first placement -- and through its
+        # rejection loops the position of the GLOBAL np.random stream (quirk Q7) -- differed from run
+        # to run, and with it every later cube position (the `o` arrays).  Seed at construction.
+        env.seed(seed + 1000 * len(logs))
         logs.append(log)
         return env
 
@@ -409,7 +414,7 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
     return out
 
 
-def main():
+def main(HERE=HERE):
     H.install()
     from gym_blocks.envs import fetch_env
     rng = np.random.RandomState(20261004)
@@ -468,5 +473,36 @@ def main():
     print('golden fixtures written to', HERE)
 
 
+def check():
+    """Regenerates every fixture into a temporary directory and compares it with the committed
+    one (arrays bit for bit, json after parsing).  Exit code 1 on any difference."""
+    import tempfile
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        main(tmp)
+        for name in sorted(os.listdir(tmp)):
+            new, old = os.path.join(tmp, name), os.path.join(HERE, name)
+            if not os.path.exists(old):
+                bad.append('%s: not committed' % name)
+            elif name.endswith('.json'):
+                if json.load(open(new)) != json.load(open(old)):
+                    bad.append('%s: differs' % name)
+            else:
+                a, b = np.load(new), np.load(old)
+                if sorted(a.files) != sorted(b.files):
+                    bad.append('%s: keys differ' % name)
+                    continue
+                for k in a.files:
+                    x, y = a[k], b[k]
+                    if x.shape != y.shape or x.dtype != y.dtype or x.tobytes() != y.tobytes():
+                        bad.append('%s[%s]: differs' % (name, k))
+    for line in bad:
+        print('MISMATCH', line)
+    print('checked: %s' % ('%d mismatches' % len(bad) if bad else 'every fixture regenerates bit-identically'))
+    return 1 if bad else 0
+
+
 if __name__ == '__main__':
+    if '--check' in sys.argv[1:]:
+        sys.exit(check())
     main()

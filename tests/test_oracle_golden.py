@@ -231,3 +231,16 @@ def test_set_action_vector(env_id):
     assert (np.abs(d['actions']) > 1).any()
     for a, exp in zip(d['actions'], d['set_action']):
         np.testing.assert_array_equal(O.set_action(a, bool(d['block_gripper'])).view(np.uint64), exp.view(np.uint64))
+
+
+def test_fixture_generator_is_deterministic():
+    """tests/golden/make_golden.py --check: every committed fixture regenerates bit-identically
+    from the reference (only where /root/reference is mounted: the build container)."""
+    import subprocess
+    import sys
+    if not os.path.isdir('/root/reference/gym_blocks'):
+        pytest.skip('the reference is not mounted here')
+    out = subprocess.run([sys.executable, os.path.join(G, 'make_golden.py'), '--check'], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'regenerates bit-identically' in out.stdout

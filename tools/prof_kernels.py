@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Runs a few launches of selected kernels of the path at the bench configuration, for
+rocprofv3 (kernel trace or one --pmc counter set per invocation):
+
+    rocprofv3 --kernel-trace --stats -d out -- python3 tools/prof_kernels.py return rollout synth
+    rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
+
+kernels: rollout (fused, masks), rollout64k, rollout512k, synth (fused, in-kernel contacts),
+step (13 batches round-robin), record, return, episode, reward
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import blockpuzzle_gym_amd as bpg  # noqa: E402
+from blockpuzzle_gym_amd import _lib  # noqa: E402
+
+ENV_ID, T, DEV = 'BlocksTouchVariation-v0', 50, torch.device('cuda', 0)
+L = _lib.lib()
+P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+
+
+def rollout(B, reps, synth=False):
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+    ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 7) % 3
+    env.reset(num_grey=ng)
+    nset = int(2.5 * 256 * 2**20 // (B * T * 9)) + 1
+    sets = []
+    for k in range(max(nset, 4)):
+        env.seed(k)
+        m = torch.empty((T, B), dtype=torch.int32, device=DEV)
+        _lib.check(L.bpg_synth_masks(env._h, 0, T, P(m), None))
+        sets.append((m, torch.empty((T, B), dtype=torch.float32, device=DEV), torch.empty((T, B), dtype=torch.uint8, device=DEV)))
+    cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    for i in range(reps):
+        m, r, f = sets[i % len(sets)]
+        a = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=None if synth else ng.data_ptr(),
+                             d_masks=None if synth else m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
+                             d_success_count=None if synth else cnt.data_ptr())
+        _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    torch.cuda.synchronize()
+
+
+def main():
+    which = sys.argv[1:] or ['rollout']
+    B = 1 << 20
+    for w in which:
+        if w == 'rollout':
+            rollout(B, 20)
+        elif w == 'rollout64k':
+            rollout(65536, 60)
+        elif w == 'rollout512k':
+            rollout(524288, 20)
+        elif w == 'synth':
+            rollout(B, 20, synth=True)
+        elif w == 'step':
+            sets = []
+            for k in range(13):
+                e = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=k)
+                e.reset()
+                m = torch.empty(B, dtype=torch.int32, device=DEV)
+                _lib.check(L.bpg_synth_masks(e._h, 0, 1, P(m), None))
+                sets.append((e, m, torch.empty(B, dtype=torch.float32, device=DEV), torch.empty(B, dtype=torch.uint8, device=DEV)))
+            for i in range(13 * 10):
+                e, m, r, f = sets[i % 13]
+                _lib.check(L.bpg_step_masks(e._h, P(m), P(r), P(f), None))
+            torch.cuda.synchronize()
+        elif w in ('record', 'return', 'episode', 'reward'):
+            env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+            env.reset()
+            m = torch.empty((T, B), dtype=torch.int32, device=DEV)
+            _lib.check(L.bpg_synth_masks(env._h, 0, T, P(m), None))
+            r = torch.empty((T, B), dtype=torch.float32, device=DEV)
+            f = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+            a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr())
+            _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            if w == 'record':
+                ag = torch.empty((B, 36), dtype=torch.float32, device=DEV)
+                sf = torch.empty(B, dtype=torch.float32, device=DEV)
+                for i in range(20):
+                    _lib.check(L.bpg_step_record(env._h, P(m[i]), P(r[i]), P(f[i]), P(sf), P(ag), 36, None))
+            elif w == 'return':
+                G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+                for i in range(10):
+                    _lib.check(L.bpg_discounted_return(P(r), B, T, 0.98, P(G), 0, None))
+            elif w == 'episode':
+                ag = torch.empty((B, T + 1, 36), dtype=torch.float32, device=DEV)
+                gg = torch.empty((B, T, 36), dtype=torch.float32, device=DEV)
+                sc = torch.empty((B, T, 1), dtype=torch.float32, device=DEV)
+                a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(),
+                                      d_ep_success=sc.data_ptr())
+                for i in range(6):
+                    _lib.check(L.bpg_rollout(env._h, C.byref(a3), None))
+            else:
+                n = 4 * B
+                cag = torch.randint(-1, 2, (n, 36), device=DEV).to(torch.float32)
+                cg = env._g[:1].expand(n, 36).contiguous()
+                co = torch.empty(n, dtype=torch.float32, device=DEV)
+                for i in range(10):
+                    _lib.check(L.bpg_compute_reward_f32(P(cag), P(cg), n, 36, P(co), 0, None))
+            torch.cuda.synchronize()
+        else:
+            raise SystemExit('unknown kernel %r' % w)
+    print('done', which)
+
+
+if __name__ == '__main__':
+    main()

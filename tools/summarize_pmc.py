@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into per-kernel HBM bytes.
+
+    python tools/summarize_pmc.py <dir with fetch_*/ and write_*/ runs> <out dir>
+
+Expects (tools/collect_profiles.sh writes them):
+    cal_fetch/  cal_write/      tools/pmc_calibrate           -> bytes-per-count for each access width
+    k_fetch/    k_write/        tools/prof_kernels.py ...     -> every kernel of the path
+    b_fetch/    b_write/        bench.py --steps 8 ...        -> the headline launch as the bench issues it
+Counters are in KiB.  gfx950 under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM section), so
+every kernel's FETCH_SIZE is multiplied by the factor the calibration kernel of the same access
+width shows in the SAME session; WRITE_SIZE likewise (it has been exact so far)."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+from collections import defaultdict
+
+GIB = 1 << 30
+# calibration kernel name fragment -> (known bytes, counter)
+CAL = {
+    'cal_read<HIP_vector_type<unsigned int, 4': (GIB, 'FETCH_SIZE', 'read16'),
+    'cal_read<HIP_vector_type<unsigned int, 2': (GIB, 'FETCH_SIZE', 'read8'),
+    'cal_read<unsigned int>': (GIB, 'FETCH_SIZE', 'read4'),
+    'cal_read_u8': (GIB // 4, 'FETCH_SIZE', 'read1'),
+    'cal_write<HIP_vector_type<unsigned int, 4u>, true': (GIB, 'WRITE_SIZE', 'write16nt'),
+    'cal_write<HIP_vector_type<unsigned int, 4u>, false': (GIB, 'WRITE_SIZE', 'write16'),
+    'cal_write<HIP_vector_type<unsigned int, 2u>, true': (GIB, 'WRITE_SIZE', 'write8nt'),
+    'cal_write<HIP_vector_type<unsigned int, 2u>, false': (GIB, 'WRITE_SIZE', 'write8'),
+    'cal_write<unsigned int, true': (GIB, 'WRITE_SIZE', 'write4nt'),
+    'cal_write<unsigned short, true': (GIB // 4, 'WRITE_SIZE', 'write2nt'),
+    'cal_write<unsigned char, true': (GIB // 8, 'WRITE_SIZE', 'write1nt'),
+    'cal_write<double, false': (GIB, 'WRITE_SIZE', 'write8f64'),
+}
+# kernel name fragment -> (label, read width key, algorithmic read bytes, algorithmic write bytes) at 1 M envs, T = 50
+B, T = 1 << 20, 50
+KERNELS = [
+    ('k_rollout<0, true, 2, 3, true, 5, false', 'k_rollout_masks', 'read8', B * (4 * T + 4), B * (5 * T + 8)),
+    ('k_rollout<1, true, 2, 3, true, 5, false', 'k_rollout_synth', 'read8', 0, B * (5 * T + 8)),
+    ('k_rollout<0, true, 1, 3, true, 10, true', 'k_rollout_masks_65536', 'read4', 65536 * (4 * T + 4), 65536 * (5 * T + 8)),
+    ('k_step_vec4<0>', 'k_step_vec4_masks', 'read16', 12 * B, 13 * B),
+    ('k_step_record<6, 0', 'k_step_record', 'read4', 12 * B, (13 + 4 + 144) * B),
+    ('k_discounted_return_reg<50>', 'k_discounted_return_reg50', 'read4', 4 * T * B, 8 * T * B),
+    ('k_episode<6, 0', 'k_episode', 'read4', B * (4 * T + 8), B * (8 + 4 * (36 * (2 * T + 1) + T))),
+    ('k_compute_reward_f32<true>', 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4),
+    ('k_reset<true>', 'k_reset_obs', 'read4', 8 * B, None),
+]
+
+
+def load(pattern):
+    rows = []
+    for f in glob.glob(pattern, recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def per_kernel(rows, counter):
+    out = defaultdict(list)
+    for r in rows:
+        if r['Counter_Name'] == counter:
+            out[r['Kernel_Name']].append(float(r['Counter_Value']) * 1024.0)
+    return out
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    cal = {}
+    for counter, sub in (('FETCH_SIZE', 'cal_fetch'), ('WRITE_SIZE', 'cal_write')):
+        pk = per_kernel(load(os.path.join(src, sub, '**', '*counter_collection.csv')), counter)
+        for frag, (known, cn, key) in CAL.items():
+            if cn != counter:
+                continue
+            vals = [v for name, vs in pk.items() if frag in name for v in vs]
+            if vals:
+                cal[key] = {'known_bytes': known, 'counter_bytes_median': statistics.median(vals),
+                            'factor': known / statistics.median(vals)}
+    json.dump(cal, open(os.path.join(dst, 'calibration.json'), 'w'), indent=1)
+    res = {}
+    for tag in ('k', 'b'):
+        fetch = per_kernel(load(os.path.join(src, tag + '_fetch', '**', '*counter_collection.csv')), 'FETCH_SIZE')
+        write = per_kernel(load(os.path.join(src, tag + '_write', '**', '*counter_collection.csv')), 'WRITE_SIZE')
+        for frag, label, rkey, aread, awrite in KERNELS:
+            fv = [v for name, vs in fetch.items() if frag in name for v in vs]
+            wv = [v for name, vs in write.items() if frag in name for v in vs]
+            if not fv or not wv:
+                continue
+            rf = cal.get(rkey, {}).get('factor', 2.0 if rkey == 'read16' else 1.0)
+            res['%s%s' % (label, '' if tag == 'k' else '_bench')] = {
+                'launches': [len(fv), len(wv)], 'read_width_calibration': rkey, 'read_factor': rf,
+                'hbm_read_bytes': statistics.median(fv) * rf, 'hbm_write_bytes': statistics.median(wv),
+                'hbm_bytes_per_launch': statistics.median(fv) * rf + statistics.median(wv),
+                'algorithmic_read': aread, 'algorithmic_write': awrite}
+    json.dump(res, open(os.path.join(dst, 'traffic_all_kernels.json'), 'w'), indent=1)
+    head = res.get('k_rollout_masks_bench') or res.get('k_rollout_masks')
+    if head:
+        json.dump({'k_rollout_masks': dict(head, envs=B, T=T,
+                                            method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; '
+                                                   'FETCH_SIZE scaled by the factor an 8-B-per-lane read stream of known '
+                                                   'size shows in the same session (profiles/r02_pmc/calibration.json)',
+                                            algorithmic_bytes_per_launch=B * (9 * T + 12))},
+                  open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+    print(json.dumps(cal, indent=1))
+    for k, v in res.items():
+        print('%-32s read %8.1f MB (alg %s)  write %8.1f MB (alg %s)' % (
+            k, v['hbm_read_bytes'] / 1e6, None if v['algorithmic_read'] is None else round(v['algorithmic_read'] / 1e6, 1),
+            v['hbm_write_bytes'] / 1e6, None if v['algorithmic_write'] is None else round(v['algorithmic_write'] / 1e6, 1)))
+
+
+if __name__ == '__main__':
+    main()

@@ -85,6 +85,52 @@ __global__ void __launch_bounds__(1024) k_mad64(uint32_t *out, unsigned long lon
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// f64: register pairs, written through the C++ operators (FP contraction off on the command line)
+#define F64KERNEL(NAME, EXPR)                                                                        \
+    __global__ void __launch_bounds__(1024) NAME(uint32_t *out, unsigned long long *cyc, uint32_t c)  \
+    {                                                                                                \
+        double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+        const double k = 1.0 + (double)c * 1e-12, m = 0.5;                                          \
+        __syncthreads();                                                                             \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                  \
+        for (int i = 0; i < ITERS; i++) {                                                            \
+            EXPR(x0) EXPR(x1) EXPR(x2) EXPR(x3) EXPR(x4) EXPR(x5) EXPR(x6) EXPR(x7)                  \
+            EXPR(x0) EXPR(x1) EXPR(x2) EXPR(x3) EXPR(x4) EXPR(x5) EXPR(x6) EXPR(x7)                  \
+        }                                                                                            \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                  \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7); \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
+    }
+#define D_MUL(x) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(k));
+#define D_ADD(x) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "v"(m));
+#define D_FMA(x) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(k), "v"(m));
+F64KERNEL(k_dmul, D_MUL)
+F64KERNEL(k_dadd, D_ADD)
+F64KERNEL(k_dfma, D_FMA)
+
+// the discounted-return inner pattern: 8 products by scalar (SGPR-pair) constants into their own
+// registers, then 8 additions into 8 accumulators
+__global__ void __launch_bounds__(1024) k_dpattern(uint32_t *out, unsigned long long *cyc, uint32_t c)
+{
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double p0, p1, p2, p3, p4, p5, p6, p7;
+    const double r = 1.0 + threadIdx.x * 1e-9;
+    double k = 1.0 + (double)c * 1e-12;
+    k = __builtin_bit_cast(double, ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, k) >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(unsigned long long, k)));
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < ITERS; i++) {
+#define PM(p) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(p) : "s"(k), "v"(r));
+#define PA(a, p) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(p));
+        PM(p0) PM(p1) PM(p2) PM(p3) PM(p4) PM(p5) PM(p6) PM(p7)
+        PA(a0, p0) PA(a1, p1) PA(a2, p2) PA(a3, p3) PA(a4, p4) PA(a5, p5) PA(a6, p6) PA(a7, p7)
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 int main()
 {
     uint32_t *out; unsigned long long *cyc;
@@ -97,7 +143,9 @@ int main()
                     {"v_mul_u32_u24", k_mul24, 1}, {"v_mul_hi_u32_u24", k_mulhi24, 1}, {"v_mad_u32_u24", k_mad24, 1},
                     {"v_alignbit_b32", k_alignbit, 1}, {"v_and_or_b32", k_andor, 1}, {"v_perm_b32", k_perm, 1},
                     {"v_bfe_u32", k_bfe, 1}, {"v_lshl_or_b32", k_lshlor, 1}, {"v_cndmask_b32", k_cndmask, 1},
-                    {"v_cmp_eq_u32", k_cmp, 1}};
+                    {"v_cmp_eq_u32", k_cmp, 1},
+                    {"v_mul_f64", k_dmul, 1}, {"v_add_f64", k_dadd, 1}, {"v_fma_f64", k_dfma, 1},
+                    {"8x v_mul_f64 v,s,v + 8x v_add_f64", k_dpattern, 1}};
     printf("%-30s %10s %10s %10s %10s   (shader cycles per wave-instruction per SIMD)\n", "instruction", "1 w/SIMD",
            "2 w/SIMD", "4 w/SIMD", "8 w/CU*");
     for (const K &k : ks) {
