@@ -310,7 +310,9 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     # launch floor of this method (events around a train of back-to-back launches): the library's
     # smallest kernel, a reset of a 1-env batch
     tiny = bpg.make(ENV_ID, num_envs=1, device=dev)
-    res['launch_floor_smallest_kernel'] = {'ms': timed(lambda: _lib.check(L.bpg_reset(tiny._h, None, None, stream)), 200)}
+    ng1 = torch.zeros(1, dtype=torch.int32, device=dev)       # explicit draw: the reset is ONE launch
+    res['launch_floor_smallest_kernel'] = {
+        'ms': timed(lambda: _lib.check(L.bpg_reset(tiny._h, C.c_void_p(ng1.data_ptr()), None, stream)), 200)}
     del tiny
 
     # (0) on-box streaming ceiling: device-to-device copy of one (T,B) u32 array (read + write)

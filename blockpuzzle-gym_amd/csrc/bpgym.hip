@@ -1424,19 +1424,23 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
 }
 
 // ------------------------------ discounted return ---------------------------
-// policy_gradient/rollout.py:255-258.  One env per lane; G[t_] starts as r[t_] and adds
-// gamma**(t-t_) * r[t] for t = t_+1.. in increasing t (float64, products and sums rounded
-// separately, so the result matches the reference's NumPy bit for bit).  gamma**k (C pow, as
-// Python computes it) comes in through the kernel arguments.
+// policy_gradient/rollout.py:255-258: G[t_] starts as r[t_] and adds gamma**(t-t_) * r[t] for
+// t = t_+1.. in increasing t (float64, products and sums rounded separately, so the result matches
+// the reference's NumPy bit for bit).  gamma**k (C pow, as Python computes it) comes in through
+// the kernel arguments.
 //
-// The loop nest is the reference's own: OUTER over the step t that brings a new reward, INNER over
-// the returns t_ < t it is added to.  All T accumulators of an env are live, and the t additions of
-// one outer step are independent of each other -- round 1 had the nest the other way round (one
-// accumulator, a serial chain of 2 * (T-1-t_) dependent f64 operations per return), which left a
-// wave waiting out the full latency of every mul and add: 0.46 of HBM peak at 255 VGPRs.  Here
-// the rewards are consumed as they arrive, the live set is T accumulators + the rewards not
-// yet used, and the 64 x T tile that turns the per-lane rows into contiguous 8-byte-per-lane
-// stores is staged through LDS in two halves (13 KB per wave instead of 26 KB).
+// The loop nest is the reference's own -- OUTER over the step t that brings a new reward, INNER over
+// the returns t_ < t it is added to -- so the additions of one outer step are independent chains.
+// That matters because an f64 result is ~60 cycles away on gfx950 (tools/valu_rates.hip: eight
+// independent products followed by eight additions still run at 8.6 cycles per instruction for a
+// wave on its own, 3.4 with four waves per SIMD): round 1's nest (one accumulator, 2 * (T-1-t_)
+// dependent operations per return, 255 VGPRs, one wave per SIMD) spent 59 % of its wave cycles in
+// issue stalls.  What it takes is occupancy, so each env is split over TWO lanes:
+//   lane (e, q), q = lane / 32, owns the returns t_ = 2i + q and consumes the reward of step
+//   t = s + q at "virtual step" s.  Then acc[i] += pw[s - 2i] * r[t] has the SAME table index for
+//   both halves of the wave (t - t_ = s - 2i either way): one instruction stream, uniform (SGPR)
+//   constants, 25 instead of 50 accumulators per lane -> ~100 VGPRs, 3-4 waves per SIMD.
+// Products are issued DR_W at a time into their own registers before the DR_W additions.
 constexpr int DR_TMAX_REG = 64;
 constexpr int DR_W = 16;
 struct PowTable { double v[DR_TMAX_REG]; };
@@ -1453,84 +1457,75 @@ template <int TT>
 __global__ void __launch_bounds__(64)
 k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable pw, double *__restrict__ G)
 {
-    constexpr int H = (TT + 1) / 2;           // rows per store pass
-    constexpr int R = H | 1;                  // odd row stride: conflict-free ds_write_b64
-    __shared__ double tile[64 * R];
-    const int lane = threadIdx.x;
-    const int64_t ntiles = (n + 63) / 64;
-    // Persistent one-wave blocks walk the 64-env tiles; the rewards of the NEXT tile are requested
-    // before the ~2 450 f64 operations of the current one, so no wave ever sits out a memory round
-    // trip (with one tile per block, 2.9 resident waves per SIMD left the VALU idle half the time).
-    // The last trip re-requests its own tile: an unconditional prefetch keeps the wait counts exact.
-    auto request = [&](int64_t tl, float *rf) {
-        // one per-lane pointer walked down the rows (the empty asm keeps it ONE register pair: the
-        // gamma**k table fills the SGPR file, so per-row bases would otherwise become 50 VGPR pairs
-        // that stay alive across the tile loop)
-        const int64_t base = tl * 64;
-        const bool ok = base + lane < n;
-        typedef const float __attribute__((address_space(1))) *gptr;      // stays a global_load behind the asm
-        gptr p = (gptr)(reward_tb + base + (ok ? lane : 0));
-        static_for<0, TT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            rf[t] = *p;
+    constexpr int NI = (TT + 1) / 2;          // accumulators per lane (half 1 leaves the last one unused when T is odd)
+    constexpr int R = TT | 1;                 // odd row stride of the 16 x T tile
+    __shared__ double tile[16 * R];
+    const int lane = threadIdx.x, e = lane & 31, q = lane >> 5;
+    const int64_t base = (int64_t)blockIdx.x * 32;
+    const int nvalid = (int)((n - base) < 32 ? (n - base) : 32);
+    const bool live = e < nvalid;
+    // rw[s] = reward of step s + q.  One per-lane pointer walked down the rows (the empty asm keeps
+    // it ONE register pair: the gamma**k table fills the SGPR file, so per-row bases would otherwise
+    // become T VGPR pairs)
+    float rw[TT];
+    {
+        typedef const float __attribute__((address_space(1))) *gptr;
+        gptr p = (gptr)(reward_tb + (int64_t)q * n + base + (live ? e : 0));
+        static_for<0, TT>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            rw[s] = (s + 1 < TT || q == 0) ? *p : 0.0f;
             p += n;
             asm volatile("" : "+v"(p));
         });
-    };
-    float cur[TT], nxt[TT];
-    int64_t tl = blockIdx.x;
-    if (tl < ntiles) request(tl, cur);
-    for (; tl < ntiles; tl += gridDim.x) {
-        const int64_t tn = tl + gridDim.x < ntiles ? tl + gridDim.x : tl;
-        request(tn, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        const int64_t base = tl * 64;
-        const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-        double acc[TT];
-        // products eight at a time into their own registers, then the eight additions (an f64
-        // result is ~20 cycles away; eight independent products cover that for a wave on its own)
-        static_for<0, TT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const double rt = (double)cur[t];
-            acc[t] = rt;
-            static_for<0, (t + DR_W - 1) / DR_W>([&](auto gc) {
-                constexpr int t0 = decltype(gc)::value * DR_W;
-                constexpr int cnt = (t - t0) < DR_W ? (t - t0) : DR_W;
+    }
+    double acc[NI];
+    static_for<0, TT>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        // half 1 is one step ahead: its last virtual step would be t = T
+        if (s + 1 < TT || q == 0) {
+            const double rt = (double)rw[s];
+            if constexpr (s % 2 == 0) acc[s / 2] = rt;                     // t_ == t: G[t_] starts as r[t_]
+            constexpr int npair = (s + 1) / 2;                             // returns 2i (+q) < t
+            static_for<0, (npair + DR_W - 1) / DR_W>([&](auto gc) {
+                constexpr int i0 = decltype(gc)::value * DR_W;
+                constexpr int cnt = (npair - i0) < DR_W ? (npair - i0) : DR_W;
                 double prod[DR_W];
                 static_for<0, cnt>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    prod[j] = pw.v[t - t0 - j] * rt;
+                    constexpr int i = i0 + decltype(jc)::value;
+                    prod[decltype(jc)::value] = pw.v[s - 2 * i] * rt;
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, cnt>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    acc[t0 + j] = acc[t0 + j] + prod[j];
+                    constexpr int i = i0 + decltype(jc)::value;
+                    acc[i] = acc[i] + prod[decltype(jc)::value];
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-        });
-        double *o = G + base * (int64_t)TT;
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-            const int r0 = pass * H, cnt = (TT - r0) < H ? (TT - r0) : H;
-            __syncthreads();                                 // the tile's previous contents streamed out
-            if (lane < nvalid) {
-                static_for<0, H>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    if (r0 + j < TT) tile[lane * R + j] = acc[pass ? (H + j < TT ? H + j : 0) : j];
-                });
-            }
-            __syncthreads();
-            const int total = nvalid * cnt;
-            int e = 0, rem = lane;
-            while (rem >= cnt) { rem -= cnt; e++; }
-            for (int f = lane; f < total; f += 64) {
-                o[(int64_t)e * TT + r0 + rem] = tile[e * R + rem];
-                rem += 64;
-                while (rem >= cnt) { rem -= cnt; e++; }
-            }
         }
-        static_for<0, TT>([&](auto tc) { cur[decltype(tc)::value] = nxt[decltype(tc)::value]; });
+    });
+    // 16 envs x T at a time through LDS (6.5 KB per wave: the LDS does not cap the occupancy below
+    // what the registers allow), each pass streamed out as one contiguous 16 * T * 8-byte piece of G
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int e0 = pass * 16;
+        if (pass) __syncthreads();                       // first half streamed out
+        if (live && (e >> 4) == pass) {
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (2 * i + q < TT) tile[(e - e0) * R + 2 * i + q] = acc[i];
+            });
+        }
+        __syncthreads();
+        const int rows = nvalid - e0 < 16 ? (nvalid - e0 < 0 ? 0 : nvalid - e0) : 16;
+        double *o = G + (base + e0) * (int64_t)TT;
+        const int total = rows * TT;
+        int ee = 0, rem = lane;
+        while (rem >= TT) { rem -= TT; ee++; }
+        for (int f = lane; f < total; f += 64) {
+            o[f] = tile[ee * R + rem];
+            rem += 64;
+            while (rem >= TT) { rem -= TT; ee++; }
+        }
     }
 }
 
@@ -2358,12 +2353,11 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
     if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
     DeviceGuard guard(device_id);
-    const int64_t ntiles = (n + 63) / 64;
-    const dim3 grid((unsigned)ntiles), block(64);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     if (T == 50 || T == 25 || T == 10) {
-        // persistent one-wave blocks, 8 per CU (two waves per SIMD: ~200 VGPRs each)
-        const dim3 pgrid((unsigned)(ntiles < 2048 ? ntiles : 2048));
-        // register-resident fast path for the horizons in use (T = max_episode_steps = 50)
+        // register-resident fast path for the horizons in use (T = max_episode_steps = 50): 32 envs per
+        // one-wave block, two lanes per env
+        const dim3 pgrid((unsigned)((n + 31) / 32));
         PowTable tab;
         std::memset(&tab, 0, sizeof(tab));
         for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
