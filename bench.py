@@ -366,7 +366,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     def step_record():
         _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
                                      C.c_void_p(flags.data_ptr()), C.c_void_p(succ_f.data_ptr()),
-                                     C.c_void_p(agrec.data_ptr()), env.dimg, stream))
+                                     C.c_void_p(agrec.data_ptr()), env.dimg, None, None, stream))
     res['step_record_single_launch'] = line(timed(step_record, 100), (29 + 4 * env.dimg) * B, B)
     del agrec, succ_f
 

@@ -885,7 +885,8 @@ template <int SIDE, int SRC, bool VEC4>
 __global__ void __launch_bounds__(64)
 k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
               uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, float *__restrict__ succ_f32,
-              float *__restrict__ ag, int64_t ld, int64_t n, StepConst c, SynthConst s, PairTable tabv)
+              float *__restrict__ ag, int64_t ld, int64_t n, StepConst c, SynthConst s, PairTable tabv,
+              const float4 *__restrict__ u_in, float4 *__restrict__ u_out)
 {
     constexpr int DIMG = SIDE * SIDE;
     __shared__ uint2 hist[64];
@@ -904,6 +905,7 @@ k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
         if (reward) reward[i] = rb;
         if (flags) flags[i] = (uint8_t)fl;
         if (succ_f32) succ_f32[i] = (fl & BPG_FLAG_SUCCESS) ? 1.0f : 0.0f;
+        if (u_out) u_out[i] = u_in[i];              // acts.append(u.copy()) of rollout.py:147, same launch
     }
     __syncthreads();
     if (!ag) return;
@@ -2013,9 +2015,11 @@ int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t
 }
 
 int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, float *d_success_f32,
-                    float *d_ag, int64_t ld, void *stream)
+                    float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out, void *stream)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if ((d_u_out != nullptr) != (d_u_in != nullptr)) return fail(BPG_ERR_ARG, "d_u_in and d_u_out go together");
+    if (!aligned16(d_u_in) || !aligned16(d_u_out)) return fail(BPG_ERR_ARG, "action buffers must be 16-byte aligned");
     if (d_ag && ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
     if (!aligned4(d_masks) || !aligned4(d_reward) || !aligned4(d_success_f32) || !aligned4(d_ag))
         return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
@@ -2033,7 +2037,8 @@ int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint
         constexpr bool EVEN = (S % 2 == 0);
 #define BPG_LAUNCH_SR(SRC, V)                                                                                  \
         hipLaunchKernelGGL((k_step_record<S, SRC, V>), grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags, \
-                           d_success_f32, d_ag, ld, b->n, c, s, tab)
+                           d_success_f32, d_ag, ld, b->n, c, s, tab, reinterpret_cast<const float4 *>(d_u_in),     \
+                           reinterpret_cast<float4 *>(d_u_out))
         if (synth) {
             if (vec) BPG_LAUNCH_SR(SRC_SYNTH, EVEN); else BPG_LAUNCH_SR(SRC_SYNTH, false);
         } else {

@@ -388,7 +388,8 @@ class BatchedBlocksEnv:
         self._place(test=False, env_mask=em, variates=variates)
         return self._get_obs()
 
-    def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None):
+    def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None,
+                   u_out=None):
         """Launches one env step; returns (reward, flags, achieved_goal) device tensors."""
         a = self._to_dev(action, torch.float32)
         if a is not None:
@@ -427,6 +428,8 @@ class BatchedBlocksEnv:
             _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), int(ag.stride(0)), st))
             if succ_out is not None:
                 succ_out.copy_((flags & _lib.FLAG_SUCCESS).reshape(succ_out.shape))
+            if u_out is not None:
+                u_out.copy_(a)
         else:
             m = None
             if contact_masks is not None:
@@ -437,8 +440,12 @@ class BatchedBlocksEnv:
             if succ_out is not None:
                 assert succ_out.numel() == self.num_envs and succ_out.is_contiguous() and succ_out.dtype == torch.float32
             # step + float achieved_goal (+ float success) in one launch; NULL masks = synthetic source
+            u_in = None
+            if u_out is not None:        # the episode's action slot is filled by the step launch itself
+                assert a is not None and u_out.shape == a.shape and u_out.is_contiguous() and self.dimu == 4
+                u_in = a if a.is_contiguous() else a.contiguous()
             _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
-                                               _ptr(ag), int(ag.stride(0)), st))
+                                               _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), st))
         return reward, flags, ag
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):

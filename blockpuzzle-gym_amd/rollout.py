@@ -205,7 +205,7 @@ class RolloutStudent:
             return o
         return self.initial_o.clone()[None].expand(T + 1, B, self.dims['o'])
 
-    def _step_into(self, u, ep, t, reward_out=None):
+    def _step_into(self, u, ep, t, reward_out=None, u_store=None):
         """One env step that writes obs['achieved_goal'] / info['is_success'] (and, through the
         backend, obs['observation']; optionally the step reward) straight into time slot t+1 / t
         of the episode."""
@@ -214,7 +214,7 @@ class RolloutStudent:
             own, env.observation = env.observation, ep['o'][t + 1]
             try:
                 r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                         reward_out=reward_out)
+                                         reward_out=reward_out, u_out=u_store)
             finally:
                 env.observation = own
             slot = ep['o'][t + 1]
@@ -222,7 +222,7 @@ class RolloutStudent:
                                                    _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out)
+                                     reward_out=reward_out, u_out=u_store)
         return r
 
     def _rollout_body(self, test, num_grey, compute_Attention=False):
@@ -249,9 +249,9 @@ class RolloutStudent:
             else:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
-            ep['u'][t] = u
-            # reward ignored: recomputed for HER (rollout.py:123-125)
-            self._step_into(u, ep, t)
+            # reward ignored: recomputed for HER (rollout.py:123-125); the step launch also stores the
+            # actions into the episode's slot (acts.append(u.copy()), rollout.py:147)
+            self._step_into(u, ep, t, u_store=ep['u'][t])
         if self._watch_o:
             self.initial_o.copy_(ep['o'][T])                       # rollout.py:153 `self.initial_o[:] = o`
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views

@@ -157,12 +157,15 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
 int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
                           uint32_t *d_masks, void *stream);
 
-/* One env.step exactly as the rollout worker consumes it (rollout.py:121-131), in ONE launch:
- * the step of bpg_step_masks (d_masks NULL = synthetic source) plus obs['achieved_goal'] as
- * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32) and
- * info['is_success'] as float32 d_success_f32[n_envs].  Every output pointer is optional. */
+/* One env.step exactly as the rollout worker consumes it (rollout.py:121-131, :144-150), in ONE
+ * launch: the step of bpg_step_masks (d_masks NULL = synthetic source) plus obs['achieved_goal'] as
+ * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32),
+ * info['is_success'] as float32 d_success_f32[n_envs], and the step's actions d_u_in (n_envs, 4)
+ * float32 stored into the episode's action slot d_u_out (`acts.append(u.copy())`, rollout.py:147).
+ * Every output pointer is optional (d_u_in / d_u_out go together). */
 int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
-                    float *d_success_f32, float *d_ag, int64_t ld, void *stream);
+                    float *d_success_f32, float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out,
+                    void *stream);
 
 /* One step whose contacts come from the build-defined counter-based synthetic
  * source keyed (seed, global env id, elapsed step) -- physics stand-in for

@@ -83,7 +83,7 @@ def main():
                 ag = torch.empty((B, 36), dtype=torch.float32, device=DEV)
                 sf = torch.empty(B, dtype=torch.float32, device=DEV)
                 for i in range(20):
-                    _lib.check(L.bpg_step_record(env._h, P(m[i]), P(r[i]), P(f[i]), P(sf), P(ag), 36, None))
+                    _lib.check(L.bpg_step_record(env._h, P(m[i]), P(r[i]), P(f[i]), P(sf), P(ag), 36, None, None, None))
             elif w == 'return':
                 G = torch.empty((B, T), dtype=torch.float64, device=DEV)
                 for i in range(10):
