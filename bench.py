@@ -237,6 +237,20 @@ def main():
         if t and t.get('envs') == B and t.get('T') == T:
             traffic = t['hbm_bytes_per_launch']
 
+    # rocprofv3 --kernel-trace --stats means of the committed profile of this same command
+    # (tools/collect_profiles.sh -> profiles/r02_pmc/kernel_means.json), quoted beside the live HIP-event figures
+    prof_means = {}
+    mf = os.path.join(ROOT, 'profiles', 'r02_pmc', 'kernel_means.json')
+    if os.path.exists(mf):
+        prof_means = json.load(open(mf))
+
+    def rocprof_of(label, nbytes):
+        m = prof_means.get(label)
+        if not m:
+            return None
+        return {'mean_us': m['mean_us'], 'calls': m['calls'],
+                'frac_hbm_peak': nbytes / (m['mean_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'source': 'profiles/r02_pmc/kernel_means.json'}
+
     out = {
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
@@ -253,7 +267,8 @@ def main():
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, 2 envs/lane, reward+flags, reset>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
-                     'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms},
+                     'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms,
+                     'rocprofv3_committed': rocprof_of('k_rollout_masks_bench', bytes_per_launch) if B == (1 << 20) and T == 50 else None},
     }
 
     if rank == 0 and world == 1 and not a.no_extras:
@@ -267,8 +282,8 @@ def main():
                 'bound': 'hbm', 'kernel': 'k_step_vec4<masks>', 'bytes_per_env_step': 25,
                 'achieved': one['GB/s'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': one['GB/s'] / HBM_PEAK_GBS, 'kernel_ms': one['ms'],
-                'how': '13 independent 1 M-env batches stepped round-robin (HBM-cold), events around a train of '
-                       'launches; the rocprofv3 mean of the same kernel is in profiles/',
+                'how': '13 independent 1 M-env batches stepped round-robin (HBM-cold), events around a train of launches',
+                'rocprofv3_committed': rocprof_of('k_step_vec4_masks', 25 * B) if B == (1 << 20) else None,
                 'graph_replay_of_T_launches': {k: grp.get(k) for k in ('ms', 'GB/s', 'frac_hbm_peak',
                                                                       'env_steps_per_sec')}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

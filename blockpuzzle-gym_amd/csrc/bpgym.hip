@@ -1466,18 +1466,16 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable
     const int64_t base = (int64_t)blockIdx.x * 32;
     const int nvalid = (int)((n - base) < 32 ? (n - base) : 32);
     const bool live = e < nvalid;
-    // rw[s] = reward of step s + q.  One per-lane pointer walked down the rows (the empty asm keeps
-    // it ONE register pair: the gamma**k table fills the SGPR file, so per-row bases would otherwise
-    // become T VGPR pairs)
+    // rw[s] = reward of step s + q.  Row bases are uniform (scalar unit), the per-lane part is ONE
+    // 32-bit byte offset (env within the row, plus one row for the upper half of the wave): no
+    // per-load address arithmetic on the vector unit.  The host guarantees 8 * n < 2^32.
     float rw[TT];
     {
-        typedef const float __attribute__((address_space(1))) *gptr;
-        gptr p = (gptr)(reward_tb + (int64_t)q * n + base + (live ? e : 0));
+        const uint32_t voff = (uint32_t)((int64_t)q * n + base + (live ? e : 0)) * 4u;
         static_for<0, TT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            rw[s] = (s + 1 < TT || q == 0) ? *p : 0.0f;
-            p += n;
-            asm volatile("" : "+v"(p));
+            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)s * n);
+            rw[s] = (s + 1 < TT || q == 0) ? *reinterpret_cast<const float *>(row + voff) : 0.0f;
         });
     }
     double acc[NI];
@@ -2359,7 +2357,7 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
     DeviceGuard guard(device_id);
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (T == 50 || T == 25 || T == 10) {
+    if ((T == 50 || T == 25 || T == 10) && n < ((int64_t)1 << 28)) {
         // register-resident fast path for the horizons in use (T = max_episode_steps = 50): 32 envs per
         // one-wave block, two lanes per env
         const dim3 pgrid((unsigned)((n + 31) / 32));

@@ -102,6 +102,17 @@ def main():
                                                    'size shows in the same session (profiles/r02_pmc/calibration.json)',
                                             algorithmic_bytes_per_launch=B * (9 * T + 12))},
                   open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+    # rocprofv3 --kernel-trace --stats means of the same kernels (what bench.py quotes beside its HIP-event figures)
+    means = {}
+    for sub, suffix in (('trace_kernels', ''), ('trace_headline', '_bench')):
+        for f in glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                for frag, label, _, aread, awrite in KERNELS:
+                    if frag in r['Name'] and not (label == 'k_rollout_masks' and not suffix):   # that trace mixes 1 M and 512 K launches
+                        means[label + suffix] = {'calls': int(r['Calls']), 'mean_us': float(r['AverageNs']) / 1e3,
+                                                 'min_us': float(r['MinNs']) / 1e3,
+                                                 'algorithmic_bytes': None if awrite is None else aread + awrite}
+    json.dump(means, open(os.path.join(dst, 'kernel_means.json'), 'w'), indent=1)
     print(json.dumps(cal, indent=1))
     for k, v in res.items():
         print('%-32s read %8.1f MB (alg %s)  write %8.1f MB (alg %s)' % (
