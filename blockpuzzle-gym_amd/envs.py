@@ -419,33 +419,30 @@ class BatchedBlocksEnv:
         else:
             ag = ag_out
             assert ag.shape == (self.num_envs, self.dimg) and ag.dtype == torch.float32 and ag.stride(1) == 1
+        m = None
         if contacts is not None:
+            # geom-id contact lists as the reference reads them (fetch_env.py:158-166): one launch maps
+            # them through id2obj to pair masks, the step launch below consumes those
             pairs = self._to_dev(contacts[0], torch.int16)
             ncon = self._to_dev(contacts[1], torch.int32)
             assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
-            _lib.check(self._L.bpg_step_contacts(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]),
-                                                 _ptr(reward), _ptr(flags), st))
-            _lib.check(self._L.bpg_get_achieved_goal_f32(self._h, _ptr(ag), int(ag.stride(0)), st))
-            if succ_out is not None:
-                succ_out.copy_((flags & _lib.FLAG_SUCCESS).reshape(succ_out.shape))
-            if u_out is not None:
-                u_out.copy_(a)
-        else:
-            m = None
-            if contact_masks is not None:
-                m = contact_masks.to(self.device).contiguous() if (
-                    torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
-                ) else self._to_dev(contact_masks, torch.int32)
-                assert m.numel() == self.num_envs
-            if succ_out is not None:
-                assert succ_out.numel() == self.num_envs and succ_out.is_contiguous() and succ_out.dtype == torch.float32
-            # step + float achieved_goal (+ float success) in one launch; NULL masks = synthetic source
-            u_in = None
-            if u_out is not None:        # the episode's action slot is filled by the step launch itself
-                assert a is not None and u_out.shape == a.shape and u_out.is_contiguous() and self.dimu == 4
-                u_in = a if a.is_contiguous() else a.contiguous()
-            _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
-                                               _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), st))
+            m = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+            _lib.check(self._L.bpg_contacts_to_masks(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]), _ptr(m), st))
+        elif contact_masks is not None:
+            m = contact_masks.to(self.device).contiguous() if (
+                torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
+            ) else self._to_dev(contact_masks, torch.int32)
+            assert m.numel() == self.num_envs
+        if succ_out is not None:
+            assert succ_out.numel() == self.num_envs and succ_out.is_contiguous() and succ_out.dtype == torch.float32
+        u_in = None
+        if u_out is not None:        # the episode's action slot is filled by the step launch itself
+            assert a is not None and u_out.shape == a.shape and u_out.is_contiguous() and self.dimu == 4
+            u_in = a if a.is_contiguous() else a.contiguous()
+        # step + float achieved_goal (+ float success, + the action store) in one launch; NULL masks =
+        # the synthetic source
+        _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
+                                           _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), st))
         return reward, flags, ag
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):
