@@ -144,8 +144,10 @@ class RolloutStudent:
         return ep
 
     def _finish(self, episode, Qs=()):
-        succ_last = episode['info_is_success'][:, -1, 0]
-        success_rate = float(succ_last.mean().item())           # rollout.py:163-167
+        # rollout.py:163-167 `successful = successes[-1]; success_rate = np.mean(successful)`: the last
+        # column of info_is_success is the has_succeeded latch of the state the rollout ended in, so
+        # the mean is the HIP success count over B (exact in float64, as NumPy's mean of 0/1 values)
+        success_rate = float(self.env.success_count().item()) / self.rollout_batch_size
         self.success_history.append(success_rate)
         if self.compute_Q and len(Qs):
             self.Q_history.append(float(np.mean([float(np.mean(q.detach().cpu().numpy() if torch.is_tensor(q) else q))
