@@ -959,6 +959,35 @@ k_contacts_to_masks(const uint32_t *__restrict__ ever, const int16_t *__restrict
     }
 }
 
+// The same for RAGGED lists (CSR): env i owns contacts offsets[i] .. offsets[i+1]-1 of one packed
+// (total, 2) geom-id array -- what a physics backend produces when it compacts sim.data.contact
+// of all envs instead of padding every env to the longest list.  Consecutive lanes own consecutive
+// segments, so a wave's loads fall into one contiguous stretch of the array.
+__global__ void __launch_bounds__(256)
+k_contacts_csr_to_masks(const uint32_t *__restrict__ ever, const uint32_t *__restrict__ pairs,
+                        const int64_t *__restrict__ offsets, int64_t total, const int8_t *__restrict__ id2obj,
+                        int is_variation, uint32_t valid, uint32_t *__restrict__ out, int64_t n)
+{
+    __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
+    for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int model = 0;
+        if (is_variation) {
+            model = (int)nobj_of(ever[i]) - 4;
+            model = model < 0 ? 0 : (model > 2 ? 2 : model);
+        }
+        const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
+        int64_t lo = offsets[i], hi = offsets[i + 1];
+        lo = lo < 0 ? 0 : (lo > total ? total : lo);                 // never index outside the packed array
+        hi = hi < lo ? lo : (hi > total ? total : hi);
+        uint32_t m = 0;
+        for (int64_t k = lo; k < hi; k++) m |= pair_bit_of(tab, pairs[k]);
+        out[i] = m & valid;
+    }
+}
+
 // ------------------------------ observation assembly ------------------------
 // obs['observation'] of _get_obs (fetch_env.py:187-228, Variation :567-621) from the
 // quantities the reference reads off the simulator.  One output element per lane
@@ -2010,6 +2039,23 @@ int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t
                        d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
                        b->n);
     return check_launch("k_contacts_to_masks");
+}
+
+int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_t *d_offsets, int64_t total,
+                              uint32_t *d_masks, void *stream)
+{
+    if (!b || !d_offsets || !d_masks || (!d_pairs && total > 0)) return fail(BPG_ERR_ARG, "NULL argument");
+    if (total < 0) return fail(BPG_ERR_ARG, "total < 0");
+    if (!aligned4(d_pairs) || !aligned4(d_masks) || ((uintptr_t)d_offsets & 7u))
+        return fail(BPG_ERR_ARG, "pairs / masks must be 4-byte, offsets 8-byte aligned");
+    const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
+    for (int m = 0; m < models; m++)
+        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_contacts_csr_to_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
+                       reinterpret_cast<const uint32_t *>(d_pairs), d_offsets, total, b->d_id2obj, b->info.is_variation,
+                       b->info.valid_pairs, d_masks, b->n);
+    return check_launch("k_contacts_csr_to_masks");
 }
 
 int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, float *d_success_f32,

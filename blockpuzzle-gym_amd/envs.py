@@ -14,7 +14,8 @@ stepped by one HIP kernel launch.
 Boundary: contacts-in.  MuJoCo (robot_env.py:60) is a closed third-party binary
 outside the reference tree; each step consumes the step's contact set, either
   * packed pair masks           step(u, contact_masks=uint32[B])
-  * geom-id pair lists          step(u, contacts=(int16[B,maxcon,2], int32[B]))
+  * geom-id pair lists          step(u, contacts=(int16[B,maxcon,2], int32[B]))   padded, or
+                                step(u, contacts=(int16[total,2], int64[B+1]))    ragged (CSR offsets)
     (what fetch_env.py:158-167 reads from sim.data.contact), or
   * the env's `contact_source`  (default: the build-defined synthetic source).
 `observation` has no physics behind it: it is zero except for the entries the
@@ -424,10 +425,17 @@ class BatchedBlocksEnv:
             # geom-id contact lists as the reference reads them (fetch_env.py:158-166): one launch maps
             # them through id2obj to pair masks, the step launch below consumes those
             pairs = self._to_dev(contacts[0], torch.int16)
-            ncon = self._to_dev(contacts[1], torch.int32)
-            assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
             m = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
-            _lib.check(self._L.bpg_contacts_to_masks(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]), _ptr(m), st))
+            if pairs.dim() == 2:
+                # ragged (CSR) form: pairs (total, 2), second element = offsets (B+1,) int64
+                offsets = self._to_dev(contacts[1], torch.int64)
+                assert pairs.shape[1] == 2 and offsets.shape == (self.num_envs + 1,)
+                _lib.check(self._L.bpg_contacts_csr_to_masks(self._h, _ptr(pairs), _ptr(offsets), int(pairs.shape[0]),
+                                                             _ptr(m), st))
+            else:
+                ncon = self._to_dev(contacts[1], torch.int32)
+                assert pairs.dim() == 3 and pairs.shape[0] == self.num_envs and pairs.shape[2] == 2
+                _lib.check(self._L.bpg_contacts_to_masks(self._h, _ptr(pairs), _ptr(ncon), int(pairs.shape[1]), _ptr(m), st))
         elif contact_masks is not None:
             m = contact_masks.to(self.device).contiguous() if (
                 torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)

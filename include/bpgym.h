@@ -157,6 +157,13 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
 int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
                           uint32_t *d_masks, void *stream);
 
+/* The same from RAGGED contact lists (CSR): env e owns contacts d_offsets[e] .. d_offsets[e+1]-1
+ * (int64, n_envs+1 entries, non-decreasing) of one packed d_pairs[total][2] int16 geom-id array --
+ * sim.data.contact of every env compacted instead of padded to the longest list.  Offsets are
+ * clamped to 0..total, so a malformed table cannot index outside d_pairs. */
+int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_t *d_offsets, int64_t total,
+                              uint32_t *d_masks, void *stream);
+
 /* One env.step exactly as the rollout worker consumes it (rollout.py:121-131, :144-150), in ONE
  * launch: the step of bpg_step_masks (d_masks NULL = synthetic source) plus obs['achieved_goal'] as
  * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32),

@@ -528,3 +528,58 @@ def test_seeding_contract():
     hi = draws(bpg.make(env_id, num_envs=B // 2, device=DEV, seed=42, env_id_base=B // 2))
     for k in range(3):
         assert torch.equal(torch.cat([lo[k], hi[k]], 0 if k != 1 else 1), first[k])
+
+
+# --------------------------------------------------------------------------
+# ragged (CSR) contact lists
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('env_id', ['BlocksTouchVariation-v0', 'ToppleTower-v0', 'GripperTouch-v0'])
+def test_ragged_contact_lists_vs_oracle(env_id):
+    """sim.data.contact of all envs compacted into one (total, 2) geom-id array with CSR offsets
+    (0..40 contacts per env, many envs with none) == the oracle's per-env list form, step after
+    step; a malformed offset table is clamped instead of indexing outside the array."""
+    v = VARIANTS[env_id]
+    B, T = 500, 12
+    rng = np.random.RandomState(7)
+    env = bpg.make(env_id, num_envs=B, device=DEV)
+    oenvs = [O.OracleEnv(env_id) for _ in range(B)]
+    num_grey = rng.randint(3, size=B).astype(np.int32)
+    env.reset(num_grey=num_grey)
+    for e, g in zip(oenvs, num_grey):
+        e.reset(num_grey=int(g))
+    model = num_grey if 'Variation' in env_id else np.zeros(B, np.int32)
+    ngeom = np.array([len(v['models'][m]['id2obj']) for m in model])
+    for t in range(T):
+        ncon = rng.randint(0, 41, size=B) * (rng.rand(B) < 0.6)
+        offsets = np.concatenate([[0], np.cumsum(ncon)]).astype(np.int64)
+        total = int(offsets[-1])
+        owner = np.repeat(np.arange(B), ncon.astype(np.int64))
+        pairs = (rng.randint(0, 1 << 30, size=(total, 2)) % ngeom[owner][:, None]).astype(np.int16)
+        obs, r, done, info = env.step(None, contacts=(pairs, offsets))
+        exp = [e.step(v['models'][int(m)]['id2obj'], pairs[offsets[b]:offsets[b + 1]])
+               for b, (e, m) in enumerate(zip(oenvs, model))]
+        np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), np.stack([x[0] for x in exp]).astype(np.float32))
+        np.testing.assert_array_equal(bits(r), np.array([np.float32(x[1]).view(np.uint32) for x in exp]))
+        np.testing.assert_array_equal(info['is_success'].cpu().numpy(), np.array([x[3] for x in exp]))
+    # the CSR launch == the padded launch on the same lists
+    L = bpg._lib.lib()
+    maxcon = 40
+    pad = np.zeros((B, maxcon, 2), np.int16)
+    for b in range(B):
+        pad[b, :offsets[b + 1] - offsets[b]] = pairs[offsets[b]:offsets[b + 1]]
+    m1 = torch.empty(B, dtype=torch.int32, device=DEV)
+    m2 = torch.empty(B, dtype=torch.int32, device=DEV)
+    dp, do = torch.as_tensor(pairs, device=DEV), torch.as_tensor(offsets, device=DEV)
+    dpad, dn = torch.as_tensor(pad, device=DEV), torch.as_tensor(np.diff(offsets).astype(np.int32), device=DEV)
+    bpg._lib.check(L.bpg_contacts_csr_to_masks(env._h, C.c_void_p(dp.data_ptr()), C.c_void_p(do.data_ptr()), total,
+                                               C.c_void_p(m1.data_ptr()), None))
+    bpg._lib.check(L.bpg_contacts_to_masks(env._h, C.c_void_p(dpad.data_ptr()), C.c_void_p(dn.data_ptr()), maxcon,
+                                           C.c_void_p(m2.data_ptr()), None))
+    assert torch.equal(m1, m2)
+    # offsets beyond the array / decreasing: clamped, no fault
+    bad = offsets.copy(); bad[B // 2] = -5; bad[B // 2 + 1] = total + 1000; bad[-1] = total + 7
+    dbad = torch.as_tensor(bad, device=DEV)
+    bpg._lib.check(L.bpg_contacts_csr_to_masks(env._h, C.c_void_p(dp.data_ptr()), C.c_void_p(dbad.data_ptr()), total,
+                                               C.c_void_p(m1.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert torch.equal(m1[:B // 2 - 1], m2[:B // 2 - 1])
