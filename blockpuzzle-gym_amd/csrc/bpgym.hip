@@ -616,6 +616,17 @@ template <int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec pack(co
     else if constexpr (EPL == 2) return make_uint2(o[0], o[1]);
     else return o[0];
 }
+// mask stream: read exactly once per launch -> nontemporal loads (tools/tune_geometry.hip: NTL)
+template <bool NTL, int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec ld_vec(const typename LaneVec<EPL>::vec *p)
+{
+    if constexpr (!NTL) return *p;
+    else if constexpr (EPL == 4)
+        return make_uint4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y),
+                          __builtin_nontemporal_load(&p->z), __builtin_nontemporal_load(&p->w));
+    else if constexpr (EPL == 2) return make_uint2(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y));
+    else return __builtin_nontemporal_load(p);
+}
+
 template <bool NT, int EPL> __device__ __forceinline__ void st_vec(typename LaneVec<EPL>::vec *p, const uint32_t *o)
 {
     if constexpr (EPL == 4) st_u4<NT>(p, make_uint4(o[0], o[1], o[2], o[3]));
@@ -637,7 +648,7 @@ enum { OUT_REWARD = 1, OUT_FLAGS = 2 };
 // RESET: the launch starts with reset_all_rollouts (rollout.py:79).  Compile-time because the
 // elapsed counter is then the same for every lane (step t of the launch), so the time-limit
 // test, the saturation and the generator's Weyl term run on the scalar unit.
-template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL = 5, bool PIPE = (EPL < 4)>
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL = 5, bool PIPE = (EPL < 4), bool NTL = true>
 __global__ void __launch_bounds__(1024)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
@@ -710,12 +721,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             Vec bufA[UNROLL], bufB[UNROLL];
             if (nb > 0) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++) bufA[u] = mrow[(int64_t)u * nvec];
+                for (int u = 0; u < UNROLL; u++) bufA[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)u * nvec]);
             }
             auto batch = [&](int t0, const Vec *cur, Vec *nxt, bool prefetch) {
                 if (prefetch) {
 #pragma unroll
-                    for (int u = 0; u < UNROLL; u++) nxt[u] = mrow[(int64_t)(t0 + UNROLL + u) * nvec];
+                    for (int u = 0; u < UNROLL; u++) nxt[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(t0 + UNROLL + u) * nvec]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of this batch's stores
                 }
 #pragma unroll
@@ -745,7 +756,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 Vec cur[UNROLL];
                 if (SRC == SRC_MASKS) {
 #pragma unroll
-                    for (int u = 0; u < UNROLL; u++) cur[u] = mrow[(int64_t)(b * UNROLL + u) * nvec];
+                    for (int u = 0; u < UNROLL; u++) cur[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(b * UNROLL + u) * nvec]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
@@ -2314,11 +2325,11 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
 #define BPG_LAUNCH_ROLLOUT(SRC, EPL, OUT, UNR, PIPE)                                                          \
         do {                                                                                                  \
             if (a->reset_first)                                                                               \
-                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, true, UNR, PIPE>), grid, block, 0, st, b->now, \
-                                   b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, true, UNR, PIPE, true>), grid, block, 0, st,   \
+                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
             else                                                                                              \
-                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, false, UNR, PIPE>), grid, block, 0, st, b->now, \
-                                   b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, false, UNR, PIPE, true>), grid, block, 0, st,  \
+                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
         } while (0)
 #define BPG_LAUNCH_ROLLOUT_OUT(SRC, EPL, UNR, PIPE)                                                           \
         do {                                                                                                  \

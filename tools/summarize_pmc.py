@@ -37,9 +37,9 @@ CAL = {
 # kernel name fragment -> (label, read width key, algorithmic read bytes, algorithmic write bytes) at 1 M envs, T = 50
 B, T = 1 << 20, 50
 KERNELS = [
-    ('k_rollout<0, true, 2, 3, true, 5, false', 'k_rollout_masks', 'read8', B * (4 * T + 4), B * (5 * T + 8)),
-    ('k_rollout<1, true, 2, 3, true, 5, false', 'k_rollout_synth', 'read8', 0, B * (5 * T + 8)),
-    ('k_rollout<0, true, 1, 3, true, 10, true', 'k_rollout_masks_65536', 'read4', 65536 * (4 * T + 4), 65536 * (5 * T + 8)),
+    ('k_rollout<0, true, 2, 3, true, 5, false, true', 'k_rollout_masks', 'read8', B * (4 * T + 4), B * (5 * T + 8)),
+    ('k_rollout<1, true, 2, 3, true, 5, false, true', 'k_rollout_synth', 'read8', 0, B * (5 * T + 8)),
+    ('k_rollout<0, true, 1, 3, true, 10, true, true', 'k_rollout_masks_65536', 'read4', 65536 * (4 * T + 4), 65536 * (5 * T + 8)),
     ('k_step_vec4<0>', 'k_step_vec4_masks', 'read16', 12 * B, 13 * B),
     ('k_step_record<6, 0', 'k_step_record', 'read4', 12 * B, (13 + 4 + 144) * B),
     ('k_discounted_return_reg<50>', 'k_discounted_return_reg50', 'read4', 4 * T * B, 8 * T * B),

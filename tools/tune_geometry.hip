@@ -68,39 +68,30 @@ static int run(int64_t B)
 #define M masks[rot % NB]
 #define R reward[rot % NB]
 #define F flags[rot % NB]
-#define GEO(EPL, BLOCK, UNR, PIPE, COUNT)                                                                     \
+#define GEO(EPL, BLOCK, UNR, PIPE, NTL, COUNT)                                                                \
     do {                                                                                                       \
         const int64_t lanes = B / EPL;                                                                         \
         int64_t grid = (lanes + BLOCK - 1) / BLOCK;                                                            \
         const int64_t cap = 256 * (1024 / BLOCK);                                                              \
         if (grid > cap) grid = cap;                                                                            \
         char nm[96];                                                                                           \
-        snprintf(nm, 96, "epl%d block%-4d grid%-5lld unr%-2d %s %s", EPL, BLOCK, (long long)grid, UNR,         \
-                 PIPE ? "pipe " : "plain", COUNT ? "+count" : "      ");                                       \
-        TIME(nm, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, 3, true, UNR, PIPE>), dim3((unsigned)grid),     \
+        snprintf(nm, 96, "epl%d block%-4d grid%-5lld unr%-2d %s %s %s", EPL, BLOCK, (long long)grid, UNR,      \
+                 PIPE ? "pipe " : "plain", NTL ? "ntl" : "   ", COUNT ? "+count" : "      ");                  \
+        TIME(nm, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, 3, true, UNR, PIPE, NTL>), dim3((unsigned)grid), \
                                     dim3(BLOCK), 0, 0, now, ever, M, R, F, B, T, c, s, rc, COUNT ? cnt : nullptr, \
                                     COUNT ? cnt + 1 : nullptr));                                               \
     } while (0)
     TIME("empty kernel (launch floor)", hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, d_counter));
-    GEO(4, 1024, 5, false, 1);
-    GEO(4, 256, 5, false, 1);
-    GEO(4, 256, 5, false, 0);
-    GEO(4, 256, 5, true, 1);
-    GEO(4, 64, 5, false, 1);
-    GEO(2, 1024, 5, true, 1);
-    GEO(2, 1024, 5, false, 1);
-    GEO(2, 256, 5, true, 1);
-    GEO(2, 256, 5, true, 0);
-    GEO(2, 256, 5, false, 1);
-    GEO(2, 256, 10, true, 1);
-    GEO(2, 128, 5, true, 1);
-    GEO(1, 1024, 5, true, 1);
-    GEO(1, 256, 5, true, 1);
-    GEO(1, 256, 5, true, 0);
-    GEO(1, 256, 5, false, 1);
-    GEO(1, 256, 10, true, 1);
-    GEO(1, 128, 10, true, 1);
-    GEO(1, 64, 10, true, 1);
+    for (int rep = 0; rep < 2; rep++) {
+        GEO(4, 1024, 5, false, false, 1);
+        GEO(4, 1024, 5, false, true, 1);
+        GEO(2, 1024, 5, false, false, 1);
+        GEO(2, 1024, 5, false, true, 1);
+        GEO(2, 256, 10, true, false, 1);
+        GEO(2, 256, 10, true, true, 1);
+        GEO(1, 256, 10, true, false, 1);
+        GEO(1, 256, 10, true, true, 1);
+    }
     // what the library picks
     {
         const RolloutGeometry g = rollout_geometry(B, masks[0], reward[0], flags[0]);
