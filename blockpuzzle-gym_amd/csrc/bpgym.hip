@@ -313,6 +313,45 @@ template <bool NT, typename V> __device__ __forceinline__ void st_1(V *p, V v)
     else *p = v;
 }
 
+// envs-per-lane vector types of the streaming kernels
+template <int EPL> struct LaneVec;
+template <> struct LaneVec<4> { using vec = uint4; using fl = uint32_t; };
+template <> struct LaneVec<2> { using vec = uint2; using fl = uint16_t; };
+template <> struct LaneVec<1> { using vec = uint32_t; using fl = uint8_t; };
+
+template <int EPL> __device__ __forceinline__ void unpack(const typename LaneVec<EPL>::vec &v, uint32_t *o)
+{
+    if constexpr (EPL == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if constexpr (EPL == 2) { o[0] = v.x; o[1] = v.y; }
+    else o[0] = v;
+}
+template <int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec pack(const uint32_t *o)
+{
+    if constexpr (EPL == 4) return make_uint4(o[0], o[1], o[2], o[3]);
+    else if constexpr (EPL == 2) return make_uint2(o[0], o[1]);
+    else return o[0];
+}
+// mask stream: read exactly once per launch -> nontemporal loads (tools/tune_geometry.hip: NTL)
+template <bool NTL, int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec ld_vec(const typename LaneVec<EPL>::vec *p)
+{
+    if constexpr (!NTL) return *p;
+    else if constexpr (EPL == 4)
+        return make_uint4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y),
+                          __builtin_nontemporal_load(&p->z), __builtin_nontemporal_load(&p->w));
+    else if constexpr (EPL == 2) return make_uint2(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y));
+    else return __builtin_nontemporal_load(p);
+}
+
+template <bool NT, int EPL> __device__ __forceinline__ void st_vec(typename LaneVec<EPL>::vec *p, const uint32_t *o)
+{
+    if constexpr (EPL == 4) st_u4<NT>(p, make_uint4(o[0], o[1], o[2], o[3]));
+    else if constexpr (EPL == 2) {
+        if (NT) { __builtin_nontemporal_store(o[0], &p->x); __builtin_nontemporal_store(o[1], &p->y); }
+        else *p = make_uint2(o[0], o[1]);
+    } else st_1<NT>(p, o[0]);
+}
+
+
 // ------------------------------ reset ---------------------------------------
 // fetch_env.py:247-255: has_succeeded = False, matrix kept (Q1);
 // Variation :646-679: matrix = -1, num_objs = 4 + num_grey.  TimeLimit: t = 0.
@@ -442,7 +481,7 @@ k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint3
         uint4 a = reinterpret_cast<uint4 *>(now)[v];
         uint4 e = reinterpret_cast<uint4 *>(ever)[v];
         uint4 m = make_uint4(0, 0, 0, 0);
-        if (SRC == SRC_MASKS) m = reinterpret_cast<const uint4 *>(masks)[v];
+        if (SRC == SRC_MASKS) m = ld_vec<true, 4>(reinterpret_cast<const uint4 *>(masks) + v);   // read once
         uint32_t an[4] = {a.x, a.y, a.z, a.w}, ee[4] = {e.x, e.y, e.z, e.w}, mm[4] = {m.x, m.y, m.z, m.w};
         uint32_t rb[4], fl[4];
 #pragma unroll
@@ -452,9 +491,11 @@ k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint3
         }
         reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
         reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
-        if (reward) reinterpret_cast<uint4 *>(reward)[v] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+        // write-once streams: nontemporal, so that they do not push the state (re-read by the next
+        // step) out of the caches
+        if (reward) st_u4<true>(reinterpret_cast<uint4 *>(reward) + v, make_uint4(rb[0], rb[1], rb[2], rb[3]));
         if (flags)
-            reinterpret_cast<uint32_t *>(flags)[v] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+            st_1<true>(reinterpret_cast<uint32_t *>(flags) + v, fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24));
     }
     const int64_t tail0 = nvec << 2;
     if (gtid < n - tail0) {
@@ -599,43 +640,6 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned lo
 // time-major (T, n) so every access is an (EPL*4)-byte-per-lane coalesced stream.
 // Optionally resets first (rollout.py:79) and counts the final successes.
 // EPL, the block size and the loop form are picked from n by rollout_geometry().
-template <int EPL> struct LaneVec;
-template <> struct LaneVec<4> { using vec = uint4; using fl = uint32_t; };
-template <> struct LaneVec<2> { using vec = uint2; using fl = uint16_t; };
-template <> struct LaneVec<1> { using vec = uint32_t; using fl = uint8_t; };
-
-template <int EPL> __device__ __forceinline__ void unpack(const typename LaneVec<EPL>::vec &v, uint32_t *o)
-{
-    if constexpr (EPL == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-    else if constexpr (EPL == 2) { o[0] = v.x; o[1] = v.y; }
-    else o[0] = v;
-}
-template <int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec pack(const uint32_t *o)
-{
-    if constexpr (EPL == 4) return make_uint4(o[0], o[1], o[2], o[3]);
-    else if constexpr (EPL == 2) return make_uint2(o[0], o[1]);
-    else return o[0];
-}
-// mask stream: read exactly once per launch -> nontemporal loads (tools/tune_geometry.hip: NTL)
-template <bool NTL, int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec ld_vec(const typename LaneVec<EPL>::vec *p)
-{
-    if constexpr (!NTL) return *p;
-    else if constexpr (EPL == 4)
-        return make_uint4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y),
-                          __builtin_nontemporal_load(&p->z), __builtin_nontemporal_load(&p->w));
-    else if constexpr (EPL == 2) return make_uint2(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y));
-    else return __builtin_nontemporal_load(p);
-}
-
-template <bool NT, int EPL> __device__ __forceinline__ void st_vec(typename LaneVec<EPL>::vec *p, const uint32_t *o)
-{
-    if constexpr (EPL == 4) st_u4<NT>(p, make_uint4(o[0], o[1], o[2], o[3]));
-    else if constexpr (EPL == 2) {
-        if (NT) { __builtin_nontemporal_store(o[0], &p->x); __builtin_nontemporal_store(o[1], &p->y); }
-        else *p = make_uint2(o[0], o[1]);
-    } else st_1<NT>(p, o[0]);
-}
-
 // OUT: which per-step streams are written (bit 0 reward, bit 1 flags) -- a compile-time choice,
 // because a store behind a run-time `if (pointer)` makes the compiler assume "maybe not issued"
 // when it counts outstanding memory operations, and every wait then also drains the stores.
