@@ -583,3 +583,39 @@ def test_ragged_contact_lists_vs_oracle(env_id):
                                                C.c_void_p(m1.data_ptr()), None))
     torch.cuda.synchronize()
     assert torch.equal(m1[:B // 2 - 1], m2[:B // 2 - 1])
+
+
+# --------------------------------------------------------------------------
+# a physics backend behind the boundary, end to end
+# --------------------------------------------------------------------------
+def test_toy_physics_backend_end_to_end():
+    """examples/toy_physics_rollout.py: reset -> placement -> on_reset -> scripted policy reading the
+    assembled observation -> set_action_vector -> toy kinematics -> geom-id contact lists -> touch
+    matrix / success.  The pusher solves BlocksTouch-v0 with the toy backend; an idle policy does not."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('toy_physics_rollout', os.path.join(root, 'examples', 'toy_physics_rollout.py'))
+    toy = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(toy)
+    B = 8192
+    worker, ep, phys = toy.run(B, device=DEV, seed=3)
+    ag = ep['ag'].reshape(B, 51, 4, 4)
+    assert (ag[:, 0, 2, 3] == -1).all()                              # placed >= 7.5 cm apart: never touched yet
+    assert (ep['info_is_success'][:, 0, 0] == 0).all()
+    assert worker.success_history[-1] > 0.95
+    first = (ag[:, :, 2, 3] == 1).float().argmax(1)                  # the push takes a few steps
+    assert first[ep['info_is_success'][:, -1, 0] == 1].float().mean() > 4
+    assert (ag[:, 1:, 1, 2] == 1).all() and (ag[:, 1:, 1, 3] == 1).all()   # cubes rest on the table
+    o = ep['o']
+    # observation slots hold what the backend assembled: block positions move only for the pushed cube
+    moved = (o[:, -1, 10:12] - o[:, 0, 10:12]).norm(dim=1)
+    assert (moved[ep['info_is_success'][:, -1, 0] == 1] > 0.01).all()
+
+    class Idle:
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            return torch.zeros(o.shape[0], 4, device=o.device)
+    worker.policy = Idle()
+    worker.generate_rollouts()
+    assert worker.success_history[-1] == 0.0
