@@ -383,16 +383,33 @@ __device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_
     }
 }
 
-// The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607), written into a
-// float32 observation buffer by the reset launch itself: obs[0] = num_blocks, the colour one-hot
-// of every present block, zeros for the slots of absent blocks (the 15 physics entries of a
-// present block are left as they are).  obs == NULL: state only.
+// The observation a reset leaves behind, written by the reset launch itself into a float32 buffer
+// (row stride ld).  There is no physics state behind the contacts-in boundary, so the row is what
+// the reference's _get_obs fills WITHOUT physics -- Variation (fetch_env.py:579-607): obs[0] =
+// num_blocks, the colour one-hot of every present block, zeros in the slots of absent blocks; every
+// variant: nothing else -- and zeros in the physics-owned entries (a backend writes those in its
+// on_reset).  full = 0 (bpg_fill_static_obs): only the physics-free entries are written, the rest of
+// the row is left as it is.  obs == NULL: state only.
 struct StaticObs {
     float *obs;
     int64_t ld;
-    int32_t enabled, nb_max, dimo;
+    int32_t enabled, nb_max, dimo, is_variation, full, flat;   // flat: ld == dimo, no env mask, 16-B aligned
     int32_t colors[BPG_MAX_OBJS];
 };
+
+__device__ __forceinline__ float obs_entry(const StaticObs &so, int k, int nb, bool &owned)
+{
+    owned = true;                                   // entry is defined without physics
+    if (!so.is_variation) { owned = false; return 0.0f; }
+    if (k == 0) return (float)nb;                                           // :580
+    const int j = k - 11;                                                   // 1 + ENV_FEATURES
+    if (j < 0) { owned = false; return 0.0f; }                              // gripper entries: physics
+    const int slot = j / 19, c = j - slot * 19;
+    if (slot >= nb) return 0.0f;                                            // zero padding :606-607
+    if (c >= 15) return so.colors[slot + 2] == c - 15 ? 1.0f : 0.0f;        // one_hot_color :599
+    owned = false;                                                          // block pose / velocity: physics
+    return 0.0f;
+}
 
 // RESET = false: only the observation entries, from the state as it is (constructor / restore).
 template <bool RESET>
@@ -419,23 +436,40 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
         __syncthreads();                             // previous tile consumed
         s_nblocks[threadIdx.x] = nbk;
         __syncthreads();
-        // each wave walks 64 of the block's rows; lane = entry of the row (two trips cover the 87
-        // entries), so what an entry is (num_blocks / slot / colour) is worked out once per lane and
-        // the stores of a row are consecutive addresses
         const int rows = (int)((n - base) < 256 ? (n - base) : 256);
+        if (so.flat) {
+            // the block's rows are one contiguous run of rows * dimo floats: float4 stores, every
+            // element's (row, entry) from a division by the row length
+            const int total = rows * so.dimo, nq = total >> 2;
+            float *o = so.obs + base * so.dimo;
+            for (int q = threadIdx.x; q < nq; q += 256) {
+                float v[4];
+                int e = (4 * q) / so.dimo, k = 4 * q - e * so.dimo;            // one division per float4
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    bool owned;
+                    v[c] = obs_entry(so, k, s_nblocks[e], owned);
+                    if (++k == so.dimo) { k = 0; e++; }
+                }
+                reinterpret_cast<float4 *>(o)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            for (int f = 4 * nq + threadIdx.x; f < total; f += 256) {
+                const int e = f / so.dimo;
+                bool owned;
+                o[f] = obs_entry(so, f - e * so.dimo, s_nblocks[e], owned);
+            }
+            continue;
+        }
+        // general form (env mask, strided rows, or only the physics-free entries): each wave walks 64
+        // of the block's rows, lane = entry of the row
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int k = lane; k < so.dimo; k += 64) {
-            const int j = k - 11;                                          // 1 + ENV_FEATURES
-            const int slot = j >= 0 ? j / 19 : -1, c = j >= 0 ? j - slot * 19 : 0;
-            const float hot = (slot >= 0 && c >= 15 && so.colors[slot + 2] == c - 15) ? 1.0f : 0.0f;
-            if (k != 0 && slot < 0) continue;                              // physics-owned gripper entries
             for (int e = wave * 64; e < rows && e < wave * 64 + 64; e++) {
                 const int nb = s_nblocks[e];
                 if (nb == 0xFF) continue;
-                float *o = so.obs + (base + e) * so.ld + k;
-                if (k == 0) *o = (float)nb;                                // :580
-                else if (slot >= nb) *o = 0.0f;                            // zero padding :606-607
-                else if (c >= 15) *o = hot;                                // one_hot_color :599
+                bool owned;
+                const float v = obs_entry(so, k, nb, owned);
+                if (owned || so.full) so.obs[(base + e) * so.ld + k] = v;
             }
         }
     }
@@ -1924,15 +1958,19 @@ int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
     return BPG_OK;
 }
 
-static StaticObs static_obs(const bpg_batch *b, float *d_obs, int64_t ld)
+static StaticObs static_obs(const bpg_batch *b, float *d_obs, int64_t ld, bool full, const uint8_t *d_env_mask)
 {
     StaticObs so;
     std::memset(&so, 0, sizeof(so));
-    so.enabled = (d_obs && b->info.is_variation) ? 1 : 0;     // only Variation has physics-free entries
+    // rewriting whole rows concerns every variant; the physics-free entries alone only Variation
+    so.enabled = (d_obs && (full || b->info.is_variation)) ? 1 : 0;
     so.obs = d_obs;
     so.ld = ld;
     so.nb_max = b->info.num_objs - 2;
     so.dimo = b->info.dimo;
+    so.is_variation = b->info.is_variation;
+    so.full = full ? 1 : 0;
+    so.flat = (full && !d_env_mask && ld == b->info.dimo && aligned16(d_obs) && (256 * b->info.dimo) % 4 == 0) ? 1 : 0;
     for (int i = 0; i < BPG_MAX_OBJS; i++) so.colors[i] = b->info.obj_colors[i];
     return so;
 }
@@ -1946,7 +1984,8 @@ int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_
     DeviceGuard guard(b->device);
     const int64_t nblk = (b->n + 255) / 256;
     hipLaunchKernelGGL(k_reset<true>, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, (hipStream_t)stream,
-                       b->now, b->ever, b->n, reset_const(b, 1, d_num_grey), d_env_mask, static_obs(b, d_obs, ld));
+                       b->now, b->ever, b->n, reset_const(b, 1, d_num_grey), d_env_mask,
+                       static_obs(b, d_obs, ld, true, d_env_mask));
     if (b->info.is_variation && !d_num_grey)     // only generator-drawn resets consume a stream index
         hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter);
     return check_launch("k_reset");
@@ -1962,7 +2001,7 @@ int bpg_fill_static_obs(bpg_batch *b, float *d_obs, int64_t ld, void *stream)
     const int64_t nblk = (b->n + 255) / 256;
     hipLaunchKernelGGL(k_reset<false>, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, (hipStream_t)stream,
                        b->now, b->ever, b->n, reset_const(b, 0, nullptr), (const uint8_t *)nullptr,
-                       static_obs(b, d_obs, ld));
+                       static_obs(b, d_obs, ld, false, nullptr));
     return check_launch("k_reset");
 }
 

@@ -18,9 +18,10 @@ outside the reference tree; each step consumes the step's contact set, either
                                 step(u, contacts=(int16[total,2], int64[B+1]))    ragged (CSR offsets)
     (what fetch_env.py:158-167 reads from sim.data.contact), or
   * the env's `contact_source`  (default: the build-defined synthetic source).
-`observation` has no physics behind it: it is zero except for the entries the
-reference fills without physics (Variation: obs[0] = num_blocks and the colour
-one-hots, fetch_env.py:579-600), unless the caller writes `env.observation`.
+`observation` has no physics behind it: reset() rewrites it to what the reference
+fills without physics (Variation: obs[0] = num_blocks and the colour one-hots,
+fetch_env.py:579-600) and zeros elsewhere; a backend writes the rest
+(`assemble_observation`, from its on_reset and on every step).
 """
 import ctypes as C
 import json
@@ -373,16 +374,24 @@ class BatchedBlocksEnv:
             x = torch.as_tensor(np.ascontiguousarray(x))
         return x.to(device=self.device, dtype=dtype).contiguous()
 
-    def reset(self, num_grey=None, env_mask=None, variates=None):
+    def reset(self, num_grey=None, env_mask=None, variates=None, observation_out=None):
         """robot_env.py:71-82.  num_grey: optional explicit (B,) draws for Variation's
         np_random.randint(3) (fetch_env.py:647); env_mask: optional (B,) partial reset (the
         reference's reset_rollout(i)); variates: optional explicit placement draws (see
-        randomize_objects).  One launch resets the state and refills the physics-free observation
-        entries; when the contact source consumes positions (`wants_positions`) the cubes are
+        randomize_objects); observation_out: optional (B, dimo) float32 buffer that becomes
+        `env.observation`.  One launch resets the state and rewrites the observation rows of the envs
+        being reset (the entries the reference fills without physics, zeros in the physics-owned ones:
+        a backend writes those from its on_reset); when the contact source consumes positions (`wants_positions`) the cubes are
         re-placed on the same stream and handed to its on_reset, as _reset_sim does
         (fetch_env.py:247-255 -> _randomize_objects)."""
         ng = self._to_dev(num_grey, torch.int32)
         em = self._to_dev(env_mask, torch.uint8)
+        if observation_out is not None:
+            # the caller's buffer (e.g. time slot 0 of an episode) becomes the env's observation: the
+            # reset launch writes the reset observation straight into it
+            assert observation_out.shape == (self.num_envs, self.dimo) and observation_out.dtype == torch.float32 \
+                and observation_out.stride(1) == 1 and env_mask is None
+            self.observation = observation_out
         obs = self.observation
         _lib.check(self._L.bpg_reset_obs(self._h, _ptr(ng), _ptr(em), _ptr(obs), int(obs.stride(0)),
                                          _stream(self.device)))

@@ -93,12 +93,11 @@ class RolloutStudent:
         self.clear_history()
 
     # -- rollout.py:47-64 -------------------------------------------------
-    def reset_all_rollouts(self, test=False, num_grey=None):
-        obs = self.env.reset(num_grey=num_grey)
+    def reset_all_rollouts(self, test=False, num_grey=None, observation_out=None):
+        obs = self.env.reset(num_grey=num_grey, observation_out=observation_out)
         if test:
             obs = self.env.unwrapped.set_test()      # maximum difficulty (rollout.py:53-55)
         # the env hands out its observation / goal buffers and a fresh achieved_goal tensor: no copies here
-        # (the episode takes its own copy of the first observation, _episode_o)
         self.initial_o = obs['observation']
         self.initial_ag = obs['achieved_goal']
         self.g = obs['desired_goal']
@@ -190,22 +189,27 @@ class RolloutStudent:
         flag = getattr(self, '_nan_flag', None)
         return flag is not None and self._watch_o and bool(flag.item())
 
-    def _episode_o(self, ep):
-        """Where the T+1 observations of the episode live.  A backend that rewrites the whole
-        observation every step gets the episode's time slot as its target (env.observation points
-        at it during the step); otherwise nothing changes the observation between resets and the
-        episode's `o` is the initial observation, expanded (stride 0) -- rollout.py:144 appends T+1
-        copies of an array nobody wrote to."""
+    def _reset_into_episode(self, test, num_grey):
+        """reset_all_rollouts with the episode's first observation as the reset's target, and where
+        the T+1 observations of the episode live.  A backend that rewrites the whole observation every
+        step (`writes_observation`) gets time slot t+1 as its target during step t (env.observation
+        points at it), and slot 0 is what the reset (and the backend's on_reset) wrote; otherwise
+        nothing changes the observation between resets and the episode's `o` is that one reset
+        observation, expanded (stride 0) -- rollout.py:144 appends T+1 copies of an array nobody wrote
+        to.  Either way the reset launch writes into episode-owned memory: no copies."""
         B, T = self.rollout_batch_size, self.T
         self._watch_o = bool(getattr(self.env.contact_source, 'writes_observation', False))
+        f32 = dict(dtype=torch.float32, device=self.device)
         if self._watch_o:
             if getattr(self, '_nan_flag', None) is None:
                 self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._nan_flag.zero_()
-            o = torch.empty((T + 1, B, self.dims['o']), dtype=torch.float32, device=self.device)
-            o[0] = self.initial_o
+            o = torch.empty((T + 1, B, self.dims['o']), **f32)
+            self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o[0])
             return o
-        return self.initial_o.clone()[None].expand(T + 1, B, self.dims['o'])
+        o0 = torch.empty((B, self.dims['o']), **f32)
+        self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)
+        return o0[None].expand(T + 1, B, self.dims['o'])
 
     def _step_into(self, u, ep, t, reward_out=None, u_store=None):
         """One env step that writes obs['achieved_goal'] / info['is_success'] (and, through the
@@ -229,12 +233,11 @@ class RolloutStudent:
 
     def _rollout_body(self, test, num_grey, compute_Attention=False):
         env, B, T = self.env, self.rollout_batch_size, self.T
-        self.reset_all_rollouts(test, num_grey=num_grey)
         # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
         # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
         # the next achieved_goal straight into slot t+1
         ep = self._alloc_episode(time_major=True, g=False, o=False)
-        ep['o'] = self._episode_o(ep)
+        ep['o'] = self._reset_into_episode(test, num_grey)
         ep['ag'][0] = self.initial_ag
         Qs = []
         for t in range(T):
@@ -255,7 +258,8 @@ class RolloutStudent:
             # actions into the episode's slot (acts.append(u.copy()), rollout.py:147)
             self._step_into(u, ep, t, u_store=ep['u'][t])
         if self._watch_o:
-            self.initial_o.copy_(ep['o'][T])                       # rollout.py:153 `self.initial_o[:] = o`
+            self.initial_o = ep['o'][T]                            # rollout.py:153 `self.initial_o[:] = o`
+            env.observation = ep['o'][T]
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
         # the goal is constant over the episode (rollout.py:151 appends the same array T times)
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
@@ -311,15 +315,16 @@ class RolloutStudent:
         backend) are returned as stride-0 expanded views unless materialize_constants=True,
         which makes the kernel write contiguous float32 copies of them as well."""
         env, B, T = self.env, self.rollout_batch_size, self.T
-        self.reset_all_rollouts(test, num_grey=num_grey)
+        o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
+        self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
         ep = self._alloc_episode(o=materialize_constants, g=materialize_constants)
         if materialize_constants:
-            ep['o'].copy_(self.initial_o[:, None, :].expand(B, T + 1, self.dims['o']))
+            ep['o'].copy_(o0[:, None, :].expand(B, T + 1, self.dims['o']))
         else:
-            ep['o'] = self.initial_o.clone()[:, None, :].expand(B, T + 1, self.dims['o'])
+            ep['o'] = o0[:, None, :].expand(B, T + 1, self.dims['o'])
             ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         if actions is not None:
-            ep['u'].copy_(torch.as_tensor(actions).to(self.device).clamp(-1, 1))
+            ep['u'].copy_(torch.as_tensor(actions).to(self.device))               # stored as given (rollout.py:147)
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device) if want_reward else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
@@ -400,10 +405,9 @@ class PGRolloutStudent(RolloutStudent):
 
     def _pg_body(self, test, exploit, num_grey):
         env, B, T = self.env, self.rollout_batch_size, self.T
-        self.reset_all_rollouts(test, num_grey=num_grey)
         beta = self.beta() if self.expert is not None else 0
         ep = self._alloc_episode(time_major=True, g=False, o=False)
-        ep['o'] = self._episode_o(ep)
+        ep['o'] = self._reset_into_episode(test, num_grey)
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
         reward = torch.empty((T, B), dtype=torch.float32, device=self.device)
         ep['ag'][0] = self.initial_ag
@@ -424,7 +428,8 @@ class PGRolloutStudent(RolloutStudent):
                 ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
             self._step_into(u, ep, t, reward_out=reward[t])
         if self._watch_o:
-            self.initial_o.copy_(ep['o'][T])
+            self.initial_o = ep['o'][T]
+            env.observation = ep['o'][T]
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         ep['G'] = discounted_return(reward, self.gamma)

@@ -126,14 +126,16 @@ int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
  * d_num_grey[b] (explicit variate for np_random.randint(3), :647) or, when
  * NULL, from the handle's counter-based generator. */
 int bpg_reset(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, void *stream);
-/* The same reset, and in the SAME launch the part of the observation the reference fills without
- * physics (Variation _get_obs, fetch_env.py:579-607: obs[0] = num_blocks, colour one-hot of every
- * present block, zeros in the slots of absent blocks) written into d_obs (n_envs rows of dimo
- * float32, row stride ld) for the envs being reset.  No-op on d_obs for the other variants. */
+/* The same reset, and in the SAME launch the observation it leaves behind, for the envs being reset:
+ * d_obs (n_envs rows of dimo float32, row stride ld) gets what the reference's _get_obs fills without
+ * physics (Variation, fetch_env.py:579-607: obs[0] = num_blocks, colour one-hot of every present
+ * block, zeros in the slots of absent blocks) and ZEROS in every physics-owned entry -- there is no
+ * physics state behind the contacts-in boundary; a backend writes its own values afterwards
+ * (bpg_assemble_obs_*, from its on_reset).  Rows of envs outside d_env_mask are not touched. */
 int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_mask, float *d_obs,
                   int64_t ld, void *stream);
-/* Only those observation entries, from the state as it stands (after construction or a restored
- * checkpoint), for every env. */
+/* Only the physics-free entries, from the state as it stands (after construction or a restored
+ * checkpoint), for every env; the physics-owned entries of d_obs are left as they are. */
 int bpg_fill_static_obs(bpg_batch *b, float *d_obs, int64_t ld, void *stream);
 
 /* RobotEnv.step (robot_env.py:57-69) after the physics: _step_callback

@@ -137,7 +137,8 @@ def test_sources_that_need_no_positions_skip_the_sampler():
 
 def test_variation_static_observation_is_written_by_the_reset_launch():
     """fetch_env.py:579-607 without physics: obs[0] = num_blocks, one-hot colours of present
-    blocks, zero padding -- and entries of present blocks that physics owns are left alone."""
+    blocks, zero padding; the physics-owned entries are zeroed by reset() (nothing behind the
+    boundary knows them) and left alone by a state restore."""
     B = 1000
     env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV)
     assert (env.observation[:, 0] == 4).all()                       # constructor state: all four blocks
@@ -147,7 +148,7 @@ def test_variation_static_observation_is_written_by_the_reset_launch():
     o = env.observation.cpu().numpy()
     nb = ng + 2
     colors = VARIANTS['BlocksTouchVariation-v0']['obj_colors']
-    exp = np.full((B, 87), 7.0, np.float32)
+    exp = np.zeros((B, 87), np.float32)
     exp[:, 0] = nb
     for s in range(4):
         sl = slice(11 + 19 * s, 11 + 19 * (s + 1))
@@ -165,11 +166,24 @@ def test_variation_static_observation_is_written_by_the_reset_launch():
     env.reset(num_grey=ng, env_mask=mask)
     o = env.observation.cpu().numpy()
     assert (o[mask == 0] == -3.0).all() and (o[mask == 1, 0] == nb[mask == 1]).all()
-    # a restored checkpoint refreshes the entries from the state
+    # strided target (a wider buffer) and a caller-provided buffer that becomes env.observation
+    wide = torch.full((B, 100), 5.0, device=DEV)
+    env.reset(num_grey=ng, observation_out=wide[:, :87])
+    assert env.observation.data_ptr() == wide.data_ptr()
+    np.testing.assert_array_equal(wide[:, :87].cpu().numpy(), exp)
+    assert (wide[:, 87:] == 5.0).all()
+    # a restored checkpoint refreshes the physics-free entries from the state, nothing else
     sd = env.state_dict()
     env.reset(num_grey=(ng + 1) % 3)
+    env.observation[:, 1:11] = 9.0
     env.load_state_dict(sd)
-    assert (env.observation[:, 0].cpu().numpy() == nb).all()
+    assert (env.observation[:, 0].cpu().numpy() == nb).all() and (env.observation[:, 1:11] == 9.0).all()
+    # the other variants have no physics-free entries: reset zeroes the rows
+    e2 = bpg.make('BlocksTouch-v0', num_envs=300, device=DEV)
+    e2.observation.fill_(3.0)
+    e2.reset(env_mask=(np.arange(300) % 2).astype(np.uint8))
+    o2 = e2.observation.cpu().numpy()
+    assert (o2[1::2] == 0).all() and (o2[0::2] == 3.0).all()
 
 
 # --------------------------------------------------------------------------
