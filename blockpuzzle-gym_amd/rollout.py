@@ -62,7 +62,10 @@ class RolloutStudent:
                  random_eps=0, history_len=100, render=False, output=None, **kwargs):
         """Same arguments as the reference (rollout.py:11-14).  `make_env` may
         return a batched env directly (called as make_env(num_envs=B) when it
-        accepts that) or a single env, which is re-created with B envs."""
+        accepts that) or a single env, which is re-created with B envs.
+        Zero-copy note: the env writes observations / achieved goals straight into the episode a
+        rollout returns, so until the next reset `env.observation` IS the last observation slot of
+        the most recent episode (stepping the env by hand in between writes into that episode)."""
         self.make_env, self.policy, self.dims, self.logger, self.T = make_env, policy, dims, logger, T
         self.rollout_batch_size = rollout_batch_size
         self.exploit, self.use_target_net, self.compute_Q = exploit, use_target_net, compute_Q
@@ -217,13 +220,9 @@ class RolloutStudent:
         of the episode."""
         env = self.env
         if self._watch_o:
-            own, env.observation = env.observation, ep['o'][t + 1]
-            try:
-                r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                         reward_out=reward_out, u_out=u_store)
-            finally:
-                env.observation = own
-            slot = ep['o'][t + 1]
+            slot = env.observation = ep['o'][t + 1]          # the backend's write lands in the episode
+            r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
+                                     reward_out=reward_out, u_out=u_store)
             _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
                                                    _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
@@ -259,7 +258,6 @@ class RolloutStudent:
             self._step_into(u, ep, t, u_store=ep['u'][t])
         if self._watch_o:
             self.initial_o = ep['o'][T]                            # rollout.py:153 `self.initial_o[:] = o`
-            env.observation = ep['o'][T]
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
         # the goal is constant over the episode (rollout.py:151 appends the same array T times)
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
@@ -429,7 +427,6 @@ class PGRolloutStudent(RolloutStudent):
             self._step_into(u, ep, t, reward_out=reward[t])
         if self._watch_o:
             self.initial_o = ep['o'][T]
-            env.observation = ep['o'][T]
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         ep['G'] = discounted_return(reward, self.gamma)
