@@ -6,7 +6,8 @@ A bench "step" = one rollout pass over the batch in ONE kernel launch: reset of
 all envs, T=50 fused env steps (contacts read as packed masks resident in HBM --
 the contacts-in boundary -- rewards + success/done flags written per env-step)
 and the success-count reduction; with N>1 GPUs the (successes, envs) rows are
-all-reduced over RCCL in slabs of `--reduce-every` rollouts (default 8), asynchronously.
+all-reduced over RCCL in slabs of `--reduce-every` rollouts (default 50 = one epoch of the
+reference's training loop, which averages across ranks once per epoch), asynchronously.
 Weak scaling by default: every GPU holds `--envs` envs (BASELINE configs[2] per GPU).
 `--total-envs E` fixes the JOB size instead and shards it over the ranks (strong scaling):
 `--gpus 8 --total-envs 4194304` is BASELINE configs[3] as written (524 288 envs per GPU).
@@ -44,13 +45,17 @@ def parse():
     p.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
                    help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of the '
                         'per-env final flag bytes [1 B/env]')
-    p.add_argument('--reduce-every', type=int, default=8,
+    p.add_argument('--reduce-every', type=int, default=50,
                    help='N>1: rollouts per collective (the statistics rows of R rollouts travel in one all-reduce; the '
-                        'reference averages across ranks once per epoch, train.py:21-26,67-76)')
+                        'reference averages across ranks once per epoch of n_cycles = 50 rollouts, train.py:21-26,67-76, '
+                        'config.py:39)')
     p.add_argument('--single-device', action='store_true',
                    help='rehearsal only: every rank uses cuda:0 (use with --backend gloo on a 1-GPU box)')
     p.add_argument('--default-stream', action='store_true',
                    help='launch on the legacy default stream instead of a dedicated non-blocking stream')
+    p.add_argument('--prewarm', type=int, default=200,
+                   help='untimed rollouts run during set-up, before the W warm-up steps, so that the clocks have '
+                        'settled when the contract\'s warm-up starts (0.02 s at the default)')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -206,6 +211,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if a.prewarm > 0:                      # set-up, not measurement: same launch, scratch statistics row
+        scratch = torch.zeros(2, dtype=torch.int64, device=dev)
+        pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
+                                d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(),
+                                d_success_count=scratch.data_ptr()) for k in range(NBUF)]
+        for i in range(a.prewarm):
+            _lib.check(L.bpg_rollout(env._h, C.byref(pre[i % NBUF]), stream))
+        torch.cuda.synchronize(dev)
     for i in range(a.warmup):
         one_rollout(i)
     drain()
