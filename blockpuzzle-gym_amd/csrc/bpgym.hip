@@ -1648,9 +1648,19 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
     if (lane < nvalid) {
         double *my = tile + lane * R;
         const float *p = reward_tb + base + lane;
+        // all rewards into the lane's LDS row first, eight requests in flight at a time (one request
+        // per trip of the accumulation loop would be T serial memory round trips)
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float r8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (t0 + u < T) r8[u] = p[(int64_t)(t0 + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (t0 + u < T) my[t0 + u] = (double)r8[u];
+        }
         for (int t = 0; t < T; t++) {
-            const double rt = (double)p[(int64_t)t * n];
-            my[t] = rt;
+            const double rt = my[t];
             int t_ = 0;
             for (; t_ + 4 <= t; t_ += 4) {
                 const double p0 = pw.v[t - t_] * rt, p1 = pw.v[t - t_ - 1] * rt, p2 = pw.v[t - t_ - 2] * rt,
@@ -1676,16 +1686,35 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
 
 // np.isnan(o_new).any() of the rollout worker (rollout.py:139-142) without a host round trip:
 // ORs 1 into *flag when any of rows x cols float32 values (row stride ld) is a NaN.
+// FLAT: the rows are one contiguous, 16-byte aligned run -> float4 loads, four in flight per lane.
+template <bool FLAT>
 __global__ void __launch_bounds__(256)
 k_nan_flag(const float *__restrict__ x, int64_t rows, int cols, int64_t ld, uint32_t *__restrict__ flag)
 {
     const int64_t total = rows * cols;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += stride) {
-        const int64_t r = f / cols;
-        const float v = x[r * ld + (f - r * cols)];
-        bad |= (v != v);
+    if (FLAT) {
+        const int64_t nq = total >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int64_t q0 = gtid; q0 < nq; q0 += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (q0 + u * stride < nq) v[u] = x4[q0 + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (q0 + u * stride < nq)
+                    bad |= (v[u].x != v[u].x) | (v[u].y != v[u].y) | (v[u].z != v[u].z) | (v[u].w != v[u].w);
+        }
+        for (int64_t f = (nq << 2) + gtid; f < total; f += stride) bad |= (x[f] != x[f]);
+    } else {
+        for (int64_t f = gtid; f < total; f += stride) {
+            const int64_t r = f / cols;
+            const float v = x[r * ld + (f - r * cols)];
+            bad |= (v != v);
+        }
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
@@ -2514,8 +2543,12 @@ int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint3
     if (rows < 0 || cols < 1 || ld < cols) return fail(BPG_ERR_ARG, "bad rows / cols / ld");
     if (rows == 0) return BPG_OK;
     DeviceGuard guard(device_id);
-    hipLaunchKernelGGL(k_nan_flag, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows, cols,
-                       ld, d_flag);
+    if (ld == cols && aligned16(d_x))
+        hipLaunchKernelGGL(k_nan_flag<true>, dim3(grid_for((rows * cols + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                           d_x, rows, cols, ld, d_flag);
+    else
+        hipLaunchKernelGGL(k_nan_flag<false>, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows,
+                           cols, ld, d_flag);
     return check_launch("k_nan_flag");
 }
 
