@@ -6,7 +6,7 @@ rocprofv3 (kernel trace or one --pmc counter set per invocation):
     rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
 
 kernels: rollout (fused, masks), rollout64k, rollout512k, synth (fused, in-kernel contacts),
-step (13 batches round-robin), record, return, episode, reward
+step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement)
 """
 import ctypes as C
 import os
@@ -103,6 +103,22 @@ def main():
                 co = torch.empty(n, dtype=torch.float32, device=DEV)
                 for i in range(10):
                     _lib.check(L.bpg_compute_reward_f32(P(cag), P(cg), n, 36, P(co), 0, None))
+            torch.cuda.synchronize()
+        elif w == 'assemble':
+            env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+            env.reset()
+            g = torch.Generator(device=DEV).manual_seed(0)
+            phys = dict(grip_pos=torch.randn(B, 3, dtype=torch.float64, device=DEV, generator=g),
+                        grip_velp=torch.randn(B, 3, dtype=torch.float64, device=DEV, generator=g),
+                        gripper_state=torch.randn(B, 2, dtype=torch.float64, device=DEV, generator=g),
+                        gripper_vel=torch.randn(B, 2, dtype=torch.float64, device=DEV, generator=g))
+            for k in ('obj_pos', 'obj_rot', 'obj_velp', 'obj_velr'):
+                phys[k] = torch.randn(B, 4, 3, dtype=torch.float64, device=DEV, generator=g)
+            u = torch.rand(B, 4, device=DEV) * 3 - 1.5
+            for i in range(10):
+                env.assemble_observation(phys)
+                env.set_action_vector(u)
+                env.randomize_objects()
             torch.cuda.synchronize()
         else:
             raise SystemExit('unknown kernel %r' % w)
