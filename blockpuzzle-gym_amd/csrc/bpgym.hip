@@ -1141,21 +1141,32 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
 // robot_env.py:58 clip + BlocksEnv._set_action (fetch_env.py:170-185): the 9-vector
 // [pos_ctrl * 0.05 (float32 product), 1, 0, 1, 0, grip, grip] the reference hands to the
 // physics (gripper targets zeroed when block_gripper), one env per lane.
+// The rows are 72 bytes: a lane writing its own row would touch nine partial lines per store
+// instruction, so the block parks its 256 rows in LDS and streams the contiguous 18 KB.
 __global__ void __launch_bounds__(256)
 k_set_action(const float *__restrict__ action, int64_t n, int block_gripper, double *__restrict__ out)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 a4 = reinterpret_cast<const float4 *>(action)[i];
-        float a[4] = {a4.x, a4.y, a4.z, a4.w};
+    __shared__ double tile[256 * 9];
+    const int64_t nblk = (n + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t base = blk * 256;
+        const int nvalid = (int)((n - base) < 256 ? (n - base) : 256);
+        if ((int)threadIdx.x < nvalid) {
+            const float4 a4 = reinterpret_cast<const float4 *>(action)[base + threadIdx.x];
+            float a[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) a[k] = a[k] < -1.0f ? -1.0f : (a[k] > 1.0f ? 1.0f : a[k]);
-        double *o = out + i * 9;
-        o[0] = (double)(a[0] * 0.05f);
-        o[1] = (double)(a[1] * 0.05f);
-        o[2] = (double)(a[2] * 0.05f);
-        o[3] = 1.0; o[4] = 0.0; o[5] = 1.0; o[6] = 0.0;
-        o[7] = o[8] = block_gripper ? 0.0 : (double)a[3];
+            for (int k = 0; k < 4; k++) a[k] = a[k] < -1.0f ? -1.0f : (a[k] > 1.0f ? 1.0f : a[k]);
+            double *o = tile + threadIdx.x * 9;
+            o[0] = (double)(a[0] * 0.05f);
+            o[1] = (double)(a[1] * 0.05f);
+            o[2] = (double)(a[2] * 0.05f);
+            o[3] = 1.0; o[4] = 0.0; o[5] = 1.0; o[6] = 0.0;
+            o[7] = o[8] = block_gripper ? 0.0 : (double)a[3];
+        }
+        __syncthreads();
+        double *o = out + base * 9;
+        for (int f = threadIdx.x; f < nvalid * 9; f += 256) o[f] = tile[f];
+        __syncthreads();
     }
 }
 

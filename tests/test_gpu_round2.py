@@ -340,7 +340,7 @@ def test_per_step_worker_matches_fused_kernel_at_1m_envs():
 # --------------------------------------------------------------------------
 # fused rollout at the other batch sizes of BASELINE.json (launch shapes)
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize('B', [65536, 131072 + 2, 524288, 65537])
+@pytest.mark.parametrize('B', [65536, 131072 + 2, 524288, 65537, 2097152, 4194304 + 2])   # the last two: grid-stride trips
 @pytest.mark.parametrize('reset_first', [1, 0])
 def test_fused_rollout_shapes_agree_with_single_steps(B, reset_first):
     """Every launch shape rollout_geometry() picks (1 / 2 envs per lane, pipelined / plain loop,
