@@ -34,6 +34,7 @@ class RolloutArgs(C.Structure):
         ('d_masks', C.c_void_p), ('d_reward_tb', C.c_void_p), ('d_flags_tb', C.c_void_p),
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
+        ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
     ]
 
 
@@ -77,6 +78,8 @@ SIGNATURES = {
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'bpg_synth_masks_ld': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_row_stride': (C.c_int64, [C.c_int64]),
     'bpg_get_achieved_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_get_achieved_goal_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_get_desired_goal_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -95,6 +98,8 @@ SIGNATURES = {
     'bpg_success_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_discounted_return': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                         C.c_int, C.c_void_p]),
+    'bpg_discounted_return_ld': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p,
+                                           C.c_int, C.c_void_p]),
     'bpg_nan_flag_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

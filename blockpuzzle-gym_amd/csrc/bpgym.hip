@@ -647,7 +647,7 @@ k_step_contacts(uint32_t *__restrict__ now, uint32_t *__restrict__ ever,
 
 __global__ void __launch_bounds__(256)
 k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint32_t *__restrict__ out,
-              SynthConst s)
+              int64_t ld, SynthConst s)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -655,7 +655,7 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
         for (int t = 0; t < T; t++) {
             uint32_t tt = (uint32_t)(t0 + t);
             tt = tt > ELAPSED_MAX ? ELAPSED_MAX : tt;
-            out[(int64_t)t * n + i] = synth_mask(l, tt);
+            out[(int64_t)t * ld + i] = synth_mask(l, tt);
         }
     }
 }
@@ -700,12 +700,14 @@ template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL = 5, bool P
 __global__ void __launch_bounds__(1024)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
+          int64_t ld_masks, int64_t ld_out,
           StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
           unsigned long long *__restrict__ zero_next)
 {
     using Vec = typename LaneVec<EPL>::vec;
     using Fl = typename LaneVec<EPL>::fl;
-    const int64_t nvec = n / EPL;               // the host guarantees n % EPL == 0
+    const int64_t nvec = n / EPL;               // the host guarantees n, ld_masks, ld_out % EPL == 0
+    const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t nsucc = 0;
     if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
@@ -751,12 +753,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 rb[k] = RBITS_FAIL ^ (okm & (RBITS_FAIL ^ RBITS_OK));
                 fl[k] = (lat[k] & (uint32_t)BPG_FLAG_SUCCESS) | (okm & (uint32_t)BPG_FLAG_STEP_OK) | dn;
             }
-            if (OUT & OUT_REWARD) st_vec<NT, EPL>(&rrow[(int64_t)t * nvec], rb);
+            if (OUT & OUT_REWARD) st_vec<NT, EPL>(&rrow[(int64_t)t * ldo], rb);
             if (OUT & OUT_FLAGS) {
                 uint32_t f = fl[0];
 #pragma unroll
                 for (int k = 1; k < EPL; k++) f |= fl[k] << (8 * k);
-                st_1<NT>(&frow[(int64_t)t * nvec], (Fl)f);
+                st_1<NT>(&frow[(int64_t)t * ldo], (Fl)f);
             }
         };
         // Steps run in batches of UNROLL.  The masks of batch b+1 are requested BEFORE the rewards /
@@ -769,12 +771,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             Vec bufA[UNROLL], bufB[UNROLL];
             if (nb > 0) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++) bufA[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)u * nvec]);
+                for (int u = 0; u < UNROLL; u++) bufA[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)u * ldm]);
             }
             auto batch = [&](int t0, const Vec *cur, Vec *nxt, bool prefetch) {
                 if (prefetch) {
 #pragma unroll
-                    for (int u = 0; u < UNROLL; u++) nxt[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(t0 + UNROLL + u) * nvec]);
+                    for (int u = 0; u < UNROLL; u++) nxt[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(t0 + UNROLL + u) * ldm]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of this batch's stores
                 }
 #pragma unroll
@@ -804,7 +806,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 Vec cur[UNROLL];
                 if (SRC == SRC_MASKS) {
 #pragma unroll
-                    for (int u = 0; u < UNROLL; u++) cur[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(b * UNROLL + u) * nvec]);
+                    for (int u = 0; u < UNROLL; u++) cur[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(b * UNROLL + u) * ldm]);
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
@@ -816,7 +818,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         }
         for (int t = nb * UNROLL; t < T; t++) {          // T % UNROLL leftover steps
             uint32_t mt[EPL] = {};
-            if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * nvec], mt);
+            if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * ldm], mt);
             one_step(t, mt);
         }
 #pragma unroll
@@ -1382,8 +1384,8 @@ __global__ void __launch_bounds__(64)
 k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
-          int64_t n, int T, int RC, int R, StepConst c, SynthConst s, PairTable tabv, ResetConst rc,
-          unsigned long long *__restrict__ count, unsigned long long *__restrict__ zero_next)
+          int64_t n, int T, int64_t ldm, int64_t ldo, int RC, int R, StepConst c, SynthConst s, PairTable tabv,
+          ResetConst rc, unsigned long long *__restrict__ count, unsigned long long *__restrict__ zero_next)
 {
     // The T+1 matrices of an episode are produced in chunks of RC rows (one chunk = the whole
     // episode for T <= 63): a short step phase (lane = env, state in registers, packed rows of
@@ -1420,7 +1422,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 if (SRC == SRC_MASKS) {
 #pragma unroll
                     for (int u = 0; u < EP_BATCH; u++)
-                        mb[u] = (t0 + u < te) ? masks[(int64_t)(t0 + u) * n + i] : 0u;
+                        mb[u] = (t0 + u < te) ? masks[(int64_t)(t0 + u) * ldm + i] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < EP_BATCH; u++) {
@@ -1431,8 +1433,8 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                         else m = synth_mask(sl, (a >> ELAPSED_SHIFT) & ELAPSED_MAX);
                         step_core(a, e, m, c, rb, fl);
                         my[t + 1 - r0] = make_uint2(a, e);
-                        if (reward_tb) reward_tb[(int64_t)t * n + i] = rb;
-                        if (flags_tb) flags_tb[(int64_t)t * n + i] = (uint8_t)fl;
+                        if (reward_tb) reward_tb[(int64_t)t * ldo + i] = rb;
+                        if (flags_tb) flags_tb[(int64_t)t * ldo + i] = (uint8_t)fl;
                     }
                 }
             }
@@ -1604,7 +1606,8 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 
 template <int TT>
 __global__ void __launch_bounds__(64)
-k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable pw, double *__restrict__ G)
+k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t ld, PowTable pw,
+                        double *__restrict__ G)
 {
     constexpr int NI = (TT + 1) / 2;          // accumulators per lane (half 1 leaves the last one unused when T is odd)
     constexpr int R = TT | 1;                 // odd row stride of the 16 x T tile
@@ -1615,13 +1618,14 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, PowTable
     const bool live = e < nvalid;
     // rw[s] = reward of step s + q.  Row bases are uniform (scalar unit), the per-lane part is ONE
     // 32-bit byte offset (env within the row, plus one row for the upper half of the wave): no
-    // per-load address arithmetic on the vector unit.  The host guarantees 8 * n < 2^32.
+    // per-load address arithmetic on the vector unit.  ld = row stride of the (T, ld) reward stream; the
+    // host guarantees 8 * ld < 2^32.
     float rw[TT];
     {
-        const uint32_t voff = (uint32_t)((int64_t)q * n + base + (live ? e : 0)) * 4u;
+        const uint32_t voff = (uint32_t)((int64_t)q * ld + base + (live ? e : 0)) * 4u;
         static_for<0, TT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)s * n);
+            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)s * ld);
             rw[s] = (s + 1 < TT || q == 0) ? *reinterpret_cast<const float *>(row + voff) : 0.0f;
         });
     }
@@ -1683,7 +1687,7 @@ constexpr int DR_TMAX = 319;                  // 64 x (T|1) x 8 B <= 160 KB of L
 struct PowTableBig { double v[DR_TMAX + 1]; };
 
 __global__ void __launch_bounds__(64)
-k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R, PowTableBig pw,
+k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int64_t ld, int T, int R, PowTableBig pw,
                     double *__restrict__ G)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1700,7 +1704,7 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int T, int R
             float r8[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if (t0 + u < T) r8[u] = p[(int64_t)(t0 + u) * n];
+                if (t0 + u < T) r8[u] = p[(int64_t)(t0 + u) * ld];
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (t0 + u < T) my[t0 + u] = (double)r8[u];
@@ -1855,11 +1859,13 @@ int fat_grid(int64_t work_items)
 // 4-per-lane instantiation.  One success-count atomic per block (block_count_add): <= 1024 per launch.
 struct RolloutGeometry { int epl, block, grid; bool pipe; };
 
-RolloutGeometry rollout_geometry(int64_t n, const void *masks, const void *reward, const void *flags)
+RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
+                                 const void *flags)
 {
-    // 2 envs per lane need an even batch and 8-byte aligned mask / reward streams (2-byte flags)
-    const bool ok2 = n % 2 == 0 && ((uintptr_t)masks & 7u) == 0 && ((uintptr_t)reward & 7u) == 0 &&
-                     ((uintptr_t)flags & 1u) == 0;
+    // 2 envs per lane need an even batch, even row strides and 8-byte aligned mask / reward streams
+    // (2-byte flags)
+    const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
+                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0;
     RolloutGeometry g;
     if (ok2 && n >= 131072) {
         g.epl = 2;
@@ -2248,12 +2254,31 @@ int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint
 
 int bpg_synth_masks(bpg_batch *b, int t0, int T, uint32_t *d_masks, void *stream)
 {
+    return bpg_synth_masks_ld(b, t0, T, d_masks, b ? b->n : 0, stream);
+}
+
+int bpg_synth_masks_ld(bpg_batch *b, int t0, int T, uint32_t *d_masks, int64_t ld, void *stream)
+{
     if (!b || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
     if (t0 < 0 || T < 1) return fail(BPG_ERR_ARG, "bad t0/T");
+    if (ld < b->n) return fail(BPG_ERR_ARG, "ld must be >= n_envs");
     DeviceGuard guard(b->device);
     hipLaunchKernelGGL(k_synth_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever, b->n,
-                       t0, T, d_masks, synth_const(b));
+                       t0, T, d_masks, ld, synth_const(b));
     return check_launch("k_synth_masks");
+}
+
+// Row stride for the time-major (T, ld) streams of an n-env batch.  Rows a power of two apart put
+// row t of every stream of a given env group on the same HBM channels, and a wave keeps 5-10 rows of
+// the same columns in flight: measured 62-68 % of peak at 2^20 .. 2^23 envs with ld = n against
+// 73-77 % with rows shifted by 0.75-1.5 KB each (profiles/r02_tune_row_stride.log; a 16 KB shift is
+// as bad as none).  ld = n rounded up to 256 elements, plus 256 when that leaves an even multiple.
+int64_t bpg_row_stride(int64_t n)
+{
+    if (n < 1) return 0;
+    int64_t ld = (n + 255) / 256 * 256;
+    if ((ld / 256) % 2 == 0) ld += 256;
+    return ld;
 }
 
 int bpg_get_achieved_goal_f32(bpg_batch *b, float *d_out, int64_t ld, void *stream)
@@ -2459,18 +2484,20 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     uint32_t *rw = reinterpret_cast<uint32_t *>(a->d_reward_tb);
     unsigned long long *cnt = a->d_success_count, *znext = a->d_zero_count;
     const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
+    const int64_t ldm = a->ld_masks ? a->ld_masks : b->n, ldo = a->ld_out ? a->ld_out : b->n;
+    if (ldm < b->n || ldo < b->n) return fail(BPG_ERR_ARG, "ld_masks / ld_out must be 0 or >= n_envs");
     int rcode = BPG_OK;
     if (!episode) {
-        const RolloutGeometry geo = rollout_geometry(b->n, a->d_masks, a->d_reward_tb, a->d_flags_tb);
+        const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb);
         const dim3 grid(geo.grid), block(geo.block);
 #define BPG_LAUNCH_ROLLOUT(SRC, EPL, OUT, UNR, PIPE)                                                          \
         do {                                                                                                  \
             if (a->reset_first)                                                                               \
                 hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, true, UNR, PIPE, true>), grid, block, 0, st,   \
-                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, cnt, znext); \
             else                                                                                              \
                 hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, false, UNR, PIPE, true>), grid, block, 0, st,  \
-                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, c, s, rc, cnt, znext); \
+                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, cnt, znext); \
         } while (0)
 #define BPG_LAUNCH_ROLLOUT_OUT(SRC, EPL, UNR, PIPE)                                                           \
         do {                                                                                                  \
@@ -2522,11 +2549,11 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
             }
             if (synth)
                 hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, RC, R, c, s,
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
                                    tab, rc, cnt, znext);
             else
                 hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
-                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, RC, R, c, s,
+                                   a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
                                    tab, rc, cnt, znext);
             return BPG_OK;
         });
@@ -2551,11 +2578,18 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream)
 int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma, double *d_G, int device_id,
                           void *stream)
 {
+    return bpg_discounted_return_ld(d_reward_tb, n, n, T, gamma, d_G, device_id, stream);
+}
+
+int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma, double *d_G,
+                             int device_id, void *stream)
+{
     if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
     if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
+    if (ld < n) return fail(BPG_ERR_ARG, "ld must be >= n");
     DeviceGuard guard(device_id);
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if ((T == 50 || T == 25 || T == 10) && n < ((int64_t)1 << 28)) {
+    if ((T == 50 || T == 25 || T == 10) && ld < ((int64_t)1 << 28)) {
         // register-resident fast path for the horizons in use (T = max_episode_steps = 50): 32 envs per
         // one-wave block, two lanes per env
         const dim3 pgrid((unsigned)((n + 31) / 32));
@@ -2563,11 +2597,11 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
         std::memset(&tab, 0, sizeof(tab));
         for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
         if (T == 50)
-            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         else if (T == 25)
-            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         else
-            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         return check_launch("k_discounted_return_reg");
     }
     PowTableBig big;
@@ -2578,7 +2612,7 @@ int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gam
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, T, R, big, d_G);
+    hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, ld, T, R, big, d_G);
     return check_launch("k_discounted_return");
 }
 

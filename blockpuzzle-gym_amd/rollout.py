@@ -41,17 +41,27 @@ def configure_dims(env):
     return dims
 
 
+def time_major_empty(T, B, dtype, device):
+    """A (T, B) device tensor for a time-major stream (masks, rewards, flags) whose rows are
+    bpg_row_stride(B) elements apart: rows a power of two apart land on the same HBM channels
+    (DESIGN.md section 4).  A view of a (T, ld) allocation; stride(1) == 1."""
+    ld = int(_lib.lib().bpg_row_stride(int(B)))
+    return torch.empty((T, ld), dtype=dtype, device=device)[:, :B]
+
+
 def discounted_return(reward_tb, gamma, out=None):
     """policy_gradient/rollout.py:255-258 on the GPU.  reward_tb: (T, B) float32
     (time-major) torch tensor; returns G (B, T) float64, bit-identical to the
     reference's in-order float64 accumulation."""
     assert reward_tb.dim() == 2 and reward_tb.dtype == torch.float32 and reward_tb.is_cuda
-    reward_tb = reward_tb.contiguous()
-    T, B = reward_tb.shape
+    if reward_tb.stride(1) != 1 or reward_tb.stride(0) < reward_tb.shape[1]:
+        reward_tb = reward_tb.contiguous()
+    T, B = reward_tb.shape                       # rows may be padded (time_major_empty): stride(0) >= B
     if out is None:
         out = torch.empty(B, T, dtype=torch.float64, device=reward_tb.device)
-    _lib.check(_lib.lib().bpg_discounted_return(_ptr(reward_tb), B, T, float(gamma), _ptr(out),
-                                                reward_tb.device.index, _stream(reward_tb.device)))
+    _lib.check(_lib.lib().bpg_discounted_return_ld(_ptr(reward_tb), B, int(reward_tb.stride(0)) if T > 1 else B, T,
+                                                   float(gamma), _ptr(out), reward_tb.device.index,
+                                                   _stream(reward_tb.device)))
     return out
 
 
@@ -323,14 +333,17 @@ class RolloutStudent:
             ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         if actions is not None:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device))               # stored as given (rollout.py:147)
-        reward = torch.empty((T, B), dtype=torch.float32, device=self.device) if want_reward else None
+        reward = time_major_empty(T, B, torch.float32, self.device) if want_reward else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
                                 d_ep_ag=ep['ag'].data_ptr(),
                                 d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
-                                d_ep_success=ep['info_is_success'].data_ptr())
-        if masks is not None:
-            assert masks.shape == (T, B) and masks.is_contiguous() and masks.element_size() == 4
+                                d_ep_success=ep['info_is_success'].data_ptr(),
+                                ld_out=0 if reward is None else int(reward.stride(0)))
+        if masks is not None:            # rows may be padded (time_major_empty): any row stride >= B
+            assert masks.shape == (T, B) and masks.stride(1) == 1 and masks.element_size() == 4 \
+                and (T == 1 or masks.stride(0) >= B)
+            args.ld_masks = int(masks.stride(0)) if T > 1 else B
         _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
         out = self._finish(ep)
         if want_reward:
@@ -407,7 +420,7 @@ class PGRolloutStudent(RolloutStudent):
         ep = self._alloc_episode(time_major=True, g=False, o=False)
         ep['o'] = self._reset_into_episode(test, num_grey)
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
-        reward = torch.empty((T, B), dtype=torch.float32, device=self.device)
+        reward = time_major_empty(T, B, torch.float32, self.device)
         ep['ag'][0] = self.initial_ag
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]

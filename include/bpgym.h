@@ -184,6 +184,15 @@ int bpg_step_synth(bpg_batch *b, float *d_reward, uint8_t *d_flags, void *stream
 /* Fills d_masks[T][n_envs] (time-major) with that synthetic source for steps
  * t0 .. t0+T-1 of the current episode. */
 int bpg_synth_masks(bpg_batch *b, int t0, int T, uint32_t *d_masks, void *stream);
+/* Same with a row stride: row t of the stream starts ld elements after row t-1 (ld >= n_envs). */
+int bpg_synth_masks_ld(bpg_batch *b, int t0, int T, uint32_t *d_masks, int64_t ld, void *stream);
+
+/* Row stride (in elements) this build recommends for the time-major (T, ld) streams of an
+ * n-env batch -- masks, rewards, flags (bpg_rollout_args.ld_masks / ld_out).  Build-defined
+ * layout choice, no reference counterpart (the reference has no time-major arrays; its episode
+ * arrays are batch-major, rollout.py:155-172): rows a power of two apart land on the same HBM
+ * channels, rows shifted by ~1 KB each do not.  Pure host function. */
+int64_t bpg_row_stride(int64_t n_envs);
 
 /* obs['achieved_goal'] / obs['desired_goal'] of _get_obs (fetch_env.py:219-228,
  * Variation :609-621) for the whole batch: env e's dimg values are written at
@@ -277,6 +286,8 @@ typedef struct {
     float *d_ep_success;       /* (n_envs, T, 1)      episode['info_is_success']  */
     unsigned long long *d_success_count; /* += #envs with has_succeeded after step T (rollout.py:163-167) */
     unsigned long long *d_zero_count;    /* optional second counter the launch sets to 0 (ping-pong) */
+    int64_t ld_masks;          /* row stride of d_masks in elements; 0 = n_envs (contiguous rows) */
+    int64_t ld_out;            /* row stride of d_reward_tb and d_flags_tb in elements; 0 = n_envs */
 } bpg_rollout_args;
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 
@@ -291,6 +302,9 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream);
  * in the kernel arguments, so the call only enqueues a launch (hipGraph-capturable). */
 int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma,
                           double *d_G, int device_id, void *stream);
+/* Same for a reward stream with row stride ld >= n (the padded rows bpg_rollout writes). */
+int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma,
+                             double *d_G, int device_id, void *stream);
 
 /* `np.isnan(o_new).any()` of the rollout worker (rollout.py:139-142) as a device-side flag:
  * *d_flag |= 1 when any of the rows x cols float32 values at d_x (row stride ld) is a NaN.  The

@@ -633,3 +633,106 @@ def test_toy_physics_backend_end_to_end():
     worker.policy = Idle()
     worker.generate_rollouts()
     assert worker.success_history[-1] == 0.0
+
+
+# --------------------------------------------------------------------------
+# padded rows of the time-major streams (bpg_row_stride, ld_masks / ld_out)
+# --------------------------------------------------------------------------
+def test_row_stride_helper():
+    L = bpg._lib.lib()
+    for n in (1, 255, 256, 257, 65536, 65537, 1 << 20, 3 << 19, (1 << 22) + 2):
+        ld = L.bpg_row_stride(n)
+        assert ld >= n and ld % 256 == 0 and (ld // 256) % 2 == 1 and ld - n < 512
+    assert L.bpg_row_stride(0) == 0
+
+
+@pytest.mark.parametrize('B,pad', [(65536, 256), (131072 + 2, 254), (524288, 256), (4096, 3), (1 << 20, 256)])
+def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
+    """Every consumer / producer of the (T, B) streams with rows ld = B + pad elements apart (even and odd
+    ld: the odd one falls back to one env per lane) == the contiguous form: synthetic masks, the packed
+    fused rollout, the episode writer, the discounted return (register and generic kernels)."""
+    env_id, T, L = 'BlocksTouchVariation-v0', 50, bpg._lib.lib()
+    ld = B + pad
+    P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    a, b = (bpg.make(env_id, num_envs=B, device=DEV, seed=21) for _ in range(2))
+    ng = torch.as_tensor(np.random.RandomState(B % 997).randint(3, size=B).astype(np.int32), device=DEV)
+    for e in (a, b):
+        e.reset(num_grey=ng)
+    m0 = torch.empty((T, B), dtype=torch.int32, device=DEV)
+    m1 = torch.full((T, ld), -1, dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks(a._h, 0, T, P(m0), None))
+    bpg._lib.check(L.bpg_synth_masks_ld(a._h, 0, T, P(m1), ld, None))
+    assert torch.equal(m1[:, :B], m0) and bool((m1[:, B:] == -1).all())           # the pad is never written
+
+    r0 = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    f0 = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+    r1 = torch.full((T, ld), 7.0, dtype=torch.float32, device=DEV)
+    f1 = torch.full((T, ld), 0xEE, dtype=torch.uint8, device=DEV)
+    c0, c1 = (torch.zeros(2, dtype=torch.int64, device=DEV) for _ in range(2))
+    for reset_first in (1, 0):
+        a0 = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=m0.data_ptr(),
+                                  d_reward_tb=r0.data_ptr(), d_flags_tb=f0.data_ptr(), d_success_count=c0.data_ptr())
+        a1 = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=m1.data_ptr(),
+                                  d_reward_tb=r1.data_ptr(), d_flags_tb=f1.data_ptr(), d_success_count=c1.data_ptr(),
+                                  ld_masks=ld, ld_out=ld)
+        bpg._lib.check(L.bpg_rollout(a._h, C.byref(a0), None))
+        bpg._lib.check(L.bpg_rollout(b._h, C.byref(a1), None))
+        assert torch.equal(r1[:, :B].view(torch.int32), r0.view(torch.int32)) and torch.equal(f1[:, :B], f0)
+        assert bool((r1[:, B:] == 7.0).all()) and bool((f1[:, B:] == 0xEE).all())
+        assert torch.equal(a.state_now, b.state_now) and torch.equal(a.state_ever, b.state_ever)
+        assert int(c0[0]) == int(c1[0])
+    # discounted return over the padded reward stream: T = 50 (register kernel) and T = 7 (generic)
+    for Tr in (50, 7):
+        G0 = torch.empty((B, Tr), dtype=torch.float64, device=DEV)
+        G1 = torch.empty((B, Tr), dtype=torch.float64, device=DEV)
+        bpg._lib.check(L.bpg_discounted_return(P(r0), B, Tr, 0.98, P(G0), 0, None))
+        bpg._lib.check(L.bpg_discounted_return_ld(P(r1), B, ld, Tr, 0.98, P(G1), 0, None))
+        assert torch.equal(G0.view(torch.int64), G1.view(torch.int64))
+    assert torch.equal(bpg.discounted_return(r1[:, :B], 0.98).view(torch.int64),
+                       bpg.discounted_return(r0, 0.98).view(torch.int64))
+    # mixed: padded masks in, contiguous out
+    r2 = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    a2 = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m1.data_ptr(),
+                              d_reward_tb=r2.data_ptr(), ld_masks=ld)
+    a0 = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m0.data_ptr(), d_reward_tb=r0.data_ptr())
+    bpg._lib.check(L.bpg_rollout(a._h, C.byref(a0), None))
+    bpg._lib.check(L.bpg_rollout(b._h, C.byref(a2), None))
+    assert torch.equal(r2.view(torch.int32), r0.view(torch.int32))
+    # the episode writer reading padded masks
+    if B <= 131074:
+        def episode(env, masks, ldm):
+            ag = torch.empty((B, T + 1, 36), dtype=torch.float32, device=DEV)
+            sc = torch.empty((B, T, 1), dtype=torch.float32, device=DEV)
+            rw = torch.full((T, ld), 3.0, dtype=torch.float32, device=DEV)
+            args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
+                                        d_ep_ag=ag.data_ptr(), d_ep_success=sc.data_ptr(), d_reward_tb=rw.data_ptr(),
+                                        ld_masks=ldm, ld_out=ld)
+            bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+            return ag, sc, rw
+        ag0, sc0, rw0 = episode(a, m0, 0)
+        ag1, sc1, rw1 = episode(b, m1, ld)
+        assert torch.equal(ag0, ag1) and torch.equal(sc0, sc1)
+        assert torch.equal(rw0[:, :B].view(torch.int32), r0.view(torch.int32)) and torch.equal(rw0, rw1)
+    # a stride below the batch size is refused
+    bad = bpg._lib.RolloutArgs(T=T, d_masks=m0.data_ptr(), ld_masks=B - 2)
+    assert L.bpg_rollout(a._h, C.byref(bad), None) != 0
+    assert L.bpg_synth_masks_ld(a._h, 0, 1, P(m0), B - 1, None) != 0
+    assert L.bpg_discounted_return_ld(P(r0), B, B - 1, 50, 0.98, P(G0), 0, None) != 0
+
+
+def test_worker_streams_use_the_recommended_row_stride():
+    B, T = 1 << 16, 50
+    t = bpg.time_major_empty(T, B, torch.float32, DEV)
+    assert t.shape == (T, B) and t.stride() == (bpg._lib.lib().bpg_row_stride(B), 1)
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make('BlocksTouchVariation-v0', num_envs=num_envs, device=DEV, seed=2),
+                           None, dims_of('BlocksTouchVariation-v0'), None, T, rollout_batch_size=B, output='torch')
+    env = w.env
+    masks = bpg.time_major_empty(T, B, torch.int32, DEV)
+    bpg._lib.check(bpg._lib.lib().bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(masks.data_ptr()), masks.stride(0), None))
+    ep1 = w.generate_rollouts_fused(masks=masks, want_reward=True)
+    ep2 = w.generate_rollouts_fused(masks=masks.contiguous(), want_reward=True)
+    assert ep1['reward_tb'].stride(0) == masks.stride(0)
+    assert torch.equal(ep1['reward_tb'].view(torch.int32), ep2['reward_tb'].view(torch.int32))
+    assert torch.equal(ep1['ag'], ep2['ag'])
+    G = bpg.discounted_return(ep1['reward_tb'], 0.98)
+    assert torch.equal(G.view(torch.int64), bpg.discounted_return(ep2['reward_tb'].contiguous(), 0.98).view(torch.int64))

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -15,7 +16,8 @@
 static int run(int64_t B)
 {
     const int T = 50, REPS = 40;
-    const size_t set_bytes = (size_t)B * T * 9;
+    const int64_t LD = B + (getenv("LDPAD") ? atoll(getenv("LDPAD")) : 0);     // row stride of the (T, LD) streams
+    const size_t set_bytes = (size_t)LD * T * 9;
     int NB = (int)((size_t)640 * 1024 * 1024 / set_bytes) + 1;      // > 2x the Infinity Cache in flight
     if (NB < 4) NB = 4;
     if (NB > 48) NB = 48;
@@ -24,8 +26,8 @@ static int run(int64_t B)
     std::vector<uint8_t *> flags(NB);
     CK(hipMalloc(&now, B * 4)); CK(hipMalloc(&ever, B * 4));
     for (int k = 0; k < NB; k++) {
-        CK(hipMalloc(&masks[k], (size_t)B * T * 4)); CK(hipMalloc(&reward[k], (size_t)B * T * 4));
-        CK(hipMalloc(&flags[k], (size_t)B * T));
+        CK(hipMalloc(&masks[k], (size_t)LD * T * 4)); CK(hipMalloc(&reward[k], (size_t)LD * T * 4));
+        CK(hipMalloc(&flags[k], (size_t)LD * T));
     }
     SynthConst s{}; s.seed = 1; s.env_base = 0;
     for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; }
@@ -33,7 +35,8 @@ static int run(int64_t B)
     hipLaunchKernelGGL(k_init, dim3(2048), dim3(256), 0, 0, now, ever, B, 6u);
     for (int k = 0; k < NB; k++) {
         s.seed = 1 + k;
-        hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, 0, T, masks[k], s);
+        for (int t = 0; t < T; t++)
+            hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, t, 1, masks[k] + (int64_t)t * LD, LD, s);
     }
     CK(hipDeviceSynchronize());
     uint32_t *d_counter; CK(hipMalloc(&d_counter, 8)); CK(hipMemset(d_counter, 0, 8));
@@ -42,6 +45,7 @@ static int run(int64_t B)
     ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1; rc.reset_counter = d_counter;
     const double bytes = (double)B * (T * 9 + 16);
     int rot = 0;
+    printf("== LD = %lld ", (long long)LD);
     printf("== B = %lld envs, T = %d, %d rotating buffer sets (%.0f MB each), bytes/launch = %.1f MB\n", (long long)B, T,
            NB, set_bytes / 1e6, bytes / 1e6);
     // back-to-back launches on one stream; per-launch time from events around each launch AND from
@@ -68,20 +72,37 @@ static int run(int64_t B)
 #define M masks[rot % NB]
 #define R reward[rot % NB]
 #define F flags[rot % NB]
-#define GEO(EPL, BLOCK, UNR, PIPE, NTL, COUNT)                                                                \
+#define GEO(EPL, BLOCK, UNR, PIPE, NTL, COUNT) GEOC(EPL, BLOCK, UNR, PIPE, NTL, COUNT, 1)
+    // CAPMUL: the grid is capped at CAPMUL x (1024 lanes' worth of blocks per CU); 0 = one block per
+    // tile of the batch, however many that is (blocks beyond the resident set start in index order
+    // as earlier ones retire)
+#define GEOC(EPL, BLOCK, UNR, PIPE, NTL, COUNT, CAPMUL)                                                        \
     do {                                                                                                       \
         const int64_t lanes = B / EPL;                                                                         \
         int64_t grid = (lanes + BLOCK - 1) / BLOCK;                                                            \
-        const int64_t cap = 256 * (1024 / BLOCK);                                                              \
-        if (grid > cap) grid = cap;                                                                            \
+        const int64_t cap = (int64_t)CAPMUL * 256 * (1024 / BLOCK);                                            \
+        if (cap && grid > cap) grid = cap;                                                                     \
         char nm[96];                                                                                           \
         snprintf(nm, 96, "epl%d block%-4d grid%-5lld unr%-2d %s %s %s", EPL, BLOCK, (long long)grid, UNR,      \
                  PIPE ? "pipe " : "plain", NTL ? "ntl" : "   ", COUNT ? "+count" : "      ");                  \
         TIME(nm, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, 3, true, UNR, PIPE, NTL>), dim3((unsigned)grid), \
-                                    dim3(BLOCK), 0, 0, now, ever, M, R, F, B, T, c, s, rc, COUNT ? cnt : nullptr, \
+                                    dim3(BLOCK), 0, 0, now, ever, M, R, F, B, T, LD, LD, c, s, rc, COUNT ? cnt : nullptr, \
                                     COUNT ? cnt + 1 : nullptr));                                               \
     } while (0)
     TIME("empty kernel (launch floor)", hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, d_counter));
+    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 2) {
+        GEOC(2, 1024, 5, false, true, 1, 1);
+        GEOC(1, 256, 10, true, true, 1, 0);
+    } else if (getenv("GEO_SHORT")) {                // the candidates around the library's thresholds
+        for (int rep = 0; rep < 2; rep++) {
+            GEOC(2, 1024, 5, false, true, 1, 1);
+            GEOC(2, 1024, 5, false, true, 1, 0);
+            GEOC(2, 256, 10, true, true, 1, 1);
+            GEOC(2, 256, 10, true, true, 1, 0);
+            GEOC(1, 256, 10, true, true, 1, 1);
+            GEOC(1, 256, 10, true, true, 1, 0);
+        }
+    } else
     for (int rep = 0; rep < 2; rep++) {
         GEO(4, 1024, 5, false, false, 1);
         GEO(4, 1024, 5, false, true, 1);
@@ -91,10 +112,24 @@ static int run(int64_t B)
         GEO(2, 256, 10, true, true, 1);
         GEO(1, 256, 10, true, false, 1);
         GEO(1, 256, 10, true, true, 1);
+        GEOC(2, 256, 10, true, true, 1, 0);
+        GEOC(2, 256, 10, true, true, 1, 2);
+        GEOC(1, 256, 10, true, true, 1, 0);
+        GEOC(1, 256, 10, true, true, 1, 2);
+        GEOC(2, 256, 5, false, true, 1, 0);
+        GEOC(1, 256, 5, false, true, 1, 0);
+        GEOC(2, 1024, 5, false, true, 1, 0);
+        GEOC(2, 512, 5, false, true, 1, 0);
+        GEOC(2, 512, 5, false, true, 1, 1);
+        GEOC(1, 512, 5, false, true, 1, 0);
+        GEOC(2, 128, 10, true, true, 1, 0);
+        GEOC(1, 128, 10, true, true, 1, 0);
+        GEOC(2, 64, 10, true, true, 1, 0);
+        GEOC(1, 64, 10, true, true, 1, 0);
     }
     // what the library picks
     {
-        const RolloutGeometry g = rollout_geometry(B, masks[0], reward[0], flags[0]);
+        const RolloutGeometry g = rollout_geometry(B, LD, LD, masks[0], reward[0], flags[0]);
         printf("library picks epl%d block%d grid%d\n", g.epl, g.block, g.grid);
     }
     CK(hipFree(now)); CK(hipFree(ever));

@@ -185,7 +185,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(k_init, dim3(2048), dim3(256), 0, 0, now, ever, B, 6u);
     for (rot = 0; rot < NB; rot++) {
         s.seed = 1 + rot;
-        hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, 0, T, masks, s);
+        hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, 0, T, masks, B, s);
     }
     CK(hipDeviceSynchronize());
     uint32_t *d_counter; CK(hipMalloc(&d_counter, 8)); CK(hipMemset(d_counter, 0, 8));   // ResetConst::reset_counter
@@ -225,7 +225,7 @@ int main(int argc, char **argv)
             ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1; rc0.reset_counter = d_counter;
             TIME("LIB k_rollout<masks,nt,4> 256x1024", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
+                                    reward, flags, B, T, B, B, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
         }
         {
@@ -234,20 +234,20 @@ int main(int argc, char **argv)
             if (!cnt) { CK(hipMalloc(&cnt, 16)); CK(hipMemset(cnt, 0, 16)); }
             TIME("LIB +count 256 blocks x 1024", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(256), dim3(1024), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+                                    reward, flags, B, T, B, B, c, s, rc0, cnt, cnt + 1));
             TIME("LIB +count 512 blocks x 512", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(512), dim3(512), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+                                    reward, flags, B, T, B, B, c, s, rc0, cnt, cnt + 1));
             TIME("LIB +count 1024 blocks x 256", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+                                    reward, flags, B, T, B, B, c, s, rc0, cnt, cnt + 1));
             TIME("LIB nocount 1024 blocks x 256", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(1024), dim3(256), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, (unsigned long long *)nullptr,
+                                    reward, flags, B, T, B, B, c, s, rc0, (unsigned long long *)nullptr,
                                     (unsigned long long *)nullptr));
             TIME("LIB +count 2048 blocks x 128", bytes,
                  hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 4, 3, true>), dim3(2048), dim3(128), 0, 0, now, ever, masks,
-                                    reward, flags, B, T, c, s, rc0, cnt, cnt + 1));
+                                    reward, flags, B, T, B, B, c, s, rc0, cnt, cnt + 1));
         }
         ROLL(1024, 5, false, false, 256);
         ROLL(256, 5, false, false, 1024);
@@ -307,25 +307,25 @@ int main(int argc, char **argv)
         }
         TIME("episode<6> plain stores", ebytes,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, false>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
-                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, RC, R, c, s, tab,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, B, B, RC, R, c, s, tab,
                                 rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
         TIME("episode<6> nt stores", ebytes,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
-                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, RC, R, c, s, tab,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, gg, sc, B, T, B, B, RC, R, c, s, tab,
                                 rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
         TIME("episode<6> plain, ag + success only", (double)B * (16 + T * 4) + 4.0 * (n_ag + n_s),
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, false>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
-                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, (float *)nullptr, sc, B, T, RC, R,
+                                ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, (float *)nullptr, sc, B, T, B, B, RC, R,
                                 c, s, tab, rc, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
         TIME("episode<6> nt, ag only", (double)B * (16 + T * 4) + 4.0 * n_ag,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
                                 ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, ag, (float *)nullptr,
-                                (float *)nullptr, B, T, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
+                                (float *)nullptr, B, T, B, B, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
                                 (unsigned long long *)nullptr));
         TIME("episode<6> nt, g only", (double)B * (16 + T * 4) + 4.0 * n_g,
              hipLaunchKernelGGL((k_episode<SIDE, SRC_MASKS, true>), dim3((unsigned)(B / 64)), dim3(64), lds, 0, now,
                                 ever, masks, (uint32_t *)nullptr, (uint8_t *)nullptr, (float *)nullptr, gg,
-                                (float *)nullptr, B, T, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
+                                (float *)nullptr, B, T, B, B, RC, R, c, s, tab, rc, (unsigned long long *)nullptr,
                                 (unsigned long long *)nullptr));
     }
     return 0;

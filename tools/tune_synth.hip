@@ -219,14 +219,14 @@ int main(int argc, char **argv)
         {
             SynthConst sc{}; sc.seed = 12345u; for (int n = 0; n < 8; n++) { sc.valid_by_n[n] = 0x1FFFFEu; sc.forced_by_n[n] = 0x700u; }
             ResetConst rc0{}; rc0.enabled = 1; rc0.is_variation = 1; rc0.base_nobj = 6; rc0.seed = 1; rc0.reset_counter = d_counter;
-            TIME("LIBRARY k_rollout<SYNTH,2,out3> 256x1024 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc0, cnt, cnt + 1));
+            TIME("LIBRARY k_rollout<SYNTH,2,out3> 256x1024 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc0, cnt, cnt + 1));
             ResetConst rc1 = rc0; rc1.enabled = 0;
-            TIME("LIBRARY k_rollout<SYNTH,2,out3> no reset, no count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, false, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc1, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
-            TIME("LIBRARY k_rollout<SYNTH,2,out3> reset, no count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc0, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
-            TIME("LIBRARY k_rollout<SYNTH,2,out3> no reset, count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, false, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc1, cnt, cnt + 1));
-            TIME("LIBRARY k_rollout<SYNTH,2,out3> 1024x256 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(1024), dim3(256), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc0, cnt, cnt + 1));
-            TIME("LIBRARY k_rollout<SYNTH,4,out3> 256x1024 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 4, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc0, cnt, cnt + 1));
-            TIME("LIBRARY k_rollout<SYNTH,1,out3> 1024x256 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 1, 3, true, 5, false>), dim3(1024), dim3(256), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, c, sc, rc0, cnt, cnt + 1));
+            TIME("LIBRARY k_rollout<SYNTH,2,out3> no reset, no count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, false, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc1, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
+            TIME("LIBRARY k_rollout<SYNTH,2,out3> reset, no count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc0, (unsigned long long *)nullptr, (unsigned long long *)nullptr));
+            TIME("LIBRARY k_rollout<SYNTH,2,out3> no reset, count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, false, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc1, cnt, cnt + 1));
+            TIME("LIBRARY k_rollout<SYNTH,2,out3> 1024x256 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 2, 3, true, 5, false>), dim3(1024), dim3(256), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc0, cnt, cnt + 1));
+            TIME("LIBRARY k_rollout<SYNTH,4,out3> 256x1024 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 4, 3, true, 5, false>), dim3(256), dim3(1024), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc0, cnt, cnt + 1));
+            TIME("LIBRARY k_rollout<SYNTH,1,out3> 1024x256 +count", hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, 1, 3, true, 5, false>), dim3(1024), dim3(256), 0, 0, now, ever, (const uint32_t *)nullptr, reward[rot % NB], flags[rot % NB], B, T, B, B, c, sc, rc0, cnt, cnt + 1));
         }
         RUN(Gen2<1>, 2, true, 1024, "2x 2-round, p = 1/8     epl2 b1024 unpacked");
         RUN(Gen2<2>, 2, true, 1024, "2x 1-round + tail 5/32  epl2 b1024 unpacked");
