@@ -56,6 +56,8 @@ def parse():
     p.add_argument('--prewarm', type=int, default=200,
                    help='untimed rollouts run during set-up, before the W warm-up steps, so that the clocks have '
                         'settled when the contract\'s warm-up starts (0.02 s at the default)')
+    p.add_argument('--contiguous-rows', action='store_true',
+                   help='time-major streams with rows exactly B elements apart (default: bpg_row_stride(B))')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -154,14 +156,21 @@ def main():
     # contact masks in the 256 MiB Infinity Cache from a previous launch: inputs come from HBM
     # (a set is B * 450 bytes: enough sets that two consecutive uses of one are > 2 x 256 MiB apart)
     NBUF = max(a.buffers, int(2.5 * 256 * 2**20 // (B * T * 9)) + 1)
+    # time-major (T, B) streams whose rows are LD = bpg_row_stride(B) elements apart (B + 256 for the
+    # power-of-two batch sizes): rows a power of two apart land on the same HBM channels.
+    # The pad is never read or written and is not counted in the bytes.  --contiguous-rows: LD = B.
+    LD = B if a.contiguous_rows else int(L.bpg_row_stride(B))
+
+    def tm_empty(dtype):
+        return torch.empty((T, LD), dtype=dtype, device=dev)[:, :B]
     masks, reward, flags = [], [], []
     for k in range(NBUF):
         env.seed(a.seed + k)
-        m = torch.empty((T, B), dtype=torch.int32, device=dev)
-        _lib.check(L.bpg_synth_masks(env._h, 0, T, C.c_void_p(m.data_ptr()), stream))
+        m = tm_empty(torch.int32)
+        _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(m.data_ptr()), LD, stream))
         masks.append(m)
-        reward.append(torch.empty((T, B), dtype=torch.float32, device=dev))
-        flags.append(torch.empty((T, B), dtype=torch.uint8, device=dev))
+        reward.append(tm_empty(torch.float32))
+        flags.append(tm_empty(torch.uint8))
     env.seed(a.seed)
     # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167).
     # Rollout i adds its success count straight into row i of `stats` = [successes, envs]; with
@@ -173,7 +182,7 @@ def main():
     rows = [stats[i] for i in range(n_it)]
     args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(),
                              d_masks=masks[i % NBUF].data_ptr(), d_reward_tb=reward[i % NBUF].data_ptr(),
-                             d_flags_tb=flags[i % NBUF].data_ptr(),
+                             d_flags_tb=flags[i % NBUF].data_ptr(), ld_masks=LD, ld_out=LD,
                              d_success_count=stats.data_ptr() + 16 * i) for i in range(n_it)]
     # ONE pair of HIP events on the launch stream around the K timed launches: the kernel's average
     # duration = elapsed / K.  (An event pair around every launch puts two marker packets between
@@ -214,7 +223,7 @@ def main():
     if a.prewarm > 0:                      # set-up, not measurement: same launch, scratch statistics row
         scratch = torch.zeros(2, dtype=torch.int64, device=dev)
         pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
-                                d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(),
+                                d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(), ld_masks=LD, ld_out=LD,
                                 d_success_count=scratch.data_ptr()) for k in range(NBUF)]
         for i in range(a.prewarm):
             _lib.check(L.bpg_rollout(env._h, C.byref(pre[i % NBUF]), stream))
@@ -274,9 +283,10 @@ def main():
         'higher_is_better': True, 'scaling': 'strong' if a.total_envs else 'weak', 'vs_baseline': None, 'dtype': 'u32',
         'data': 'synthetic',
         'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
-                               'resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
-                               'env-step' % (ENV_ID, B, T),
-                   'envs_per_gpu': B, 'total_envs': total, 'T': T, 'parallelism': 'env-shard x%d' % world,
+                               '(rows %d elements apart) resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
+                               'env-step' % (ENV_ID, B, T, LD),
+                   'envs_per_gpu': B, 'total_envs': total, 'T': T, 'row_stride_elements': LD,
+                   'parallelism': 'env-shard x%d' % world,
                    'buffer_sets': NBUF, 'collective': (a.collective if world > 1 else None),
                    'rollouts_per_collective': (R if world > 1 else None),
                    'success_rate': succ_rate},
@@ -348,7 +358,9 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
 
     # (0) on-box streaming ceiling: device-to-device copy of one (T,B) u32 array (read + write)
     src, dst = masks, reward.view(torch.int32)
+    src, dst = src.contiguous(), torch.empty((T, B), dtype=torch.int32, device=dev)
     res['copy_ceiling_torch_d2d'] = line(timed(lambda: dst.copy_(src), 20), 2 * masks.numel() * 4, 0)
+    del src, dst
 
     # (0a) the headline kernel at BASELINE.json's other batch sizes (configs[1]: 65 536 envs;
     # configs[3]: 4 194 304 over 8 GPUs = 524 288 per GPU), masks read cold from HBM
@@ -439,15 +451,17 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
 
     # (3) fused rollout with in-kernel synthetic contacts (SURVEY 8d's "contacts generated in-kernel"):
     # reward 4 + flags 1 written per env-step + 8 B of state per env (the in-launch reset reads nothing)
+    LD = int(masks.stride(0))             # the three streams share the row stride
+    assert reward.stride(0) == LD and flags.stride(0) == LD
     a2 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=None, d_reward_tb=reward.data_ptr(),
-                          d_flags_tb=flags.data_ptr())
+                          d_flags_tb=flags.data_ptr(), ld_out=LD)
 
     def synth():
         _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
     res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 8), B * T)
 
     # (3b) compact outputs: flags alone (bit2 encodes the reward) -> mask 4 in + flags 1 out per env-step
-    a2c = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_flags_tb=flags.data_ptr())
+    a2c = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_flags_tb=flags.data_ptr(), ld_masks=LD, ld_out=LD)
 
     def compact():
         _lib.check(L.bpg_rollout(env._h, C.byref(a2c), stream))
@@ -476,7 +490,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     G = torch.empty((B, T), dtype=torch.float64, device=dev)
 
     def dr():
-        _lib.check(L.bpg_discounted_return(C.c_void_p(reward.data_ptr()), B, T, 1.0 - 1.0 / T,
+        _lib.check(L.bpg_discounted_return_ld(C.c_void_p(reward.data_ptr()), B, LD, T, 1.0 - 1.0 / T,
                                            C.c_void_p(G.data_ptr()), dev.index, stream))
     res['discounted_return_f64'] = line(timed(dr, 5), B * T * 12, B * T)
     del G
@@ -487,7 +501,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         ag = torch.empty((B, T + 1, dimg), dtype=torch.float32, device=dev)
         gg = torch.empty((B, T, dimg), dtype=torch.float32, device=dev)
         sc = torch.empty((B, T, 1), dtype=torch.float32, device=dev)
-        a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(),
+        a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), ld_masks=LD,
                               d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(), d_ep_success=sc.data_ptr())
 
         def episode():
@@ -518,12 +532,12 @@ def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line):
     sets = []
     for k in range(nset):
         e.seed(7 + k)
-        m = torch.empty((T, Bx), dtype=torch.int32, device=dev)
-        _lib.check(L.bpg_synth_masks(e._h, 0, T, C.c_void_p(m.data_ptr()), stream))
-        sets.append((m, torch.empty((T, Bx), dtype=torch.float32, device=dev),
-                     torch.empty((T, Bx), dtype=torch.uint8, device=dev)))
+        m = bpg.time_major_empty(T, Bx, torch.int32, dev)        # rows bpg_row_stride(Bx) apart, as the headline
+        ld = int(m.stride(0))
+        _lib.check(L.bpg_synth_masks_ld(e._h, 0, T, C.c_void_p(m.data_ptr()), ld, stream))
+        sets.append((m, bpg.time_major_empty(T, Bx, torch.float32, dev), bpg.time_major_empty(T, Bx, torch.uint8, dev)))
     cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(),
+    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=ld, ld_out=ld,
                              d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
             for m, r, f in sets]
     it = [0]

@@ -1869,7 +1869,10 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
     RolloutGeometry g;
     if (ok2 && n >= 131072) {
         g.epl = 2;
-        const bool fat = n >= 524288 && n < 4194304;
+        // from 4 M envs on, contiguous power-of-two rows run best as many small pipelined blocks; rows
+        // shifted against each other (bpg_row_stride) keep the fat shape best at every size measured
+        const bool aliased = ld_masks % 4096 == 0 || ld_out % 4096 == 0;
+        const bool fat = n >= 524288 && (n < 4194304 || !aliased);
         g.block = fat ? 1024 : 256;
         g.pipe = !fat;
     } else {
@@ -2268,14 +2271,17 @@ int bpg_synth_masks_ld(bpg_batch *b, int t0, int T, uint32_t *d_masks, int64_t l
     return check_launch("k_synth_masks");
 }
 
-// Row stride for the time-major (T, ld) streams of an n-env batch.  Rows a power of two apart put
-// row t of every stream of a given env group on the same HBM channels, and a wave keeps 5-10 rows of
-// the same columns in flight: measured 62-68 % of peak at 2^20 .. 2^23 envs with ld = n against
-// 73-77 % with rows shifted by 0.75-1.5 KB each (profiles/r02_tune_row_stride.log; a 16 KB shift is
-// as bad as none).  ld = n rounded up to 256 elements, plus 256 when that leaves an even multiple.
+// Row stride for the time-major (T, ld) streams of an n-env batch.  A wave keeps 5-10 rows of the
+// same columns in flight, and rows a large power of two apart put all of them on the same HBM
+// channels: measured at 2^20 .. 2^23 envs, 53-68 % of peak with ld = n against 67-75 % with every row
+// shifted by 0.5-1.5 KB (profiles/r02_tune_row_stride.log; a 128-byte shift is worse than none, a
+// 16 KB shift as bad as none; the gain is largest on the boxes where ld = n is slowest).  Below 2^20
+// envs the shift does not pay (neutral up to 2^18, -2 % at 2^19 and 3 * 2^18).
+// ld = n below 2^20; otherwise n rounded up to 256 elements, plus 256 when that leaves an even multiple.
 int64_t bpg_row_stride(int64_t n)
 {
     if (n < 1) return 0;
+    if (n < ((int64_t)1 << 20)) return n;
     int64_t ld = (n + 255) / 256 * 256;
     if ((ld / 256) % 2 == 0) ld += 256;
     return ld;

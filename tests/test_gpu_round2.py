@@ -640,7 +640,9 @@ def test_toy_physics_backend_end_to_end():
 # --------------------------------------------------------------------------
 def test_row_stride_helper():
     L = bpg._lib.lib()
-    for n in (1, 255, 256, 257, 65536, 65537, 1 << 20, 3 << 19, (1 << 22) + 2):
+    for n in (1, 255, 65536, 65537, (1 << 20) - 1):
+        assert L.bpg_row_stride(n) == n                 # no shift below 2^20 envs
+    for n in (1 << 20, (1 << 20) + 1, 3 << 19, (1 << 22) + 2, 1 << 25):
         ld = L.bpg_row_stride(n)
         assert ld >= n and ld % 256 == 0 and (ld // 256) % 2 == 1 and ld - n < 512
     assert L.bpg_row_stride(0) == 0
@@ -722,16 +724,17 @@ def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
 
 def test_worker_streams_use_the_recommended_row_stride():
     B, T = 1 << 16, 50
-    t = bpg.time_major_empty(T, B, torch.float32, DEV)
-    assert t.shape == (T, B) and t.stride() == (bpg._lib.lib().bpg_row_stride(B), 1)
+    t = bpg.time_major_empty(T, 1 << 20, torch.float32, DEV)
+    assert t.shape == (T, 1 << 20) and t.stride() == ((1 << 20) + 256, 1)
+    del t
     w = bpg.RolloutStudent(lambda num_envs: bpg.make('BlocksTouchVariation-v0', num_envs=num_envs, device=DEV, seed=2),
                            None, dims_of('BlocksTouchVariation-v0'), None, T, rollout_batch_size=B, output='torch')
     env = w.env
-    masks = bpg.time_major_empty(T, B, torch.int32, DEV)
+    masks = torch.empty((T, B + 256), dtype=torch.int32, device=DEV)[:, :B]      # rows of the caller's choosing
     bpg._lib.check(bpg._lib.lib().bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(masks.data_ptr()), masks.stride(0), None))
     ep1 = w.generate_rollouts_fused(masks=masks, want_reward=True)
     ep2 = w.generate_rollouts_fused(masks=masks.contiguous(), want_reward=True)
-    assert ep1['reward_tb'].stride(0) == masks.stride(0)
+    assert ep1['reward_tb'].stride(0) == bpg._lib.lib().bpg_row_stride(B)
     assert torch.equal(ep1['reward_tb'].view(torch.int32), ep2['reward_tb'].view(torch.int32))
     assert torch.equal(ep1['ag'], ep2['ag'])
     G = bpg.discounted_return(ep1['reward_tb'], 0.98)

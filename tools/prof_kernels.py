@@ -23,6 +23,7 @@ from blockpuzzle_gym_amd import _lib  # noqa: E402
 ENV_ID, T, DEV = 'BlocksTouchVariation-v0', 50, torch.device('cuda', 0)
 L = _lib.lib()
 P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+TM = lambda B, dtype: bpg.time_major_empty(T, B, dtype, DEV)   # noqa: E731  (T, B) stream, rows bpg_row_stride(B) apart
 
 
 def rollout(B, reps, synth=False):
@@ -33,13 +34,14 @@ def rollout(B, reps, synth=False):
     sets = []
     for k in range(max(nset, 4)):
         env.seed(k)
-        m = torch.empty((T, B), dtype=torch.int32, device=DEV)
-        _lib.check(L.bpg_synth_masks(env._h, 0, T, P(m), None))
-        sets.append((m, torch.empty((T, B), dtype=torch.float32, device=DEV), torch.empty((T, B), dtype=torch.uint8, device=DEV)))
+        m = TM(B, torch.int32)
+        _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), m.stride(0), None))
+        sets.append((m, TM(B, torch.float32), TM(B, torch.uint8)))
     cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
     for i in range(reps):
         m, r, f = sets[i % len(sets)]
-        a = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=None if synth else ng.data_ptr(),
+        a = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=None if synth else ng.data_ptr(), ld_masks=m.stride(0),
+                             ld_out=r.stride(0),
                              d_masks=None if synth else m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
                              d_success_count=None if synth else cnt.data_ptr())
         _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
@@ -73,11 +75,11 @@ def main():
         elif w in ('record', 'return', 'episode', 'reward'):
             env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
             env.reset()
-            m = torch.empty((T, B), dtype=torch.int32, device=DEV)
-            _lib.check(L.bpg_synth_masks(env._h, 0, T, P(m), None))
-            r = torch.empty((T, B), dtype=torch.float32, device=DEV)
-            f = torch.empty((T, B), dtype=torch.uint8, device=DEV)
-            a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr())
+            m, r, f = TM(B, torch.int32), TM(B, torch.float32), TM(B, torch.uint8)
+            LD = m.stride(0)
+            _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), LD, None))
+            a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
+                                 ld_masks=LD, ld_out=LD)
             _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
             if w == 'record':
                 ag = torch.empty((B, 36), dtype=torch.float32, device=DEV)
@@ -87,12 +89,12 @@ def main():
             elif w == 'return':
                 G = torch.empty((B, T), dtype=torch.float64, device=DEV)
                 for i in range(10):
-                    _lib.check(L.bpg_discounted_return(P(r), B, T, 0.98, P(G), 0, None))
+                    _lib.check(L.bpg_discounted_return_ld(P(r), B, LD, T, 0.98, P(G), 0, None))
             elif w == 'episode':
                 ag = torch.empty((B, T + 1, 36), dtype=torch.float32, device=DEV)
                 gg = torch.empty((B, T, 36), dtype=torch.float32, device=DEV)
                 sc = torch.empty((B, T, 1), dtype=torch.float32, device=DEV)
-                a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(),
+                a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), ld_masks=LD, d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(),
                                       d_ep_success=sc.data_ptr())
                 for i in range(6):
                     _lib.check(L.bpg_rollout(env._h, C.byref(a3), None))
