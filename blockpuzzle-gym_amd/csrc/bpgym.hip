@@ -1604,16 +1604,29 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     }
 }
 
-template <int TT>
-__global__ void __launch_bounds__(64)
+// The waves of a block work on consecutive 32-env groups and never exchange anything: their LDS tiles
+// are private and synchronised at wave scope, the block only makes the four waves' 128-byte pieces of a
+// reward row arrive at the memory side together.
+constexpr int DR_WPB = 4;
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TT, int WPB = DR_WPB>
+__global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t ld, PowTable pw,
                         double *__restrict__ G)
 {
     constexpr int NI = (TT + 1) / 2;          // accumulators per lane (half 1 leaves the last one unused when T is odd)
     constexpr int R = TT | 1;                 // odd row stride of the 16 x T tile
-    __shared__ double tile[16 * R];
-    const int lane = threadIdx.x, e = lane & 31, q = lane >> 5;
-    const int64_t base = (int64_t)blockIdx.x * 32;
+    __shared__ double tiles[WPB][16 * R];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e = lane & 31, q = lane >> 5;
+    double *tile = tiles[wave];
+    const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 32;
+    if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
     const int nvalid = (int)((n - base) < 32 ? (n - base) : 32);
     const bool live = e < nvalid;
     // rw[s] = reward of step s + q.  Row bases are uniform (scalar unit), the per-lane part is ONE
@@ -1659,14 +1672,14 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int e0 = pass * 16;
-        if (pass) __syncthreads();                       // first half streamed out
+        if (pass) wave_lds_sync();                       // first half streamed out
         if (live && (e >> 4) == pass) {
             static_for<0, NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if (2 * i + q < TT) tile[(e - e0) * R + 2 * i + q] = acc[i];
             });
         }
-        __syncthreads();
+        wave_lds_sync();
         const int rows = nvalid - e0 < 16 ? (nvalid - e0 < 0 ? 0 : nvalid - e0) : 16;
         double *o = G + (base + e0) * (int64_t)TT;
         const int total = rows * TT;
@@ -1783,11 +1796,17 @@ k_fill_goal(float *__restrict__ out, int64_t total, int dimg, int64_t ld, PairTa
 // ---------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------
-int grid_for(int64_t work_items, int block)
+// cap = 2048: 256 CUs x 8 blocks, grid-stride the rest.  Pure read streams run faster as one short-lived
+// block per tile (blocks beyond the resident set start in address order as earlier ones retire: the
+// box's read ceiling is 6.2-6.7 TB/s that way against 5.2-5.5 for a grid-stride loop,
+// profiles/r02_stream_ceiling.log) -- those pass GRID_UNCAPPED; kernels with scattered small stores
+// (k_fill_goal: 2x slower uncapped) keep the cap.
+constexpr int64_t GRID_UNCAPPED = (int64_t)1 << 22;
+int grid_for(int64_t work_items, int block, int64_t cap = 2048)
 {
     int64_t g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;      // 256 CUs x 8 blocks, grid-stride the rest
+    if (g > cap) g = cap;
     return (int)g;
 }
 
@@ -2375,7 +2394,7 @@ int bpg_set_action_f64(bpg_batch *b, const float *d_actions, double *d_out9, voi
     if (!b || !d_actions || !d_out9) return fail(BPG_ERR_ARG, "NULL argument");
     if (!aligned16(d_actions)) return fail(BPG_ERR_ARG, "d_actions must be 16-byte aligned");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_set_action, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, d_actions, b->n,
+    hipLaunchKernelGGL(k_set_action, dim3(grid_for(b->n, 256, GRID_UNCAPPED)), dim3(256), 0, (hipStream_t)stream, d_actions, b->n,
                        b->info.block_gripper, d_out9);
     return check_launch("k_set_action");
 }
@@ -2598,16 +2617,16 @@ int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, in
     if ((T == 50 || T == 25 || T == 10) && ld < ((int64_t)1 << 28)) {
         // register-resident fast path for the horizons in use (T = max_episode_steps = 50): 32 envs per
         // one-wave block, two lanes per env
-        const dim3 pgrid((unsigned)((n + 31) / 32));
+        const dim3 pgrid((unsigned)((n + 32 * DR_WPB - 1) / (32 * DR_WPB))), pblock(64 * DR_WPB);
         PowTable tab;
         std::memset(&tab, 0, sizeof(tab));
         for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
         if (T == 50)
-            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         else if (T == 25)
-            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         else
-            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, block, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
+            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
         return check_launch("k_discounted_return_reg");
     }
     PowTableBig big;
@@ -2630,7 +2649,7 @@ int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint3
     if (rows == 0) return BPG_OK;
     DeviceGuard guard(device_id);
     if (ld == cols && aligned16(d_x))
-        hipLaunchKernelGGL(k_nan_flag<true>, dim3(grid_for((rows * cols + 15) / 16, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_nan_flag<true>, dim3(grid_for((rows * cols + 15) / 16, 256, GRID_UNCAPPED)), dim3(256), 0, (hipStream_t)stream,
                            d_x, rows, cols, ld, d_flag);
     else
         hipLaunchKernelGGL(k_nan_flag<false>, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d_x, rows,

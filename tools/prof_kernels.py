@@ -6,7 +6,7 @@ rocprofv3 (kernel trace or one --pmc counter set per invocation):
     rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
 
 kernels: rollout (fused, masks), rollout64k, rollout512k, synth (fused, in-kernel contacts),
-step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement)
+step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement), nan
 """
 import ctypes as C
 import os
@@ -121,6 +121,12 @@ def main():
                 env.assemble_observation(phys)
                 env.set_action_vector(u)
                 env.randomize_objects()
+            torch.cuda.synchronize()
+        elif w == 'nan':
+            x = torch.zeros(4, B, 87, dtype=torch.float32, device=DEV)
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            for i in range(12):
+                _lib.check(L.bpg_nan_flag_f32(P(x[i % 4]), B, 87, 87, P(flag), 0, None))
             torch.cuda.synchronize()
         else:
             raise SystemExit('unknown kernel %r' % w)
