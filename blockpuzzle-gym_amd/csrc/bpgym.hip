@@ -1062,12 +1062,32 @@ k_contacts_csr_to_masks(const uint32_t *__restrict__ ever, const uint32_t *__res
 // load and a dependent gather per element, one request in flight per lane -- 900 us for 1 M
 // Variation envs, 0.12 of HBM peak.)
 struct ObsConst {
-    int32_t dimo, nb_max, is_variation;
+    int32_t dimo, nb_max, is_variation, vec;    // vec: the arrays are 16-byte aligned
     int32_t colors[BPG_MAX_OBJS];
     double dt;
 };
 
-template <typename OutT>
+// An env's N consecutive doubles into registers: 16-byte loads when the row is an even number of
+// doubles (and the array 16-byte aligned), so that every 32-byte sector is requested by two instructions
+// instead of four.
+template <int N>
+__device__ __forceinline__ void load_row_f64(const double *__restrict__ p, bool vec, double *o)
+{
+    if (N % 2 == 0 && vec) {
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) {
+            const double2 v = reinterpret_cast<const double2 *>(p)[k];
+            o[2 * k] = v.x; o[2 * k + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) o[k] = p[k];
+    }
+}
+
+// NB = block slots of the variant (num_objs - 2): compile-time, so that the env's 10 + 12 * NB inputs
+// are all requested before the first one is used and live in registers with constant indices.
+template <typename OutT, int NB>
 __global__ void __launch_bounds__(64)
 k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, ObsConst oc,
                OutT *__restrict__ out, int64_t ld)
@@ -1081,52 +1101,51 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
     if (lane < nvalid) {
         const int64_t e = base + lane;
         OutT *row = tile + lane * dimo;
-        const int nblocks = (int)nobj_of(ever[e]) - 2;
-        const double gp[3] = {ph.d_grip_pos[e * 3], ph.d_grip_pos[e * 3 + 1], ph.d_grip_pos[e * 3 + 2]};
+        double gp[3], gvp[3], gs[2], gvl[2], pos[NB * 3], rot[NB * 3], vp[NB * 3], vr[NB * 3];
+        const uint32_t ev = ever[e];
+        load_row_f64<3>(ph.d_grip_pos + e * 3, false, gp);
+        load_row_f64<3>(ph.d_grip_velp + e * 3, false, gvp);
+        load_row_f64<2>(ph.d_gripper_state + e * 2, oc.vec != 0, gs);
+        load_row_f64<2>(ph.d_gripper_vel + e * 2, oc.vec != 0, gvl);
+        load_row_f64<NB * 3>(ph.d_obj_pos + e * (NB * 3), oc.vec != 0, pos);
+        load_row_f64<NB * 3>(ph.d_obj_rot + e * (NB * 3), oc.vec != 0, rot);
+        load_row_f64<NB * 3>(ph.d_obj_velp + e * (NB * 3), oc.vec != 0, vp);
+        load_row_f64<NB * 3>(ph.d_obj_velr + e * (NB * 3), oc.vec != 0, vr);
+        const int nblocks = (int)nobj_of(ev) - 2;
         double gv[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) gv[c] = __dmul_rn(ph.d_grip_velp[e * 3 + c], oc.dt);        // :191 / :571
+        for (int c = 0; c < 3; c++) gv[c] = __dmul_rn(gvp[c], oc.dt);                           // :191 / :571
         int k = 0;
         if (oc.is_variation) row[k++] = (OutT)(double)nblocks;                                  // :580
         // [grip_pos, gripper_state, grip_velp * dt, gripper_vel * dt]  (:222 / :580)
 #pragma unroll
         for (int c = 0; c < 3; c++) row[k++] = (OutT)gp[c];
 #pragma unroll
-        for (int c = 0; c < 2; c++) row[k++] = (OutT)ph.d_gripper_state[e * 2 + c];
+        for (int c = 0; c < 2; c++) row[k++] = (OutT)gs[c];
 #pragma unroll
         for (int c = 0; c < 3; c++) row[k++] = (OutT)gv[c];
 #pragma unroll
-        for (int c = 0; c < 2; c++) row[k++] = (OutT)__dmul_rn(ph.d_gripper_vel[e * 2 + c], oc.dt);
-        for (int blk = 0; blk < oc.nb_max; blk++) {
-            const int64_t o = (e * oc.nb_max + blk) * 3;
+        for (int c = 0; c < 2; c++) row[k++] = (OutT)__dmul_rn(gvl[c], oc.dt);
+        const int per = oc.is_variation ? 19 : 15;
+#pragma unroll
+        for (int blk = 0; blk < NB; blk++) {
             if (blk < nblocks) {
-                double pos[3], rot[3], vp[3], vr[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    pos[c] = ph.d_obj_pos[o + c]; rot[c] = ph.d_obj_rot[o + c];
-                    vp[c] = ph.d_obj_velp[o + c]; vr[c] = ph.d_obj_velr[o + c];
+                    row[k + c] = (OutT)pos[blk * 3 + c];
+                    row[k + 3 + c] = (OutT)__dsub_rn(pos[blk * 3 + c], gp[c]);                                    // :210
+                    row[k + 6 + c] = (OutT)rot[blk * 3 + c];
+                    row[k + 9 + c] = (OutT)__dsub_rn(__dmul_rn(vp[blk * 3 + c], oc.dt), gv[c]);                   // :207, :211
+                    row[k + 12 + c] = (OutT)__dmul_rn(vr[blk * 3 + c], oc.dt);                                    // :208
                 }
-#pragma unroll
-                for (int c = 0; c < 3; c++) row[k + c] = (OutT)pos[c];
-#pragma unroll
-                for (int c = 0; c < 3; c++) row[k + 3 + c] = (OutT)__dsub_rn(pos[c], gp[c]);                     // :210
-#pragma unroll
-                for (int c = 0; c < 3; c++) row[k + 6 + c] = (OutT)rot[c];
-#pragma unroll
-                for (int c = 0; c < 3; c++) row[k + 9 + c] = (OutT)__dsub_rn(__dmul_rn(vp[c], oc.dt), gv[c]);     // :207, :211
-#pragma unroll
-                for (int c = 0; c < 3; c++) row[k + 12 + c] = (OutT)__dmul_rn(vr[c], oc.dt);                      // :208
-                k += 15;
                 if (oc.is_variation) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) row[k + c] = (OutT)((oc.colors[blk + 2] == c) ? 1.0 : 0.0);       // one_hot_color :599
-                    k += 4;
+                    for (int c = 0; c < 4; c++) row[k + 15 + c] = (OutT)((oc.colors[blk + 2] == c) ? 1.0 : 0.0);  // one_hot_color :599
                 }
             } else {
-                const int per = oc.is_variation ? 19 : 15;
                 for (int c = 0; c < per; c++) row[k + c] = (OutT)0.0;                                             // zero padding :606-607
-                k += per;
             }
+            k += per;
         }
     }
     __syncthreads();
@@ -1875,7 +1894,7 @@ int fat_grid(int64_t work_items)
 //     1 048 576   89 us                              88.3 us  2/lane, 1024, plain
 //     4 194 304   372 us                             355 us   2/lane, 256, pipelined
 // 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
-// 4-per-lane instantiation.  One success-count atomic per block (block_count_add): <= 1024 per launch.
+// 4-per-lane instantiation.  One success-count atomic per block (block_count_add).
 struct RolloutGeometry { int epl, block, grid; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
@@ -1886,6 +1905,17 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
     const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
                      ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0;
     RolloutGeometry g;
+    if (ok2 && n >= 131072 && !masks) {
+        // contacts generated in-kernel: write-only and co-limited by the generator's arithmetic.  One
+        // short-lived 256-lane block per 512 envs (no grid cap: blocks start in address order as
+        // earlier ones retire), 10 steps per trip: 51 vs 53-58 us at 1 M envs, 178 vs 190-220 us at
+        // 4 M (profiles/r02_tune_geometry_synth.log)
+        g.epl = 2;
+        g.block = 256;
+        g.pipe = false;
+        g.grid = (int)((n / 2 + 255) / 256);
+        return g;
+    }
     if (ok2 && n >= 131072) {
         g.epl = 2;
         // from 4 M envs on, contiguous power-of-two rows run best as many small pipelined blocks; rows
@@ -2370,12 +2400,25 @@ static int assemble_obs(bpg_batch *b, const bpg_phys_state *ph, void *d_obs, int
     oc.dt = ph->dt;
     const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
     const size_t lds = (size_t)64 * b->info.dimo * (f64 ? sizeof(double) : sizeof(float));   // <= 44.5 KB
-    if (f64)
-        hipLaunchKernelGGL(k_assemble_obs<double>, grid, block, lds, (hipStream_t)stream, b->ever, b->n, *ph, oc,
-                           static_cast<double *>(d_obs), ld);
-    else
-        hipLaunchKernelGGL(k_assemble_obs<float>, grid, block, lds, (hipStream_t)stream, b->ever, b->n, *ph, oc,
-                           static_cast<float *>(d_obs), ld);
+    oc.vec = (aligned16(ph->d_gripper_state) && aligned16(ph->d_gripper_vel) && aligned16(ph->d_obj_pos) &&
+              aligned16(ph->d_obj_rot) && aligned16(ph->d_obj_velp) && aligned16(ph->d_obj_velr)) ? 1 : 0;
+#define BPG_LAUNCH_ASSEMBLE(NB)                                                                                   \
+    do {                                                                                                          \
+        if (f64)                                                                                                  \
+            hipLaunchKernelGGL((k_assemble_obs<double, NB>), grid, block, lds, (hipStream_t)stream, b->ever, b->n, *ph, \
+                               oc, static_cast<double *>(d_obs), ld);                                             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_assemble_obs<float, NB>), grid, block, lds, (hipStream_t)stream, b->ever, b->n, *ph,  \
+                               oc, static_cast<float *>(d_obs), ld);                                              \
+    } while (0)
+    switch (oc.nb_max) {
+    case 1: BPG_LAUNCH_ASSEMBLE(1); break;
+    case 2: BPG_LAUNCH_ASSEMBLE(2); break;
+    case 3: BPG_LAUNCH_ASSEMBLE(3); break;
+    case 4: BPG_LAUNCH_ASSEMBLE(4); break;
+    default: return fail(BPG_ERR_ARG, "unsupported number of block slots");
+    }
+#undef BPG_LAUNCH_ASSEMBLE
     return check_launch("k_assemble_obs");
 }
 
@@ -2539,7 +2582,7 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
             else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 2, 5, false);
             else BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 1, 10, true);
         } else {                                   // nothing to request: the plain loop
-            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 2, 5, false);
+            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 2, 10, false);
             else BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 1, 5, false);
         }
 #undef BPG_LAUNCH_ROLLOUT_OUT

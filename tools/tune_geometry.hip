@@ -90,7 +90,25 @@ static int run(int64_t B)
                                     COUNT ? cnt + 1 : nullptr));                                               \
     } while (0)
     TIME("empty kernel (launch floor)", hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, d_counter));
-    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 2) {
+#define GEOS(EPL, BLOCK, UNR, CAPMUL)                                                                          \
+    do {                                                                                                       \
+        const int64_t lanes = B / EPL;                                                                         \
+        int64_t grid = (lanes + BLOCK - 1) / BLOCK;                                                            \
+        const int64_t cap = (int64_t)CAPMUL * 256 * (1024 / BLOCK);                                            \
+        if (cap && grid > cap) grid = cap;                                                                     \
+        char nm[96];                                                                                           \
+        snprintf(nm, 96, "SYNTH epl%d block%-4d grid%-5lld unr%-2d", EPL, BLOCK, (long long)grid, UNR);         \
+        TIME(nm, hipLaunchKernelGGL((k_rollout<SRC_SYNTH, true, EPL, 3, true, UNR, false, true>), dim3((unsigned)grid), \
+                                    dim3(BLOCK), 0, 0, now, ever, (const uint32_t *)nullptr, R, F, B, T, LD, LD, c, s, rc, cnt, \
+                                    cnt + 1));                                                                 \
+    } while (0)
+    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 3) {       // in-kernel contacts: write-only
+        for (int rep = 0; rep < 2; rep++) {
+            GEOS(2, 1024, 5, 1); GEOS(2, 1024, 5, 0); GEOS(2, 512, 5, 1); GEOS(2, 512, 5, 0);
+            GEOS(2, 256, 5, 1); GEOS(2, 256, 5, 0); GEOS(1, 256, 5, 0); GEOS(1, 512, 5, 0); GEOS(1, 1024, 5, 0);
+            GEOS(2, 256, 10, 0); GEOS(1, 256, 10, 0); GEOS(4, 256, 5, 0); GEOS(4, 1024, 5, 1);
+        }
+    } else if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 2) {
         GEOC(2, 1024, 5, false, true, 1, 1);
         GEOC(1, 256, 10, true, true, 1, 0);
     } else if (getenv("GEO_SHORT")) {                // the candidates around the library's thresholds
