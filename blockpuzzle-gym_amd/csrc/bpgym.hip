@@ -663,7 +663,8 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
 // ------------------------------ fused rollout -------------------------------
 // rollout.py:163-167 inside a kernel: per-wave ballot + popcount, LDS sum over
 // the block's waves, ONE atomic per block (a same-address atomic costs ~12 ns
-// at the memory side, so the grid is kept at <= 256 fat blocks).
+// at the memory side; blocks finish at different times, so even the 8 192 blocks
+// of the contacts-in-kernel shape at 4 M envs do not queue up behind it).
 __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned long long *count)
 {
     __shared__ uint32_t s_part[16];
@@ -1886,13 +1887,14 @@ int fat_grid(int64_t work_items)
 // stream with T independent requests per lane, so what matters is (a) enough resident waves on
 // every CU to cover the HBM latency and (b), when there are not, that no wave waits for a store
 // round trip before it can consume a load (the pipelined loop).  Measured kernel time per launch:
-//     envs        plain 4/lane x 1024 (round 1)     chosen shape
-//     65 536      49 us                              10.8 us  1/lane, 256-lane blocks, pipelined
+//     envs        plain 4/lane x 1024 (round 1)     chosen shape (contiguous rows)
+//     65 536      49 us                              10.1 us  1/lane, 256-lane blocks, pipelined
 //     131 072     45 us                              15.2 us  2/lane, 256, pipelined
 //     262 144     52 us                              24.8 us  2/lane, 256, pipelined
-//     524 288     58 us                              45.7 us  2/lane, 1024, plain
-//     1 048 576   89 us                              88.3 us  2/lane, 1024, plain
-//     4 194 304   372 us                             355 us   2/lane, 256, pipelined
+//     524 288     58 us                              43-46 us 2/lane, 1024, plain
+//     1 048 576   89 us                              88-101 us 2/lane, 1024, plain   (80-86 us with shifted rows)
+//     4 194 304   372 us                             355 us   2/lane, 256, pipelined (317-322 us, 2/lane x 1024, shifted rows)
+// "Shifted rows": the row stride bpg_row_stride() recommends (profiles/r02_tune_row_stride.log).
 // 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
 // 4-per-lane instantiation.  One success-count atomic per block (block_count_add).
 struct RolloutGeometry { int epl, block, grid; bool pipe; };

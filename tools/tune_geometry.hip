@@ -102,7 +102,14 @@ static int run(int64_t B)
                                     dim3(BLOCK), 0, 0, now, ever, (const uint32_t *)nullptr, R, F, B, T, LD, LD, c, s, rc, cnt, \
                                     cnt + 1));                                                                 \
     } while (0)
-    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 3) {       // in-kernel contacts: write-only
+    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 4) {       // small batches: more rows in flight per lane
+        for (int rep = 0; rep < 2; rep++) {
+            GEOC(1, 256, 10, true, true, 1, 1); GEOC(1, 256, 25, true, true, 1, 1); GEOC(1, 256, 50, false, true, 1, 1);
+            GEOC(1, 128, 25, true, true, 1, 1); GEOC(1, 64, 25, true, true, 1, 1); GEOC(1, 64, 50, false, true, 1, 1);
+            GEOC(2, 256, 10, true, true, 1, 1); GEOC(2, 256, 25, true, true, 1, 1); GEOC(2, 128, 25, true, true, 1, 1);
+            GEOC(2, 64, 25, true, true, 1, 1);
+        }
+    } else if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 3) {       // in-kernel contacts: write-only
         for (int rep = 0; rep < 2; rep++) {
             GEOS(2, 1024, 5, 1); GEOS(2, 1024, 5, 0); GEOS(2, 512, 5, 1); GEOS(2, 512, 5, 0);
             GEOS(2, 256, 5, 1); GEOS(2, 256, 5, 0); GEOS(1, 256, 5, 0); GEOS(1, 512, 5, 0); GEOS(1, 1024, 5, 0);
