@@ -1635,27 +1635,50 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int TT, int WPB = DR_WPB>
+// STAGE: the rewards wait in LDS instead of registers.  Lane (e, q) fetches the rows t = 2i + q of env e
+// (NI requests instead of TT: each reward is requested once per wave, not once per half) into a
+// [TT][32] float tile that shares its LDS with the output tile, and virtual step s reads
+// stage[s + q][e]: 25 transient VGPRs instead of 50 live ones.  W = products issued ahead of their
+// additions.
+template <int TT, int WPB = DR_WPB, bool STAGE = true, int W = DR_W>
 __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t ld, PowTable pw,
                         double *__restrict__ G)
 {
     constexpr int NI = (TT + 1) / 2;          // accumulators per lane (half 1 leaves the last one unused when T is odd)
-    constexpr int R = TT | 1;                 // odd row stride of the 16 x T tile
-    __shared__ double tiles[WPB][16 * R];
+    // Row stride of the 16 x T output tile.  Even T: dense rows -- lane (e, q) writes element 2i + q of
+    // row e, 100 e + 2 (2i + q) in bank units, which is conflict-free over the 16 x 2 active lanes --
+    // so that the tile is the output image itself and streams out with 16-byte accesses.  Odd T: rows
+    // padded to an odd length (T | 1), 8-byte accesses.
+    constexpr bool DENSE = TT % 2 == 0;
+    constexpr int R = DENSE ? TT : (TT | 1);
+    constexpr int TILE_BYTES = (16 * R * 8 > TT * 32 * 4) ? 16 * R * 8 : TT * 32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TILE_BYTES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e = lane & 31, q = lane >> 5;
-    double *tile = tiles[wave];
+    double *tile = reinterpret_cast<double *>(lds_raw[wave]);
+    float *stage = reinterpret_cast<float *>(lds_raw[wave]);
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 32;
     if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
     const int nvalid = (int)((n - base) < 32 ? (n - base) : 32);
     const bool live = e < nvalid;
-    // rw[s] = reward of step s + q.  Row bases are uniform (scalar unit), the per-lane part is ONE
-    // 32-bit byte offset (env within the row, plus one row for the upper half of the wave): no
-    // per-load address arithmetic on the vector unit.  ld = row stride of the (T, ld) reward stream; the
-    // host guarantees 8 * ld < 2^32.
-    float rw[TT];
-    {
-        const uint32_t voff = (uint32_t)((int64_t)q * ld + base + (live ? e : 0)) * 4u;
+    // Row bases are uniform (scalar unit), the per-lane part is ONE 32-bit byte offset (env within the
+    // row, plus one row for the upper half of the wave): no per-load address arithmetic on the vector
+    // unit.  ld = row stride of the (T, ld) reward stream; the host guarantees 8 * ld < 2^32.
+    const uint32_t voff = (uint32_t)((int64_t)q * ld + base + (live ? e : 0)) * 4u;
+    float rw[STAGE ? 1 : TT];                 // !STAGE: rw[s] = reward of step s + q
+    if constexpr (STAGE) {
+        float tmp[NI];
+        static_for<0, NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)(2 * i) * ld);
+            tmp[i] = (2 * i + 1 < TT || q == 0) ? *reinterpret_cast<const float *>(row + voff) : 0.0f;
+        });
+        static_for<0, NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (2 * i + 1 < TT || q == 0) stage[(2 * i + q) * 32 + e] = tmp[i];
+        });
+        wave_lds_sync();
+    } else {
         static_for<0, TT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)s * ld);
@@ -1667,13 +1690,15 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
         constexpr int s = decltype(sc)::value;
         // half 1 is one step ahead: its last virtual step would be t = T
         if (s + 1 < TT || q == 0) {
-            const double rt = (double)rw[s];
+            double rt;
+            if constexpr (STAGE) rt = (double)stage[(s + q) * 32 + e];
+            else rt = (double)rw[s];
             if constexpr (s % 2 == 0) acc[s / 2] = rt;                     // t_ == t: G[t_] starts as r[t_]
             constexpr int npair = (s + 1) / 2;                             // returns 2i (+q) < t
-            static_for<0, (npair + DR_W - 1) / DR_W>([&](auto gc) {
-                constexpr int i0 = decltype(gc)::value * DR_W;
-                constexpr int cnt = (npair - i0) < DR_W ? (npair - i0) : DR_W;
-                double prod[DR_W];
+            static_for<0, (npair + W - 1) / W>([&](auto gc) {
+                constexpr int i0 = decltype(gc)::value * W;
+                constexpr int cnt = (npair - i0) < W ? (npair - i0) : W;
+                double prod[W];
                 static_for<0, cnt>([&](auto jc) {
                     constexpr int i = i0 + decltype(jc)::value;
                     prod[decltype(jc)::value] = pw.v[s - 2 * i] * rt;
@@ -1687,6 +1712,7 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
             });
         }
     });
+    if constexpr (STAGE) wave_lds_sync();     // every lane is done reading the staged rewards
     // 16 envs x T at a time through LDS (6.5 KB per wave: the LDS does not cap the occupancy below
     // what the registers allow), each pass streamed out as one contiguous 16 * T * 8-byte piece of G
 #pragma unroll
@@ -1703,12 +1729,19 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
         const int rows = nvalid - e0 < 16 ? (nvalid - e0 < 0 ? 0 : nvalid - e0) : 16;
         double *o = G + (base + e0) * (int64_t)TT;
         const int total = rows * TT;
-        int ee = 0, rem = lane;
-        while (rem >= TT) { rem -= TT; ee++; }
-        for (int f = lane; f < total; f += 64) {
-            o[f] = tile[ee * R + rem];
-            rem += 64;
+        if constexpr (DENSE) {
+            // (base + e0) * T * 8 bytes is a multiple of 16 * T * 8: 16-byte aligned
+            const double2 *t2 = reinterpret_cast<const double2 *>(tile);
+            double2 *o2 = reinterpret_cast<double2 *>(o);
+            for (int f = lane; f < total / 2; f += 64) o2[f] = t2[f];
+        } else {
+            int ee = 0, rem = lane;
             while (rem >= TT) { rem -= TT; ee++; }
+            for (int f = lane; f < total; f += 64) {
+                o[f] = tile[ee * R + rem];
+                rem += 64;
+                while (rem >= TT) { rem -= TT; ee++; }
+            }
         }
     }
 }

@@ -36,9 +36,12 @@ int main(int argc, char **argv)
                    bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);                                   \
         } while (0)
 #define RUN(WPB)                                                                                   \
-        TIME("waves/block " #WPB, hipLaunchKernelGGL((k_discounted_return_reg<50, WPB>),           \
+        TIME("waves/block " #WPB, hipLaunchKernelGGL((k_discounted_return_reg<50, WPB, false>),           \
              dim3((unsigned)((B + 32 * WPB - 1) / (32 * WPB))), dim3(64 * WPB), 0, 0, r[rot % NB], B, LD, tab, G[rot % NB]))
-        for (int rep = 0; rep < 2; rep++) { RUN(1); RUN(2); RUN(4); RUN(8); }
+#define RUNS(WPB, W)                                                                               \
+        TIME("staged, waves " #WPB " W " #W, hipLaunchKernelGGL((k_discounted_return_reg<50, WPB, true, W>), \
+             dim3((unsigned)((B + 32 * WPB - 1) / (32 * WPB))), dim3(64 * WPB), 0, 0, r[rot % NB], B, LD, tab, G[rot % NB]))
+        for (int rep = 0; rep < 2; rep++) { RUN(1); RUN(4); RUNS(4, 16); RUNS(4, 8); RUNS(4, 4); RUNS(2, 8); RUNS(8, 8); RUNS(1, 8); }
         for (int k = 0; k < NB; k++) { CK(hipFree(r[k])); CK(hipFree(G[k])); }
     }
     return 0;
