@@ -326,14 +326,14 @@ class BatchedBlocksEnv:
         self.difficulty += 1
         return False
 
-    def set_test(self, variates=None, env_mask=None):
+    def set_test(self, variates=None, env_mask=None, achieved_goal_out=None):
         if not self.info.set_test_supported:
             raise NotImplementedError()             # fetch_env.py:100-101
         # fetch_env.py:365-368 / :443-446 re-place the cubes at the maximum ranges and return
         # _get_obs(); Variation :641-644 only returns it (its re-placement is commented out).
         if not self.info.is_variation:
             self._place(test=True, env_mask=self._to_dev(env_mask, torch.uint8), variates=variates)
-        return self._get_obs()
+        return self._get_obs(ag_out=achieved_goal_out)
 
     def _place(self, test, env_mask, variates=None):
         """_randomize_objects for the envs being reset, handed to the contact source's on_reset
@@ -374,12 +374,13 @@ class BatchedBlocksEnv:
             x = torch.as_tensor(np.ascontiguousarray(x))
         return x.to(device=self.device, dtype=dtype).contiguous()
 
-    def reset(self, num_grey=None, env_mask=None, variates=None, observation_out=None):
+    def reset(self, num_grey=None, env_mask=None, variates=None, observation_out=None, achieved_goal_out=None):
         """robot_env.py:71-82.  num_grey: optional explicit (B,) draws for Variation's
         np_random.randint(3) (fetch_env.py:647); env_mask: optional (B,) partial reset (the
         reference's reset_rollout(i)); variates: optional explicit placement draws (see
         randomize_objects); observation_out: optional (B, dimo) float32 buffer that becomes
-        `env.observation`.  One launch resets the state and rewrites the observation rows of the envs
+        `env.observation`; achieved_goal_out: optional (B, dimg) float32 view (unit inner stride, e.g.
+        time slot 0 of an episode) that receives obs['achieved_goal'].  One launch resets the state and rewrites the observation rows of the envs
         being reset (the entries the reference fills without physics, zeros in the physics-owned ones:
         a backend writes those from its on_reset); when the contact source consumes positions (`wants_positions`) the cubes are
         re-placed on the same stream and handed to its on_reset, as _reset_sim does
@@ -396,7 +397,7 @@ class BatchedBlocksEnv:
         _lib.check(self._L.bpg_reset_obs(self._h, _ptr(ng), _ptr(em), _ptr(obs), int(obs.stride(0)),
                                          _stream(self.device)))
         self._place(test=False, env_mask=em, variates=variates)
-        return self._get_obs()
+        return self._get_obs(ag_out=achieved_goal_out)
 
     def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None,
                    u_out=None):

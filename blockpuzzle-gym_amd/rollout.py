@@ -106,10 +106,10 @@ class RolloutStudent:
         self.clear_history()
 
     # -- rollout.py:47-64 -------------------------------------------------
-    def reset_all_rollouts(self, test=False, num_grey=None, observation_out=None):
-        obs = self.env.reset(num_grey=num_grey, observation_out=observation_out)
-        if test:
-            obs = self.env.unwrapped.set_test()      # maximum difficulty (rollout.py:53-55)
+    def reset_all_rollouts(self, test=False, num_grey=None, observation_out=None, achieved_goal_out=None):
+        obs = self.env.reset(num_grey=num_grey, observation_out=observation_out, achieved_goal_out=achieved_goal_out)
+        if test:                                     # maximum difficulty (rollout.py:53-55)
+            obs = self.env.unwrapped.set_test(achieved_goal_out=achieved_goal_out)
         # the env hands out its observation / goal buffers and a fresh achieved_goal tensor: no copies here
         self.initial_o = obs['observation']
         self.initial_ag = obs['achieved_goal']
@@ -202,7 +202,7 @@ class RolloutStudent:
         flag = getattr(self, '_nan_flag', None)
         return flag is not None and self._watch_o and bool(flag.item())
 
-    def _reset_into_episode(self, test, num_grey):
+    def _reset_into_episode(self, test, num_grey, ag_out=None):
         """reset_all_rollouts with the episode's first observation as the reset's target, and where
         the T+1 observations of the episode live.  A backend that rewrites the whole observation every
         step (`writes_observation`) gets time slot t+1 as its target during step t (env.observation
@@ -218,10 +218,10 @@ class RolloutStudent:
                 self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._nan_flag.zero_()
             o = torch.empty((T + 1, B, self.dims['o']), **f32)
-            self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o[0])
+            self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o[0], achieved_goal_out=ag_out)
             return o
         o0 = torch.empty((B, self.dims['o']), **f32)
-        self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)
+        self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0, achieved_goal_out=ag_out)
         return o0[None].expand(T + 1, B, self.dims['o'])
 
     def _step_into(self, u, ep, t, reward_out=None, u_store=None):
@@ -246,8 +246,7 @@ class RolloutStudent:
         # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
         # the next achieved_goal straight into slot t+1
         ep = self._alloc_episode(time_major=True, g=False, o=False)
-        ep['o'] = self._reset_into_episode(test, num_grey)
-        ep['ag'][0] = self.initial_ag
+        ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])   # slot 0 = initial_ag (rollout.py:82-83)
         Qs = []
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]
@@ -418,10 +417,9 @@ class PGRolloutStudent(RolloutStudent):
         env, B, T = self.env, self.rollout_batch_size, self.T
         beta = self.beta() if self.expert is not None else 0
         ep = self._alloc_episode(time_major=True, g=False, o=False)
-        ep['o'] = self._reset_into_episode(test, num_grey)
+        ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
         reward = time_major_empty(T, B, torch.float32, self.device)
-        ep['ag'][0] = self.initial_ag
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]
             if np.random.rand() < beta:
