@@ -15,7 +15,7 @@
 
 static int run(int64_t B)
 {
-    const int T = 50, REPS = 40;
+    const int T = getenv("GEO_T") ? atoi(getenv("GEO_T")) : 50, REPS = 40;
     const int64_t LD = B + (getenv("LDPAD") ? atoll(getenv("LDPAD")) : 0);     // row stride of the (T, LD) streams
     const size_t set_bytes = (size_t)LD * T * 9;
     int NB = (int)((size_t)640 * 1024 * 1024 / set_bytes) + 1;      // > 2x the Infinity Cache in flight
