@@ -418,6 +418,18 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
         const uint8_t *__restrict__ env_mask, StaticObs so)
 {
     __shared__ uint8_t s_nblocks[256];              // 0xFF = env not touched by this launch
+    // whole-row form: the row is a function of the episode's block count alone -> one template row
+    // per count (<= 5 x 87 floats), built once per block; the streaming loop below is then two LDS
+    // reads per element instead of obs_entry()'s divisions
+    __shared__ float s_tmpl[(BPG_MAX_OBJS - 1) * 88];
+    if (so.enabled && so.flat) {
+        const int nt = (so.nb_max + 1) * so.dimo;
+        for (int i = threadIdx.x; i < nt; i += 256) {
+            const int nb = i / so.dimo;
+            bool owned;
+            s_tmpl[i] = obs_entry(so, i - nb * so.dimo, nb, owned);
+        }
+    }
     const int64_t nblk = (n + 255) / 256;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t base = blk * 256, i = base + threadIdx.x;
@@ -447,16 +459,14 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
                 int e = (4 * q) / so.dimo, k = 4 * q - e * so.dimo;            // one division per float4
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    bool owned;
-                    v[c] = obs_entry(so, k, s_nblocks[e], owned);
+                    v[c] = s_tmpl[s_nblocks[e] * so.dimo + k];
                     if (++k == so.dimo) { k = 0; e++; }
                 }
                 reinterpret_cast<float4 *>(o)[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
             for (int f = 4 * nq + threadIdx.x; f < total; f += 256) {
                 const int e = f / so.dimo;
-                bool owned;
-                o[f] = obs_entry(so, f - e * so.dimo, s_nblocks[e], owned);
+                o[f] = s_tmpl[s_nblocks[e] * so.dimo + (f - e * so.dimo)];
             }
             continue;
         }

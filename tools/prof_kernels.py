@@ -6,7 +6,7 @@ rocprofv3 (kernel trace or one --pmc counter set per invocation):
     rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
 
 kernels: rollout (fused, masks), rollout64k, rollout512k, synth (fused, in-kernel contacts),
-step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement), nan
+step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement), nan, reset
 """
 import ctypes as C
 import os
@@ -121,6 +121,13 @@ def main():
                 env.assemble_observation(phys)
                 env.set_action_vector(u)
                 env.randomize_objects()
+            torch.cuda.synchronize()
+        elif w == 'reset':
+            env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+            ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 7) % 3
+            obs = [torch.empty(B, 87, dtype=torch.float32, device=DEV) for _ in range(3)]
+            for i in range(13):
+                env.reset(num_grey=ng, observation_out=obs[i % 3])
             torch.cuda.synchronize()
         elif w == 'nan':
             x = torch.zeros(4, B, 87, dtype=torch.float32, device=DEV)
