@@ -1696,12 +1696,19 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
         });
     }
     double acc[NI];
+    // STAGE: the reward of virtual step s + 1 is requested from LDS before the arithmetic of step s
+    // (the sched_barriers below keep the compiler from moving the read), so its latency is never exposed
+    float rcur = 0.0f, rnext = 0.0f;
+    if constexpr (STAGE) rcur = stage[q * 32 + e];
     static_for<0, TT>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
+        if constexpr (STAGE && s + 1 < TT) {
+            if (s + 2 < TT || q == 0) rnext = stage[(s + 1 + q) * 32 + e];
+        }
         // half 1 is one step ahead: its last virtual step would be t = T
         if (s + 1 < TT || q == 0) {
             double rt;
-            if constexpr (STAGE) rt = (double)stage[(s + q) * 32 + e];
+            if constexpr (STAGE) rt = (double)rcur;
             else rt = (double)rw[s];
             if constexpr (s % 2 == 0) acc[s / 2] = rt;                     // t_ == t: G[t_] starts as r[t_]
             constexpr int npair = (s + 1) / 2;                             // returns 2i (+q) < t
@@ -1721,6 +1728,7 @@ k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t 
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        rcur = rnext;
     });
     if constexpr (STAGE) wave_lds_sync();     // every lane is done reading the staged rewards
     // 16 envs x T at a time through LDS (6.5 KB per wave: the LDS does not cap the occupancy below
