@@ -868,7 +868,8 @@ __device__ __forceinline__ float tern(uint32_t now, uint32_t ever, uint32_t p)
 // (env_stride = rows * DIMG when the whole region is contiguous).
 template <int SIDE, bool NT>
 __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int nvalid, int rows, int env_stride,
-                                                    const uint2 *hist, int R, const PairTable *tab, int lane)
+                                                    const uint2 *hist, int R, const PairTable *tab, int lane,
+                                                    int nlanes = 64)
 {
     constexpr int DIMG = SIDE * SIDE;
     if (SIDE % 2 == 0) {
@@ -881,7 +882,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
         // iteration) measured SLOWER (3.0 vs 2.45 ms for the full episode at 1 M envs)
         int e = 0, rem = lane;
         while (rem >= per_env) { rem -= per_env; e++; }
-        for (int cidx = lane; cidx < total; cidx += 64) {
+        for (int cidx = lane; cidx < total; cidx += nlanes) {
             const int r = rem / QPR, q = rem - r * QPR;
             const uint2 h = hist[e * R + r];
             const uint32_t pw = tab->quad[q];
@@ -891,7 +892,7 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
             v.z = tern(h.x, h.y, (pw >> 10) & 31u);
             v.w = tern(h.x, h.y, (pw >> 15) & 31u);
             st_f4<NT>(&o4[(int64_t)e * es4 + rem], v);
-            rem += 64;
+            rem += nlanes;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
     } else {
@@ -899,11 +900,11 @@ __device__ __forceinline__ void wave_write_matrices(float *__restrict__ out, int
         const int total = nvalid * per_env;
         int e = 0, rem = lane;
         while (rem >= per_env) { rem -= per_env; e++; }
-        for (int f = lane; f < total; f += 64) {
+        for (int f = lane; f < total; f += nlanes) {
             const int r = rem / DIMG, k = rem - r * DIMG;
             const uint2 h = hist[e * R + r];
             st_1<NT>(&out[(int64_t)e * env_stride + rem], tern(h.x, h.y, tab->flat[k]));
-            rem += 64;
+            rem += nlanes;
             while (rem >= per_env) { rem -= per_env; e++; }
         }
     }
@@ -1410,7 +1411,7 @@ k_randomize_objects(const uint32_t *__restrict__ ever, int64_t n, PlaceConst pc,
 // streams its contiguous slices of episode['ag'] (B,T+1,dimg), episode['g']
 // (B,T,dimg) and episode['info_is_success'] (B,T,1) as float32.
 template <int SIDE, int SRC, bool NT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
@@ -1425,13 +1426,13 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2 *hist = reinterpret_cast<uint2 *>(smem);                       // [64][R]
     PairTable *tab = reinterpret_cast<PairTable *>(smem + (size_t)64 * R * sizeof(uint2));
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, nlanes = blockDim.x;     // wave 0 (lane < 64) steps the envs, every wave streams
     if (lane == 0) *tab = tabv;
     if (zero_next && blockIdx.x == 0 && lane == 0) *zero_next = 0ull;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-    const bool active = lane < nvalid;
-    const int64_t i = base + lane;
+    const bool active = lane < nvalid;                        // nvalid <= 64: only wave 0 can be active
+    const int64_t i = base + (active ? lane : 0);
     uint32_t a = 0, e = 0;
     SynthLane sl = {};
     if (active) {
@@ -1472,7 +1473,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         __syncthreads();
         if (ep_ag)
             wave_write_matrices<SIDE, NT>(ep_ag + (base * (int64_t)(T + 1) + r0) * DIMG, nvalid, r1 - r0,
-                                          (T + 1) * DIMG, hist, R, tab, lane);
+                                          (T + 1) * DIMG, hist, R, tab, lane, nlanes);
         if (ep_succ) {
             // info['is_success'] after step t = latch in row t+1 (rollout.py:127-128,131)
             const int rs = (r0 == 0) ? 1 : r0, cnt = r1 - rs;    // rows rs .. r1-1 -> steps rs-1 .. r1-2
@@ -1480,16 +1481,16 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             const int total = nvalid * cnt;
             int ee = 0, rem = lane;
             while (cnt > 0 && rem >= cnt) { rem -= cnt; ee++; }
-            for (int f = lane; f < total; f += 64) {
+            for (int f = lane; f < total; f += nlanes) {
                 st_1<NT>(&o[(int64_t)ee * T + rem], (hist[ee * R + (rs - r0) + rem].y >> 31) ? 1.0f : 0.0f);
-                rem += 64;
+                rem += nlanes;
                 while (rem >= cnt) { rem -= cnt; ee++; }
             }
         }
         __syncthreads();                                         // the tile is reused by the next chunk
     }
     if (active) { now[i] = a; ever[i] = e; }
-    if (count) {
+    if (count && lane < 64) {
         const unsigned long long nb = (unsigned long long)__popcll(__ballot(active && (e >> 31) != 0));
         if (lane == 0 && nb) atomicAdd(count, nb);
     }
@@ -1500,13 +1501,13 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         if (SIDE % 2 == 0) {
             constexpr int QPR = DIMG / 4;
             float4 *o4 = reinterpret_cast<float4 *>(o);
-            for (int cidx = lane; cidx < total / 4; cidx += 64) {
+            for (int cidx = lane; cidx < total / 4; cidx += nlanes) {
                 const int q = cidx % QPR;
                 st_f4<NT>(&o4[cidx], make_float4(tab->goal[4 * q], tab->goal[4 * q + 1], tab->goal[4 * q + 2],
                                                  tab->goal[4 * q + 3]));
             }
         } else {
-            for (int f = lane; f < total; f += 64) st_1<NT>(&o[f], tab->goal[f % DIMG]);
+            for (int f = lane; f < total; f += nlanes) st_1<NT>(&o[f], tab->goal[f % DIMG]);
         }
     }
 }
@@ -2657,7 +2658,9 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         const int R = RC | 1;
         const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
         const PairTable tab = pair_table(b->info);
-        const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
+        // two waves per 64-env block: the first steps the envs, both stream the block's region (2.5-3 %
+        // over one wave on three boxes; three or four waves add nothing)
+        const dim3 grid((unsigned)((b->n + 63) / 64)), block(128);
         const bool synth = (a->d_masks == nullptr);
         rcode = dispatch_side(b->info.side, [&](auto side) {
             constexpr int S = decltype(side)::value;
