@@ -117,3 +117,20 @@ def test_shard_ranges_cover_the_batch():
             assert a[1] == b[0]
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_row_stride_helper_is_a_pure_host_function():
+    """bpg_row_stride (layout of the time-major streams) needs no GPU: contiguous rows
+    below 2^20 envs, above that an odd multiple of 256 elements (rows shifted by 1 KB against each other)."""
+    L = _lib.lib()
+    assert L.bpg_row_stride(0) == 0 and L.bpg_row_stride(-5) == 0
+    for n in (1, 3, 65536, (1 << 20) - 1):
+        assert L.bpg_row_stride(n) == n
+    assert L.bpg_row_stride(1 << 20) == (1 << 20) + 256
+    assert L.bpg_row_stride((1 << 20) + 256) == (1 << 20) + 256          # already an odd multiple
+    for n in (1 << 20, (1 << 20) + 1, 3 << 19, 1 << 22, (1 << 22) + 2, 1 << 25, 45_000_002):
+        ld = L.bpg_row_stride(n)
+        assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
+    # the struct the header declares and the ctypes mirror agree on the new trailing fields
+    a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16

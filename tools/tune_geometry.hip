@@ -102,7 +102,13 @@ static int run(int64_t B)
                                     dim3(BLOCK), 0, 0, now, ever, (const uint32_t *)nullptr, R, F, B, T, LD, LD, c, s, rc, cnt, \
                                     cnt + 1));                                                                 \
     } while (0)
-    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 4) {       // small batches: more rows in flight per lane
+    if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 5) {       // rows in flight per lane at the fat shape
+        for (int rep = 0; rep < 2; rep++) {
+            GEOC(2, 1024, 5, false, true, 1, 1); GEOC(2, 1024, 2, false, true, 1, 1); GEOC(2, 1024, 3, false, true, 1, 1);
+            GEOC(2, 1024, 10, false, true, 1, 1); GEOC(2, 512, 5, false, true, 1, 1); GEOC(2, 512, 10, false, true, 1, 1);
+            GEOC(2, 1024, 5, false, false, 1, 1);
+        }
+    } else if (getenv("GEO_SHORT") && atoi(getenv("GEO_SHORT")) == 4) {       // small batches: more rows in flight per lane
         for (int rep = 0; rep < 2; rep++) {
             GEOC(1, 256, 10, true, true, 1, 1); GEOC(1, 256, 25, true, true, 1, 1); GEOC(1, 256, 50, false, true, 1, 1);
             GEOC(1, 128, 25, true, true, 1, 1); GEOC(1, 64, 25, true, true, 1, 1); GEOC(1, 64, 50, false, true, 1, 1);
