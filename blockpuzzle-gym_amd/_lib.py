@@ -41,7 +41,7 @@ class RolloutArgs(C.Structure):
 class PhysState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ('d_grip_pos', 'd_grip_velp', 'd_gripper_state', 'd_gripper_vel',
-                 'd_obj_pos', 'd_obj_rot', 'd_obj_velp', 'd_obj_velr')] + [('dt', C.c_double)]
+                 'd_obj_pos', 'd_obj_rot', 'd_obj_velp', 'd_obj_velr')] + [('dt', C.c_double), ('d_nan_flag', C.c_void_p)]
 
 
 class PlacementArgs(C.Structure):

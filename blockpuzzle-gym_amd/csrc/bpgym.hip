@@ -1110,6 +1110,8 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
     const int dimo = oc.dimo;
+    bool bad = false;                          // any NaN among the values this lane writes (ph.d_nan_flag)
+    auto put = [&](OutT *p, double v) { bad |= (v != v); *p = (OutT)v; };
     if (lane < nvalid) {
         const int64_t e = base + lane;
         OutT *row = tile + lane * dimo;
@@ -1131,24 +1133,24 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
         if (oc.is_variation) row[k++] = (OutT)(double)nblocks;                                  // :580
         // [grip_pos, gripper_state, grip_velp * dt, gripper_vel * dt]  (:222 / :580)
 #pragma unroll
-        for (int c = 0; c < 3; c++) row[k++] = (OutT)gp[c];
+        for (int c = 0; c < 3; c++) put(&row[k++], gp[c]);
 #pragma unroll
-        for (int c = 0; c < 2; c++) row[k++] = (OutT)gs[c];
+        for (int c = 0; c < 2; c++) put(&row[k++], gs[c]);
 #pragma unroll
-        for (int c = 0; c < 3; c++) row[k++] = (OutT)gv[c];
+        for (int c = 0; c < 3; c++) put(&row[k++], gv[c]);
 #pragma unroll
-        for (int c = 0; c < 2; c++) row[k++] = (OutT)__dmul_rn(gvl[c], oc.dt);
+        for (int c = 0; c < 2; c++) put(&row[k++], __dmul_rn(gvl[c], oc.dt));
         const int per = oc.is_variation ? 19 : 15;
 #pragma unroll
         for (int blk = 0; blk < NB; blk++) {
             if (blk < nblocks) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    row[k + c] = (OutT)pos[blk * 3 + c];
-                    row[k + 3 + c] = (OutT)__dsub_rn(pos[blk * 3 + c], gp[c]);                                    // :210
-                    row[k + 6 + c] = (OutT)rot[blk * 3 + c];
-                    row[k + 9 + c] = (OutT)__dsub_rn(__dmul_rn(vp[blk * 3 + c], oc.dt), gv[c]);                   // :207, :211
-                    row[k + 12 + c] = (OutT)__dmul_rn(vr[blk * 3 + c], oc.dt);                                    // :208
+                    put(&row[k + c], pos[blk * 3 + c]);
+                    put(&row[k + 3 + c], __dsub_rn(pos[blk * 3 + c], gp[c]));                                    // :210
+                    put(&row[k + 6 + c], rot[blk * 3 + c]);
+                    put(&row[k + 9 + c], __dsub_rn(__dmul_rn(vp[blk * 3 + c], oc.dt), gv[c]));                   // :207, :211
+                    put(&row[k + 12 + c], __dmul_rn(vr[blk * 3 + c], oc.dt));                                    // :208
                 }
                 if (oc.is_variation) {
 #pragma unroll
@@ -1160,6 +1162,7 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
             k += per;
         }
     }
+    if (ph.d_nan_flag && __ballot(bad) != 0ull && lane == 0) atomicOr(ph.d_nan_flag, 1u);
     __syncthreads();
     if (ld == dimo) {
         OutT *o = out + base * dimo;

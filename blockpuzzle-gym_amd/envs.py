@@ -517,13 +517,17 @@ class BatchedBlocksEnv:
     PHYS_FIELDS = ('grip_pos', 'grip_velp', 'gripper_state', 'gripper_vel',
                    'obj_pos', 'obj_rot', 'obj_velp', 'obj_velr')
 
-    def assemble_observation(self, phys, dt=0.04, dtype=torch.float32, out=None):
+    def assemble_observation(self, phys, dt=0.04, dtype=torch.float32, out=None, nan_flag=None):
         """_get_obs' observation vector (fetch_env.py:187-228, Variation :567-621) from a
         physics backend's state: `phys` maps PHYS_FIELDS to float64 arrays/tensors shaped
         (B,3),(B,3),(B,2),(B,2),(B,nb,3)x4 (euler angles in obj_rot; velocities unscaled);
         dt = nsubsteps * timestep = 20 * 0.002 for every preset (tasks.py).  float64 output
         is bit-identical to the reference; float32 is what rollout.py stores.  With
-        out=None and float32 the env's shared `observation` buffer is updated."""
+        out=None and float32 the env's shared `observation` buffer is updated.
+        nan_flag: optional int32 device tensor, |= 1 when a written value is a NaN (the worker's
+        np.isnan(o_new).any(), rollout.py:139-142, inside this launch).  A rollout worker that watches
+        `env.observation` installs its flag as `env.observation_nan_flag`; writes into that buffer
+        use it by default and tell the worker that the step's observation has been checked."""
         t = {k: self._to_dev(phys[k], torch.float64) for k in self.PHYS_FIELDS}
         nb = self.num_objs - 2
         for k in ('grip_pos', 'grip_velp'):
@@ -532,10 +536,18 @@ class BatchedBlocksEnv:
             assert t[k].shape == (self.num_envs, 2), k
         for k in ('obj_pos', 'obj_rot', 'obj_velp', 'obj_velr'):
             assert t[k].shape == (self.num_envs, nb, 3), k
-        ph = _lib.PhysState(dt=float(dt), **{'d_' + k: t[k].data_ptr() for k in self.PHYS_FIELDS})
         if out is None:
             out = self.observation if dtype == torch.float32 else torch.empty(
                 self.num_envs, self.dimo, dtype=torch.float64, device=self.device)
+        watched = out.data_ptr() == self.observation.data_ptr()
+        if nan_flag is None and watched:
+            nan_flag = getattr(self, 'observation_nan_flag', None)
+        if nan_flag is not None:
+            assert nan_flag.dtype == torch.int32 and nan_flag.numel() >= 1 and nan_flag.device == self.device
+            if watched:
+                self._observation_checked = True
+        ph = _lib.PhysState(dt=float(dt), d_nan_flag=None if nan_flag is None else nan_flag.data_ptr(),
+                            **{'d_' + k: t[k].data_ptr() for k in self.PHYS_FIELDS})
         fn = self._L.bpg_assemble_obs_f32 if out.dtype == torch.float32 else self._L.bpg_assemble_obs_f64
         _lib.check(fn(self._h, C.byref(ph), _ptr(out), int(out.stride(0)), _stream(self.device)))
         return out

@@ -218,8 +218,11 @@ class RolloutStudent:
                 self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._nan_flag.zero_()
             o = torch.empty((T + 1, B, self.dims['o']), **f32)
+            self.env.observation_nan_flag = None       # the reference checks o_new of the steps only
             self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o[0], achieved_goal_out=ag_out)
+            self.env.observation_nan_flag = self._nan_flag
             return o
+        self.env.observation_nan_flag = None
         o0 = torch.empty((B, self.dims['o']), **f32)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0, achieved_goal_out=ag_out)
         return o0[None].expand(T + 1, B, self.dims['o'])
@@ -231,10 +234,12 @@ class RolloutStudent:
         env = self.env
         if self._watch_o:
             slot = env.observation = ep['o'][t + 1]          # the backend's write lands in the episode
+            env._observation_checked = False
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
                                      reward_out=reward_out, u_out=u_store)
-            _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
-                                                   _ptr(self._nan_flag), self.device.index, _stream(self.device)))
+            if not env._observation_checked:                 # written by other means than assemble_observation
+                _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
+                                                       _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
                                      reward_out=reward_out, u_out=u_store)

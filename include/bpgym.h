@@ -215,6 +215,9 @@ typedef struct {
     const double *d_grip_pos, *d_grip_velp, *d_gripper_state, *d_gripper_vel;
     const double *d_obj_pos, *d_obj_rot, *d_obj_velp, *d_obj_velr;
     double dt;
+    uint32_t *d_nan_flag;   /* optional: *d_nan_flag |= 1 when any value written is a NaN -- the rollout
+                               worker's np.isnan(o_new).any() (rollout.py:139-142) inside the launch that
+                               produces o_new, instead of a second pass over it (bpg_nan_flag_f32) */
 } bpg_phys_state;
 int bpg_assemble_obs_f64(bpg_batch *b, const bpg_phys_state *ph, double *d_obs, int64_t ld, void *stream);
 int bpg_assemble_obs_f32(bpg_batch *b, const bpg_phys_state *ph, float *d_obs, int64_t ld, void *stream);

@@ -204,13 +204,23 @@ def _flaky_worker(env_id, B, T, fail_at, mode, cls=bpg.RolloutStudent, **kw):
     phys = {k: np.repeat(d[k][:1], B, 0) for k in bpg.BatchedBlocksEnv.PHYS_FIELDS}
     state = dict(calls=0, resets=0)
 
+    row = torch.as_tensor(d['obs'][0].astype(np.float32), device=DEV)
+
     def physics(env, actions):
         state['calls'] += 1
         if state['calls'] == fail_at and mode == 'raise':
             raise bpg.PhysicsError('simulation unstable')
-        env.assemble_observation(phys, dt=float(d['dt']))
-        if state['calls'] == fail_at and mode == 'nan':
-            env.observation[5, 3] = float('nan')
+        if mode == 'nan_direct':                    # a backend that writes the observation by its own means:
+            env.observation.copy_(row.expand(B, -1))      # the worker's separate NaN pass has to find it
+            if state['calls'] == fail_at:
+                env.observation[5, 3] = float('nan')
+        else:                                       # 'nan': the physics state blows up -> caught inside the
+            ph = phys                               # assemble launch (bpg_phys_state.d_nan_flag), no second pass
+            if state['calls'] == fail_at and mode == 'nan':
+                ph = dict(phys)
+                ph['grip_velp'] = phys['grip_velp'].copy()
+                ph['grip_velp'][5, 1] = np.nan
+            env.assemble_observation(ph, dt=float(d['dt']))
         return torch.zeros(B, dtype=torch.int32, device=DEV)
 
     def on_reset(env, xy, status, env_mask, test):
@@ -234,7 +244,7 @@ def _flaky_worker(env_id, B, T, fail_at, mode, cls=bpg.RolloutStudent, **kw):
     return w, state, log, exp_obs
 
 
-@pytest.mark.parametrize('mode', ['raise', 'nan'])
+@pytest.mark.parametrize('mode', ['raise', 'nan', 'nan_direct'])
 def test_rollout_restarts_after_a_backend_failure(mode):
     env_id, B, T = 'BlocksTouchChoose-v0', 64, 6
     w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=4, mode=mode)
@@ -242,7 +252,7 @@ def test_rollout_restarts_after_a_backend_failure(mode):
     ep = w.generate_rollouts()
     # the failed attempt consumed 4 (raise) or all 6 (NaN found at the end) backend calls, then a clean rollout
     assert state['calls'] == (4 if mode == 'raise' else T) + T
-    assert len(log.lines) == 1 and ('NaN caught' in log.lines[0]) == (mode == 'nan')
+    assert len(log.lines) == 1 and ('NaN caught' in log.lines[0]) == (mode != 'raise')
     assert state['resets'] - resets0 == (2 if mode == 'raise' else 3)   # NaN: reset_all_rollouts + the restart's own reset
     assert not torch.isnan(ep['o']).any()
     assert torch.equal(ep['o'][:, 1:], exp_obs.expand(B, T, -1))
@@ -273,6 +283,35 @@ def test_a_backend_that_keeps_failing_gives_up():
                            dims_of(env_id), None, T, rollout_batch_size=B)
     with pytest.warns(UserWarning), pytest.raises(RuntimeError):
         w.generate_rollouts()
+
+
+def test_assemble_observation_reports_nans_in_its_own_launch():
+    env_id, B = 'BlocksTouchVariation-v0', 1000
+    d = np.load(os.path.join(GOLDEN, 'obs_%s.npz' % short(env_id)))
+    phys = {k: np.repeat(d[k][:1], B, 0) for k in bpg.BatchedBlocksEnv.PHYS_FIELDS}
+    env = bpg.make(env_id, num_envs=B, device=DEV)
+    env.reset()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    env.assemble_observation(phys, dt=float(d['dt']), nan_flag=flag)
+    assert int(flag) == 0
+    for key, idx in (('obj_velr', (999, 1, 2)), ('gripper_state', (0, 1)), ('obj_pos', (517, 0, 0))):
+        flag.zero_()
+        bad = dict(phys)
+        bad[key] = phys[key].copy()
+        bad[key][idx] = np.nan
+        for dtype in (torch.float32, torch.float64):
+            flag.zero_()
+            o = env.assemble_observation(bad, dt=float(d['dt']), dtype=dtype, nan_flag=flag)
+            assert int(flag) == 1 and bool(torch.isnan(o).any())
+    # a NaN in the slot of a block the episode does not have is never written -> not reported
+    nb = (env.num_objs_per_env() - 2).cpu().numpy()
+    e = int(np.nonzero(nb < 4)[0][0])
+    flag.zero_()
+    bad = dict(phys)
+    bad['obj_rot'] = phys['obj_rot'].copy()
+    bad['obj_rot'][e, 3, 0] = np.nan
+    o = env.assemble_observation(bad, dt=float(d['dt']), nan_flag=flag)
+    assert int(flag) == 0 and not bool(torch.isnan(o).any())
 
 
 def test_nan_flag_kernel():
