@@ -1519,7 +1519,9 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 // fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
 // staged through LDS with coalesced loads (row stride padded odd).
 constexpr int CR_ROWS_MAX = 128;
-template <bool VEC4>
+// BCAST: one goal row for every row of ag (env.compute_reward(ag, env.goal), fetch_env.py:135-143 with
+// NumPy broadcasting): staged once per block, read by every lane at the same LDS address.
+template <bool VEC4, bool BCAST = false>
 __global__ void __launch_bounds__(CR_ROWS_MAX)
 k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
                      uint32_t *__restrict__ out)
@@ -1530,7 +1532,10 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
     float *s_g = s_ag + CR_ROWS * ldp;
     const int64_t row0 = (int64_t)blockIdx.x * CR_ROWS;
     const int rows = (int)((n - row0) < CR_ROWS ? (n - row0) : CR_ROWS);
-    const float *pa = ag + row0 * len, *pg = g + row0 * len;
+    const float *pa = ag + row0 * len, *pg = BCAST ? g : g + row0 * len;
+    if (BCAST) {
+        for (int k = threadIdx.x; k < len; k += CR_ROWS) s_g[k] = pg[k];
+    }
     if (VEC4) {
         // len % 4 == 0: a float4 never straddles a row; (row, col) advance incrementally
         const int qpr = len >> 2, total = rows * qpr;
@@ -1541,18 +1546,24 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
         // trip the tile took rows * len / (4 * CR_ROWS) serial memory round trips (0.59 of HBM peak)
         constexpr int CR_U = 9;
         for (int q0 = threadIdx.x; q0 < total; q0 += CR_ROWS * CR_U) {
-            float4 va[CR_U], vg[CR_U];
+            float4 va[CR_U], vg[BCAST ? 1 : CR_U];
 #pragma unroll
             for (int u = 0; u < CR_U; u++) {
                 const int q = q0 + u * CR_ROWS;
-                if (q < total) { va[u] = a4[q]; vg[u] = g4[q]; }
+                if (q < total) {
+                    va[u] = a4[q];
+                    if constexpr (!BCAST) vg[u] = g4[q];
+                }
             }
 #pragma unroll
             for (int u = 0; u < CR_U; u++) {
                 if (q0 + u * CR_ROWS < total) {
-                    float *da = s_ag + r * ldp + 4 * cq, *dg = s_g + r * ldp + 4 * cq;
+                    float *da = s_ag + r * ldp + 4 * cq;
                     da[0] = va[u].x; da[1] = va[u].y; da[2] = va[u].z; da[3] = va[u].w;
-                    dg[0] = vg[u].x; dg[1] = vg[u].y; dg[2] = vg[u].z; dg[3] = vg[u].w;
+                    if constexpr (!BCAST) {
+                        float *dg = s_g + r * ldp + 4 * cq;
+                        dg[0] = vg[u].x; dg[1] = vg[u].y; dg[2] = vg[u].z; dg[3] = vg[u].w;
+                    }
                 }
                 r += r_inc; cq += c_inc;
                 if (cq >= qpr) { cq -= qpr; r++; }
@@ -1563,12 +1574,12 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
         for (int f = threadIdx.x; f < total; f += CR_ROWS) {
             const int r = f / len, k = f - r * len;
             s_ag[r * ldp + k] = pa[f];
-            s_g[r * ldp + k] = pg[f];
+            if (!BCAST) s_g[r * ldp + k] = pg[f];
         }
     }
     __syncthreads();
     if ((int)threadIdx.x < rows) {
-        const float *ra = s_ag + threadIdx.x * ldp, *rg = s_g + threadIdx.x * ldp;
+        const float *ra = s_ag + threadIdx.x * ldp, *rg = BCAST ? s_g : s_g + threadIdx.x * ldp;
         float d = 0.0f;
         int cnt = 0;
         for (int k = 0; k < len; k++) {
@@ -2555,8 +2566,23 @@ int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters)
     return BPG_OK;
 }
 
+static int compute_reward_f32(const float *d_ag, const float *d_g, bool bcast, int64_t n, int len, float *d_out,
+                              int device_id, void *stream);
+
 int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len, float *d_out, int device_id,
                            void *stream)
+{
+    return compute_reward_f32(d_ag, d_g, false, n, len, d_out, device_id, stream);
+}
+
+int bpg_compute_reward_f32_goal(const float *d_ag, const float *d_goal_row, int64_t n, int len, float *d_out,
+                                int device_id, void *stream)
+{
+    return compute_reward_f32(d_ag, d_goal_row, true, n, len, d_out, device_id, stream);
+}
+
+static int compute_reward_f32(const float *d_ag, const float *d_g, bool bcast, int64_t n, int len, float *d_out,
+                              int device_id, void *stream)
 {
     if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
     if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
@@ -2566,17 +2592,19 @@ int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int l
     // two row tiles of CR_ROWS x ldp floats in LDS: 128 rows up to 159 floats per row, 64 rows beyond
     const int CR_ROWS = ((size_t)2 * CR_ROWS_MAX * ldp * sizeof(float) <= 160 * 1024) ? CR_ROWS_MAX : 64;
     const size_t lds = (size_t)2 * CR_ROWS * ldp * sizeof(float);
-    const bool vec = (len % 4 == 0) && (len / 4 <= CR_ROWS) && aligned16(d_ag) && aligned16(d_g);
-    const void *fn = vec ? reinterpret_cast<const void *>(k_compute_reward_f32<true>)
-                         : reinterpret_cast<const void *>(k_compute_reward_f32<false>);
+    const bool vec = (len % 4 == 0) && (len / 4 <= CR_ROWS) && aligned16(d_ag) && (bcast || aligned16(d_g));
+    const void *fn = vec ? (bcast ? reinterpret_cast<const void *>(k_compute_reward_f32<true, true>)
+                                  : reinterpret_cast<const void *>(k_compute_reward_f32<true, false>))
+                         : (bcast ? reinterpret_cast<const void *>(k_compute_reward_f32<false, true>)
+                                  : reinterpret_cast<const void *>(k_compute_reward_f32<false, false>));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), block(CR_ROWS);
-    if (vec)
-        hipLaunchKernelGGL(k_compute_reward_f32<true>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp,
-                           reinterpret_cast<uint32_t *>(d_out));
-    else
-        hipLaunchKernelGGL(k_compute_reward_f32<false>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len,
-                           ldp, reinterpret_cast<uint32_t *>(d_out));
+    uint32_t *o = reinterpret_cast<uint32_t *>(d_out);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec && bcast) hipLaunchKernelGGL((k_compute_reward_f32<true, true>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
+    else if (vec) hipLaunchKernelGGL((k_compute_reward_f32<true, false>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
+    else if (bcast) hipLaunchKernelGGL((k_compute_reward_f32<false, true>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
+    else hipLaunchKernelGGL((k_compute_reward_f32<false, false>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
     return check_launch("k_compute_reward_f32");
 }
 

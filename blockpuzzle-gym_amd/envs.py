@@ -634,12 +634,20 @@ def compute_reward(achieved_goal, goal, device=None):
     dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
     ag = torch.as_tensor(np.asarray(achieved_goal) if np_in else achieved_goal).to(dev, torch.float32)
     g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal).to(dev, torch.float32)
-    g = g.expand_as(ag).contiguous()
     ag = ag.contiguous()
     lead = ag.shape[:-1]
     n = int(np.prod(lead, dtype=np.int64)) if len(lead) else 1
     out = torch.empty(n, dtype=torch.float32, device=dev)
-    if n:
+    # one goal row for every row (a 1-D goal, or leading axes that are all broadcast: size 1 / stride 0)
+    # goes to the kernel as ONE row; anything else row by row
+    one_row = g.shape[-1] == ag.shape[-1] and all(sz == 1 or st == 0 for sz, st in zip(g.shape[:-1], g.stride()[:-1]))
+    if n and one_row:
+        row = g.reshape(-1)[:ag.shape[-1]] if g.dim() == 1 else g[(0,) * (g.dim() - 1)]
+        row = row.contiguous()
+        _lib.check(L.bpg_compute_reward_f32_goal(_ptr(ag), _ptr(row), n, int(ag.shape[-1]), _ptr(out),
+                                                 dev.index, _stream(dev)))
+    elif n:
+        g = g.expand_as(ag).contiguous()
         _lib.check(L.bpg_compute_reward_f32(_ptr(ag), _ptr(g), n, int(ag.shape[-1]), _ptr(out),
                                             dev.index, _stream(dev)))
     out = out.reshape(lead)

@@ -268,6 +268,10 @@ int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters);
  * HER calls it (config.py:110-111): n rows of `len` floats each, len in 1..256. */
 int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len,
                            float *d_out, int device_id, void *stream);
+/* Same against ONE goal row of `len` floats shared by every row of d_ag -- env.compute_reward(ag,
+ * env.goal) with NumPy broadcasting (fetch_env.py:135-143; the goal is constant per variant, :260-273). */
+int bpg_compute_reward_f32_goal(const float *d_ag, const float *d_goal_row, int64_t n, int len,
+                                float *d_out, int device_id, void *stream);
 /* Same on packed states against packed goal planes. */
 int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,
                               uint32_t want_touch, uint32_t want_never, int64_t n,

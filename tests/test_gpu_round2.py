@@ -537,6 +537,35 @@ def test_compute_reward_long_rows():
         bpg.compute_reward(torch.zeros((4, 257), device=DEV), torch.zeros((4, 257), device=DEV))
 
 
+def test_compute_reward_with_one_goal_row():
+    """env.compute_reward(ag, env.goal): ONE goal row against every row of ag (NumPy broadcasting in
+    fetch_env.py:141-143) goes through bpg_compute_reward_f32_goal -- no materialised (n, len) goal.
+    Every variant's row length (9, 16, 25, 36: float4 and scalar staging), ragged tile tails, leading
+    axes, numpy and torch inputs; == the row-by-row kernel and the oracle."""
+    rng = np.random.RandomState(12)
+    for env_id in ENV_IDS:
+        v = VARIANTS[env_id]
+        env = bpg.make(env_id, num_envs=2, device=DEV)
+        goal = np.asarray(env.goal, np.float64)
+        ln = goal.shape[0]
+        for lead in [(1,), (127,), (129,), (5, 51), (1000,)]:
+            ag = rng.randint(-1, 2, size=lead + (ln,)).astype(np.float32)
+            hit = rng.rand(*lead) < 0.3                                      # rows that satisfy the goal
+            ag[hit] = np.where(goal != 0, goal, ag[hit]).astype(np.float32)
+            exp = O.compute_reward(ag.reshape(-1, ln), goal).reshape(lead)
+            got_np = env.compute_reward(ag, goal, {})                         # numpy in -> numpy out, 1-D goal
+            np.testing.assert_array_equal(got_np.view(np.uint32), exp.view(np.uint32))
+            tag = torch.as_tensor(ag, device=DEV)
+            tg = torch.as_tensor(goal.astype(np.float32), device=DEV)
+            for gform in (tg, tg[None], tg.expand(*lead, ln), tg.expand(*lead, ln).contiguous()):
+                got = bpg.compute_reward(tag, gform)
+                np.testing.assert_array_equal(bits(got).reshape(lead), exp.view(np.uint32))
+            assert (exp == 0).any() and (exp != 0).any() or lead == (1,)
+    # keyword spelling of the reference's call site (config.py:110-111)
+    r = env.compute_reward(achieved_goal=ag, desired_goal=goal, info={})
+    np.testing.assert_array_equal(r.view(np.uint32), exp.view(np.uint32))
+
+
 # --------------------------------------------------------------------------
 # seeding contract (SURVEY 8 a12: build-defined replacement of seed + 1000 * idx)
 # --------------------------------------------------------------------------
