@@ -44,7 +44,7 @@ KERNELS = [
     ('k_step_record<6, 0', 'k_step_record', 'read4', 12 * B, (13 + 4 + 144) * B),
     ('k_discounted_return_reg<50', 'k_discounted_return_reg50', 'read4', 4 * T * B, 8 * T * B),
     ('k_episode<6, 0', 'k_episode', 'read4', B * (4 * T + 8), B * (8 + 4 * (36 * (2 * T + 1) + T))),
-    ('k_compute_reward_f32<true>', 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4),
+    ('k_compute_reward_f32<true', 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4),
     ('k_reset<true>', 'k_reset_obs', 'read4', 8 * B, None),
     ('k_assemble_obs<float, 4>', 'k_assemble_obs_f32', 'read8', B * (4 + 8 * 58), B * 4 * 87),
     ('k_set_action', 'k_set_action', 'read16', 16 * B, 72 * B),
