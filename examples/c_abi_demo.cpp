@@ -76,6 +76,44 @@ int main()
     CHECK(bpg_success_count(h, d_cnt, nullptr));
     HIP(hipMemcpy(&cnt, d_cnt, 8, hipMemcpyDeviceToHost));
     std::printf("success count %llu of %lld, mismatches %d\n", cnt, (long long)B, bad);
+
+    // A whole T-step rollout in one launch (rollout.py:100-153) over time-major (T, ld) streams: contact
+    // masks in, rewards / flags out, once with contiguous rows (ld = B) and once with the row stride the
+    // library recommends for its batch size (bpg_row_stride; here an arbitrary padded one, the batch is
+    // small) -- the results must be identical.  Zero-initialised args: every optional field is "default".
+    const int T = info.max_episode_steps;
+    const int64_t ld = B + 24;
+    uint32_t *d_m0, *d_m1; float *d_r0, *d_r1; uint8_t *d_f0, *d_f1;
+    HIP(hipMalloc(&d_m0, (size_t)T * B * 4)); HIP(hipMalloc(&d_m1, (size_t)T * ld * 4));
+    HIP(hipMalloc(&d_r0, (size_t)T * B * 4)); HIP(hipMalloc(&d_r1, (size_t)T * ld * 4));
+    HIP(hipMalloc(&d_f0, (size_t)T * B)); HIP(hipMalloc(&d_f1, (size_t)T * ld));
+    CHECK(bpg_synth_masks(h, 0, T, d_m0, nullptr));
+    CHECK(bpg_synth_masks_ld(h, 0, T, d_m1, ld, nullptr));
+    unsigned long long *d_c2; HIP(hipMalloc(&d_c2, 16)); HIP(hipMemset(d_c2, 0, 16));
+    bpg_rollout_args ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_reward_tb = d_r0; ra.d_flags_tb = d_f0; ra.d_success_count = d_c2;
+    CHECK(bpg_rollout(h, &ra, nullptr));
+    ra.d_masks = d_m1; ra.d_reward_tb = d_r1; ra.d_flags_tb = d_f1; ra.d_success_count = d_c2 + 1;
+    ra.ld_masks = ld; ra.ld_out = ld;
+    CHECK(bpg_rollout(h, &ra, nullptr));
+    HIP(hipDeviceSynchronize());
+    std::vector<float> r0((size_t)T * B), r1((size_t)T * ld);
+    std::vector<uint8_t> f0((size_t)T * B), f1((size_t)T * ld);
+    unsigned long long c2[2];
+    HIP(hipMemcpy(r0.data(), d_r0, r0.size() * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(r1.data(), d_r1, r1.size() * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(f0.data(), d_f0, f0.size(), hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(f1.data(), d_f1, f1.size(), hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(c2, d_c2, 16, hipMemcpyDeviceToHost));
+    int bad2 = (c2[0] != c2[1]);
+    for (int t = 0; t < T; t++)
+        for (int64_t b = 0; b < B; b++) {
+            bad2 += std::memcmp(&r0[(size_t)t * B + b], &r1[(size_t)t * ld + b], 4) != 0;
+            bad2 += f0[(size_t)t * B + b] != f1[(size_t)t * ld + b];
+        }
+    std::printf("fused rollout, T = %d: %llu successes; padded rows (ld = %lld; bpg_row_stride(2^20) = %lld) vs contiguous: %d mismatches\n",
+                T, c2[0], (long long)ld, (long long)bpg_row_stride((int64_t)1 << 20), bad2);
     CHECK(bpg_destroy(h));
-    return (bad == 0 && cnt == (unsigned long long)B) ? 0 : 2;
+    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0) ? 0 : 2;
 }

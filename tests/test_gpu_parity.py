@@ -935,6 +935,7 @@ def test_c_abi_from_plain_cpp_host(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'reward bits 0x80000000' in out.stdout and 'success count 1000 of 1000, mismatches 0' in out.stdout
+    assert 'vs contiguous: 0 mismatches' in out.stdout and 'bpg_row_stride(2^20) = 1048832' in out.stdout
 
 
 def test_contact_list_input_is_sanitised():
