@@ -467,7 +467,8 @@ def main(HERE=HERE):
         modes = [0, 0, 1, 0] if can_test else [0, 0, 0]
         ro = rollout_trace(eid, seed=500 + k, B=5, modes=modes)
         np.savez_compressed(os.path.join(HERE, 'rollout_%s.npz' % eid.split('-')[0]), **ro)
-    for k, eid in enumerate(['BlocksTouch-v0', 'BlocksTouchVariation-v0']):
+    for k, eid in enumerate(['BlocksTouch-v0', 'BlocksTouchVariation-v0', 'ToppleTower-v0', 'GripperTouch-v0',
+                             'BlocksTouchChoose-v0']):
         ro = rollout_trace(eid, seed=700 + k, B=4, modes=[0, 0], pg=True)
         np.savez_compressed(os.path.join(HERE, 'pg_rollout_%s.npz' % eid.split('-')[0]), **ro)
     print('golden fixtures written to', HERE)

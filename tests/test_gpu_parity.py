@@ -135,7 +135,7 @@ def test_golden_compute_reward():
         np.testing.assert_array_equal(r3.view(np.uint32), d[k + '_rbits3'])
 
 
-@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation'])
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower', 'GripperTouch', 'BlocksTouchChoose'])
 def test_golden_pg_rollout_return(name):
     """policy_gradient/rollout.py: reference G (float64) bit-for-bit."""
     env_id = name + '-v0'

@@ -134,7 +134,7 @@ def test_rollout_student_episodes(env_id):
         assert out['success_rate'] == float(d['r%d_success_rate' % r])
 
 
-@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation'])
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower', 'GripperTouch', 'BlocksTouchChoose'])
 def test_pg_discounted_return(name):
     """policy_gradient/rollout.py:255-258 return accumulation, bit-exact f64."""
     env_id = name + '-v0'
