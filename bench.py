@@ -14,13 +14,24 @@ Weak scaling by default: every GPU holds `--envs` envs (BASELINE configs[2] per 
 
     python bench.py [--gpus N --steps K --warmup W] [--total-envs E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself, the
+way the reference's `mpi_fork` does (gym_blocks/train.py:113-119: the parent re-launches the program once
+per rank and only waits): N fresh child processes of this file with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, the parent never touches the GPU (no HIP call, no torch import), relays rank 0's JSON line
+and exits non-zero if any rank does.  A rank that fails prints a JSON line with an "error" key instead of
+dying on a bare assert.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -61,6 +72,8 @@ def parse():
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
+    p.add_argument('--launch-timeout', type=float, default=900.0,
+                   help='self-launched N>1 runs: seconds before the parent ends the rank processes it started')
     return p.parse_args()
 
 
@@ -109,8 +122,112 @@ def cpu_baseline(T, seconds):
     return out
 
 
+METRIC = 'env_steps_per_sec'
+
+
+def error_line(msg, a, **kw):
+    """What a failed run prints instead of a result: one parseable JSON line."""
+    out = {'metric': METRIC, 'value': None, 'unit': 'env-steps/s', 'n_gpus': a.gpus, 'steps': a.steps,
+           'warmup': a.warmup, 'error': msg}
+    out.update(kw)
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_environments(a, base_env=None, port=None):
+    """The environment of each of the N rank processes (the torchrun contract: RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT), one dict per rank.  Pure host logic (CPU-tested)."""
+    base = dict(os.environ if base_env is None else base_env)
+    port = port or _free_port()
+    envs = []
+    for r in range(a.gpus):
+        e = dict(base)
+        e.update(RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_RANK='0' if a.single_device else str(r),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), BPG_BENCH_SPAWNED='1')
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it here
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(a, argv):
+    """The reference's mpi_fork (gym_blocks/train.py:113-119) for `python bench.py --gpus N`: start N
+    fresh rank processes of this file and wait.  The parent makes no HIP call and never imports torch;
+    nothing is exec'ed from a process that holds the GPU.  Rank 0's stdout (the JSON line) is relayed;
+    the other ranks' stdout goes to stderr.  Exit code: 0 only if every rank exited 0 and rank 0 printed a
+    JSON line; otherwise a JSON error line is printed (unless rank 0 already printed one) and the code is 1."""
+    envs = rank_environments(a)
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    out0_file = tempfile.TemporaryFile(mode='w+')        # rank 0's stdout (a file: no pipe to fill up)
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen(cmd, env=e, stdout=out0_file if r == 0 else sys.stderr, stderr=sys.stderr))
+    deadline = time.time() + a.launch_timeout
+    rcs = [None] * len(procs)
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+        # a rank that died leaves the others waiting in a collective: end exactly the processes started here
+        if (failed_at is not None and time.time() - failed_at > 15) or time.time() > deadline:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = p.wait()
+            break
+        if any(rc is None for rc in rcs):
+            time.sleep(0.05)
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    line = None
+    for ln in out0.splitlines():
+        try:
+            cand = json.loads(ln)
+        except ValueError:
+            print(ln, file=sys.stderr)
+            continue
+        if isinstance(cand, dict) and 'metric' in cand:
+            line = cand
+        else:
+            print(ln, file=sys.stderr)
+    ok = all(rc == 0 for rc in rcs) and line is not None and 'error' not in line
+    if line is None or (not ok and 'error' not in line):
+        line = error_line('rank exit codes %s%s' % (rcs, '' if time.time() <= deadline else ' (launch timeout)'), a,
+                          rank_exit_codes=rcs)
+    line['launcher'] = {'how': 'bench.py started %d rank processes itself (train.py:113-119 mpi_fork)' % a.gpus,
+                        'rank_exit_codes': rcs}
+    print(json.dumps(line), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    try:
+        run(a)
+    except SystemExit:
+        raise
+    except BaseException as e:          # noqa: BLE001  (a parseable line instead of a bare traceback)
+        rank = int(os.environ.get('RANK', '0'))
+        traceback.print_exc()
+        line = error_line('%s: %s' % (type(e).__name__, str(e)[:500]), a, rank=rank)
+        print(json.dumps(line), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+        sys.exit(2)
+
+
+def run(a):
     import torch
     import torch.distributed as dist
     import blockpuzzle_gym_amd as bpg
@@ -125,8 +242,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         torch.cuda.set_device(local)
         dist.init_process_group(a.backend or 'nccl', rank=0, world_size=1, device_id=torch.device('cuda', local))
-    assert world == a.gpus, 'launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    if world != a.gpus:
+        raise RuntimeError('--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts the ranks '
+                           'itself) or under torchrun --nproc-per-node N' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU (no CPU fallback)')
     multi = world > 1 or force_dist          # take the collective code path
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -244,6 +364,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = ev0.elapsed_time(ev1) / a.steps
+    rank_kernel_ms = [kernel_ms]
+    if multi:                                   # every rank's own HIP-event figure (the headline uses rank 0's)
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        allk = [torch.zeros_like(km) for _ in range(dist.get_world_size())]
+        dist.all_gather(allk, km)
+        rank_kernel_ms = [float(k.item()) for k in allk]
     if multi and a.collective == 'allgather':
         succ_rate = float((gathered[((n_it - 1) // R) % 2] & 1).float().mean().item())
     else:
@@ -287,9 +413,17 @@ def main():
                                'env-step' % (ENV_ID, B, T, LD),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'row_stride_elements': LD,
                    'parallelism': 'env-shard x%d' % world,
-                   'buffer_sets': NBUF, 'collective': (a.collective if world > 1 else None),
-                   'rollouts_per_collective': (R if world > 1 else None),
+                   'buffer_sets': NBUF, 'collective': (a.collective if multi else None),
+                   'rollouts_per_collective': (R if multi else None),
                    'success_rate': succ_rate},
+        # what the collective path actually ran with (observed, not requested)
+        'rccl_world_size': (dist.get_world_size() if dist.is_initialized() else 1),
+        'backend': (dist.get_backend() if dist.is_initialized() else None),
+        'collective': (a.collective if multi else None),
+        'collective_bytes_per_rollout': (None if not multi else
+                                         (world * B if a.collective == 'allgather' else 16)),
+        'gathered_bytes_per_rollout': (world * B if (multi and a.collective == 'allgather') else None),
+        'kernel_ms_per_rank': {'min': min(rank_kernel_ms), 'max': max(rank_kernel_ms), 'all': rank_kernel_ms},
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, 2 envs/lane, reward+flags, reset>', 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'bytes_per_launch': bytes_per_launch,

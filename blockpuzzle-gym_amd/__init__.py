@@ -11,9 +11,10 @@ from . import _lib
 from .registration import make, register, registry, register_with_gym
 from .envs import (BatchedBlocksEnv, SyntheticContacts, ScriptedContacts, CallableContacts, PhysicsError,
                    compute_reward, mat2euler, geom2objid, default_geom_names)
-from .rollout import RolloutStudent, PGRolloutStudent, configure_dims, discounted_return, time_major_empty
+from .rollout import (RolloutStudent, PGRolloutStudent, configure_dims, discounted_return, discounted_return_scan,
+                      time_major_empty)
 from . import distributed
 
 __all__ = ['make', 'register', 'registry', 'register_with_gym', 'BatchedBlocksEnv', 'RolloutStudent', 'PGRolloutStudent',
            'SyntheticContacts', 'ScriptedContacts', 'CallableContacts', 'PhysicsError', 'compute_reward',
-           'configure_dims', 'discounted_return', 'time_major_empty', 'mat2euler', 'geom2objid', 'default_geom_names', 'distributed']
+           'configure_dims', 'discounted_return', 'discounted_return_scan', 'time_major_empty', 'mat2euler', 'geom2objid', 'default_geom_names', 'distributed']

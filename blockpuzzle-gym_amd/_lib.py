@@ -35,6 +35,7 @@ class RolloutArgs(C.Structure):
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
         ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
+        ('d_G', C.c_void_p), ('gamma', C.c_double),
     ]
 
 
@@ -101,6 +102,8 @@ SIGNATURES = {
                                         C.c_int, C.c_void_p]),
     'bpg_discounted_return_ld': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                            C.c_int, C.c_void_p]),
+    'bpg_discounted_return_scan': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p,
+                                             C.c_int, C.c_void_p]),
     'bpg_nan_flag_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

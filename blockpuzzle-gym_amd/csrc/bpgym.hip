@@ -31,6 +31,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -154,6 +155,8 @@ struct bpg_batch {
     uint32_t *ever;
     int8_t *d_id2obj;   // [BPG_MAX_MODELS][BPG_MAX_GEOMS]
     int ngeom[BPG_MAX_MODELS];
+    unsigned long long *d_count_shards;   // COUNT_SHARDS words on 128-byte lines of their own (block_count_add)
+    uint64_t *d_okbits;                   // n words: the step-ok bits of the last rollout that asked for G
 };
 
 namespace bpgk {   // kernels + launch helpers (named so profiles read bpgk::k_*)
@@ -184,7 +187,26 @@ struct StepConst {
     uint32_t want_touch;   // goal == +1 pairs
     uint32_t want_never;   // goal == -1 pairs
     uint32_t max_steps;    // TimeLimit
+    // fetch_env.py:154-157 demotes 1 -> 0 only for i, j < num_objs.  Variation's matrix is always 6 x 6
+    // while num_objs is 4..6 (:649), so an entry that involves an object >= num_objs -- no id2obj table
+    // can produce one, but a raw mask can carry it -- is set by :166-167 and never demoted again: it
+    // stays 1.  sticky_by_n[n] = pairs of the matrix with an index >= n (0 for n >= side); sticky_on = 0
+    // for the variants whose num_objs is the matrix side (nothing to keep, the lookup is skipped).
+    uint32_t sticky_on;
+    uint32_t sticky_by_n[BPG_MAX_OBJS];
 };
+
+// per-env sticky pairs (see StepConst): compare-select over the table rows, which sit in SGPRs
+__device__ __forceinline__ uint32_t sticky_of(const StepConst &c, uint32_t ever)
+{
+    uint32_t s = 0u;
+    if (c.sticky_on) {                                   // uniform
+        const uint32_t n = (ever >> NOBJ_SHIFT) & 7u;
+#pragma unroll
+        for (uint32_t k = 0; k < BPG_MAX_OBJS; k++) s = n == k ? c.sticky_by_n[k] : s;
+    }
+    return s;
+}
 
 struct SynthConst {
     uint32_t seed;         // folded 64 -> 32 on the host
@@ -200,7 +222,7 @@ struct SynthConst {
 __device__ __forceinline__ void step_core(uint32_t &now, uint32_t &ever, uint32_t mask,
                                           const StepConst &c, uint32_t &rbits, uint32_t &flags)
 {
-    const uint32_t cm = mask & c.valid;
+    const uint32_t cm = (mask & c.valid) | (now & sticky_of(c, ever));
     uint32_t elapsed = (now >> ELAPSED_SHIFT) & ELAPSED_MAX;
     elapsed = elapsed < ELAPSED_MAX ? elapsed + 1 : ELAPSED_MAX;
     const uint32_t ev = ever | cm;
@@ -671,11 +693,46 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
 }
 
 // ------------------------------ fused rollout -------------------------------
-// rollout.py:163-167 inside a kernel: per-wave ballot + popcount, LDS sum over
-// the block's waves, ONE atomic per block (a same-address atomic costs ~12 ns
-// at the memory side; blocks finish at different times, so even the 8 192 blocks
-// of the contacts-in-kernel shape at 4 M envs do not queue up behind it).
-__device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned long long *count)
+// rollout.py:163-167 inside a kernel: per-wave ballot + popcount, LDS sum over the block's waves, then
+// ONE returning atomic per block on one of COUNT_SHARDS shard words (each on a 128-byte line of its
+// own, owned by the handle, all zero between launches).  Device-scope atomics execute at the memory
+// side and same-address ones queue up at 11-13 ns each: 256 blocks that finish together on ONE word
+// cost 2-4 us at the end of the launch (the whole T-independent gap between a 65 536-env rollout with
+// and without the count, profiles/r02_tune_geometry.log), 1 024 blocks 12 us.  Sharded, the chains are
+// COUNT_SHARDS times shorter and run in parallel.  A shard word carries the sum (low 40 bits) and the
+// number of arrivals (high 24 bits); the block whose add comes last on its shard -- told by the value
+// the add returned, so no block ever waits -- moves the shard's sum to the caller's counter (at most
+// COUNT_SHARDS adds on that word) and clears the shard for the next launch.  Blocks b with
+// b % COUNT_SHARDS == s share shard s; which CU or XCD runs them does not matter.
+constexpr int COUNT_SHARDS = 32;
+constexpr int COUNT_SHARD_STRIDE = 16;              // uint64 words between shards (128 bytes)
+constexpr unsigned long long COUNT_SUM_MASK = (1ull << 40) - 1ull;
+
+struct CountArgs {
+    unsigned long long *count;       // caller's counter (+= successes), or NULL
+    unsigned long long *zero_next;   // optional second counter the launch sets to 0
+    unsigned long long *shards;      // COUNT_SHARDS * COUNT_SHARD_STRIDE words; NULL = one plain atomic per block
+};
+
+// one thread per block
+__device__ __forceinline__ void shard_count_add(unsigned long long tot, const CountArgs &ca)
+{
+    if (!ca.shards) {
+        if (tot) atomicAdd(ca.count, tot);
+        return;
+    }
+    const uint32_t s = blockIdx.x % COUNT_SHARDS;
+    const uint32_t in_shard = (gridDim.x - s + COUNT_SHARDS - 1) / COUNT_SHARDS;      // blocks on this shard (>= 1)
+    unsigned long long *w = ca.shards + (size_t)s * COUNT_SHARD_STRIDE;
+    const unsigned long long old = atomicAdd(w, (1ull << 40) | tot);
+    if ((uint32_t)(old >> 40) + 1u == in_shard) {                                    // the shard's last arrival
+        const unsigned long long sum = (old & COUNT_SUM_MASK) + tot;
+        (void)__hip_atomic_exchange(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sum) atomicAdd(ca.count, sum);
+    }
+}
+
+__device__ __forceinline__ void block_count_add(uint32_t lane_count, const CountArgs &ca)
 {
     __shared__ uint32_t s_part[16];
     uint32_t c = lane_count;
@@ -687,7 +744,7 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned lo
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
         for (int w = 0; w < nw; w++) tot += s_part[w];
-        if (tot) atomicAdd(count, tot);
+        shard_count_add(tot, ca);
     }
 }
 
@@ -700,20 +757,158 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, unsigned lo
 // when it counts outstanding memory operations, and every wait then also drains the stores.
 enum { OUT_REWARD = 1, OUT_FLAGS = 2 };
 
+// ---- policy-gradient return from the step-ok words of a rollout (policy_gradient/rollout.py:255-258) ----
+// G[t_] starts as r[t_] and receives gamma**(t - t_) * r[t] for t = t_+1 .. T-1 in increasing t, in
+// float64, every product and sum rounded on its own (NumPy).  Inside the rollout the step rewards are
+// not arbitrary floats: r[t] is -0.0 when the step's success condition holds and -1.0 otherwise
+// (fetch_env.py:141-143), i.e. ONE bit per step, and T <= 64 of them are a 64-bit mask the lane already
+// holds.  With r in {-1.0, -0.0} the product gamma**k * r is exact (-gamma**k or -0.0), and adding
+// -0.0 leaves every float64 value unchanged, so the reference's arithmetic is, bit for bit,
+//     if (!ok[t]) G[t_] = G[t_] - pw[t - t_]          for all t_ < t, t ascending,
+// one float64 subtraction per (t_, t) pair under the wave's execution mask instead of a product and a sum
+// (round 2's k_discounted_return_reg: 2 450 float64 operations per env, here at most 1 225), no reward stream
+// written and read back (21 -> 13 bytes per env-step for the pg path), and no per-lane reward operand:
+// pw[k] sits in SGPRs.  Lane = env, TT accumulators in registers.  The T x T triangle is walked in two
+// passes over the lag k = t - t_ (first k <= TT/2, then the rest): per accumulator the additions still
+// come in increasing t, and each pass needs only half of the gamma**k table in SGPRs at a time.
+constexpr int DR_TMAX_REG = 64;
+struct PowTable { double v[DR_TMAX_REG]; };
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The gamma**k table reaches the kernels as their FIRST by-value argument, i.e. at offset 0 of the kernarg
+// segment, and is read from there with scalar loads where it is used.  Left to itself the compiler loads
+// every kernel argument in the entry block: 100 SGPRs of table alive through the whole launch, spilled to
+// VGPR lanes and read back lane by lane.  kernarg_pow() hands out the segment pointer through an opaque
+// asm, once per pass, so the loads stay where the pass is.
+using KernargDouble = const __attribute__((address_space(4))) double;
+__device__ __forceinline__ KernargDouble *kernarg_pow()
+{
+    KernargDouble *p = (KernargDouble *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// an opaque asm keeps a loaded constant in its SGPR pair: scalar loads from the kernarg segment can be
+// rematerialised, and under SGPR pressure the register allocator re-loaded the constants inside every
+// conditional block below (129 s_load_dwordx16 + a full lgkmcnt wait per step) instead of keeping them
+__device__ __forceinline__ void pin_sgpr(double &x) { asm volatile("" : "+s"(x)); }
+
+template <int TT>
+__device__ __forceinline__ void returns_from_okbits(uint64_t ok, double (&acc)[TT])
+{
+    constexpr int KA = TT / 2;
+    static_for<0, TT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        acc[t] = ((ok >> t) & 1ull) ? -0.0 : -1.0;                    // returns.append(r_new.copy())
+    });
+    {
+        KernargDouble *pw = kernarg_pow();
+        double ck[KA + 1];
+        static_for<1, KA + 1>([&](auto kc) { ck[decltype(kc)::value] = pw[decltype(kc)::value]; });
+        static_for<1, KA + 1>([&](auto kc) { pin_sgpr(ck[decltype(kc)::value]); });
+        static_for<1, TT>([&](auto tc) {                                // lags 1 .. KA
+            constexpr int t = decltype(tc)::value;
+            if (!((ok >> t) & 1ull)) {
+                static_for<(t > KA ? t - KA : 0), t>([&](auto uc) {
+                    constexpr int t_ = decltype(uc)::value;
+                    acc[t_] = acc[t_] - ck[t - t_];
+                });
+            }
+        });
+    }
+    if constexpr (KA + 1 < TT) {
+        KernargDouble *pw = kernarg_pow();
+        double ck[TT];
+        static_for<KA + 1, TT>([&](auto kc) { ck[decltype(kc)::value] = pw[decltype(kc)::value]; });
+        static_for<KA + 1, TT>([&](auto kc) { pin_sgpr(ck[decltype(kc)::value]); });
+        static_for<KA + 1, TT>([&](auto tc) {                           // lags KA+1 .. TT-1
+            constexpr int t = decltype(tc)::value;
+            if (!((ok >> t) & 1ull)) {
+                static_for<0, t - KA>([&](auto uc) {
+                    constexpr int t_ = decltype(uc)::value;
+                    acc[t_] = acc[t_] - ck[t - t_];
+                });
+            }
+        });
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The G rows of 64 consecutive envs (lane = env, first env e0, envs >= n are not written) leave through a
+// wave-private LDS tile of 16 rows -- the tile is the output image itself, so every quarter of the wave's
+// rows streams out as one contiguous 16 * TT * 8-byte piece with 16-byte stores.
+constexpr int G_TILE_ROWS = 16;
+template <int TT>
+__device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], double *tile, double *__restrict__ G,
+                                                   int64_t e0, int64_t n, int lane)
+{
+    constexpr bool PAIRS = TT % 2 == 0;          // rows are whole 16-byte pieces: 16-byte LDS and global accesses
+#pragma unroll
+    for (int c = 0; c < 64 / G_TILE_ROWS; c++) {
+        if (c) wave_lds_sync();                                          // previous quarter streamed out
+        if ((lane / G_TILE_ROWS) == c) {
+            double *row = tile + (lane % G_TILE_ROWS) * TT;
+            if constexpr (PAIRS) {
+                static_for<0, TT / 2>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    reinterpret_cast<double2 *>(row)[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+                });
+            } else {
+                static_for<0, TT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    row[i] = acc[i];
+                });
+            }
+        }
+        wave_lds_sync();
+        const int64_t first = e0 + c * G_TILE_ROWS;
+        const int64_t left = n - first;
+        const int rows = left >= G_TILE_ROWS ? G_TILE_ROWS : (left > 0 ? (int)left : 0);
+        double *o = G + first * TT;
+        if constexpr (PAIRS) {
+            const double2 *t2 = reinterpret_cast<const double2 *>(tile);
+            double2 *o2 = reinterpret_cast<double2 *>(o);                // first * TT * 8 bytes: 16-byte aligned
+            for (int f = lane; f < rows * (TT / 2); f += 64) o2[f] = t2[f];
+        } else {
+            for (int f = lane; f < rows * TT; f += 64) o[f] = tile[f];
+        }
+    }
+}
+
+
 // PIPE: software-pipelined mask requests (see the loop); used for the latency-bound batch sizes.
 // The plain loop (PIPE = false: UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound
-// 4-envs-per-lane shape runs: with >= 16 waves per CU other waves cover the round trips, and the
-// pipelined form of that shape needs more than the 128 VGPRs a 1024-lane block may use.
+// fat shape runs: with >= 16 waves per CU other waves cover the round trips.
 // RESET: the launch starts with reset_all_rollouts (rollout.py:79).  Compile-time because the
 // elapsed counter is then the same for every lane (step t of the launch), so the time-limit
 // test, the saturation and the generator's Weyl term run on the scalar unit.
-template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL = 5, bool PIPE = (EPL < 4), bool NTL = true>
-__global__ void __launch_bounds__(1024)
+// LB: the largest block the instantiation is ever launched with (the register budget follows from it:
+// 128 VGPRs at 1024 lanes, 512 / waves-per-SIMD below).
+// OKB: the launch also stores every env's step-ok word (bit t = the success condition held at step t, i.e. the
+// step reward was -0.0f; T <= 64) into okbits[n] -- 8 bytes per env instead of a 4 T-byte reward stream -- from
+// which k_returns_from_okbits computes the policy-gradient return.  (Computing G inside this launch, right
+// after a wave's steps, was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs,
+// profiles/r03_tune_pg_path.log -- the memory-bound step phase and the VALU-bound return phase of the same
+// waves do not overlap -- and removed.)
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false>
+__global__ void __launch_bounds__(LB)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
-          StepConst c, SynthConst s, ResetConst rc, unsigned long long *__restrict__ count,
-          unsigned long long *__restrict__ zero_next)
+          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits)
 {
     using Vec = typename LaneVec<EPL>::vec;
     using Fl = typename LaneVec<EPL>::fl;
@@ -721,7 +916,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t nsucc = 0;
-    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0ull;
+    if (ca.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *ca.zero_next = 0ull;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
         // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
@@ -735,7 +930,8 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         // the ever set (+ num_objs bits, untouched), the elapsed counter and the success latch (as
         // an all-ones / zero mask) each in a register of their own, and the two comparisons of
         // step_core turned into sign-bit arithmetic -- 11 instead of ~20 instructions per env-step.
-        uint32_t cm[EPL], ev[EPL], el[EPL], lat[EPL];
+        uint32_t cm[EPL], ev[EPL], el[EPL], lat[EPL], stk[EPL];
+        uint64_t okb[EPL];                          // OKB: bit t = the success condition held at step t
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
             if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc);
@@ -744,6 +940,9 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
             ev[k] = ee[k] & ~SUCC_BIT;
             lat[k] = (uint32_t)((int32_t)ee[k] >> 31);
+            // pairs that are never demoted (StepConst); the synthetic source only emits pairs of present objects
+            stk[k] = (SRC == SRC_SYNTH) ? 0u : sticky_of(c, ee[k]);
+            okb[k] = 0ull;
         }
         const Vec *mrow = reinterpret_cast<const Vec *>(masks) + v;
         Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + v;
@@ -753,12 +952,13 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 #pragma unroll
             for (int k = 0; k < EPL; k++) {
                 if (RESET) el[k] = (uint32_t)t;            // uniform: elapsed == step of the launch (T <= 1023)
-                const uint32_t m = (SRC == SRC_SYNTH) ? synth_mask(sl[k], el[k]) : mt[k];
-                cm[k] = m & c.valid;
+                if (SRC == SRC_SYNTH) cm[k] = synth_mask(sl[k], el[k]) & c.valid;
+                else cm[k] = (mt[k] & c.valid) | (cm[k] & stk[k]);
                 ev[k] |= cm[k];
                 const uint32_t bad = (c.want_touch & ~cm[k]) | (c.want_never & ev[k]);    // < 2^21
                 const uint32_t okm = (uint32_t)((int32_t)(bad - 1u) >> 31);               // ~0 iff bad == 0
                 lat[k] |= okm;
+                if (OKB) okb[k] |= (uint64_t)(okm & 1u) << t;
                 el[k] = min(el[k] + 1u, ELAPSED_MAX);
                 const uint32_t dn = ((c.max_steps - 1u - el[k]) >> 30) & (uint32_t)BPG_FLAG_DONE;   // el >= max_steps
                 rb[k] = RBITS_FAIL ^ (okm & (RBITS_FAIL ^ RBITS_OK));
@@ -840,8 +1040,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         }
         reinterpret_cast<Vec *>(now)[v] = pack<EPL>(an);
         reinterpret_cast<Vec *>(ever)[v] = pack<EPL>(ee);
+        if constexpr (OKB) {
+#pragma unroll
+            for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
+        }
     }
-    if (count) block_count_add(nsucc, count);
+    if (ca.count) block_count_add(nsucc, ca);
 }
 
 // ------------------------------ float views ---------------------------------
@@ -1419,7 +1623,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
           int64_t n, int T, int64_t ldm, int64_t ldo, int RC, int R, StepConst c, SynthConst s, PairTable tabv,
-          ResetConst rc, unsigned long long *__restrict__ count, unsigned long long *__restrict__ zero_next)
+          ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits_out)
 {
     // The T+1 matrices of an episode are produced in chunks of RC rows (one chunk = the whole
     // episode for T <= 63): a short step phase (lane = env, state in registers, packed rows of
@@ -1431,12 +1635,13 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     PairTable *tab = reinterpret_cast<PairTable *>(smem + (size_t)64 * R * sizeof(uint2));
     const int lane = threadIdx.x, nlanes = blockDim.x;     // wave 0 (lane < 64) steps the envs, every wave streams
     if (lane == 0) *tab = tabv;
-    if (zero_next && blockIdx.x == 0 && lane == 0) *zero_next = 0ull;
+    if (ca.zero_next && blockIdx.x == 0 && lane == 0) *ca.zero_next = 0ull;
     const int64_t base = (int64_t)blockIdx.x * 64;
     const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
     const bool active = lane < nvalid;                        // nvalid <= 64: only wave 0 can be active
     const int64_t i = base + (active ? lane : 0);
     uint32_t a = 0, e = 0;
+    uint64_t okb = 0ull;                 // bit t = the success condition held at step t (t < 64): the step rewards
     SynthLane sl = {};
     if (active) {
         a = now[i]; e = ever[i];
@@ -1467,6 +1672,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                         else m = synth_mask(sl, (a >> ELAPSED_SHIFT) & ELAPSED_MAX);
                         step_core(a, e, m, c, rb, fl);
                         my[t + 1 - r0] = make_uint2(a, e);
+                        okb |= (uint64_t)((fl >> 2) & 1u) << (t & 63);
                         if (reward_tb) reward_tb[(int64_t)t * ldo + i] = rb;
                         if (flags_tb) flags_tb[(int64_t)t * ldo + i] = (uint8_t)fl;
                     }
@@ -1492,10 +1698,15 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         }
         __syncthreads();                                         // the tile is reused by the next chunk
     }
-    if (active) { now[i] = a; ever[i] = e; }
-    if (count && lane < 64) {
+    if (active) {
+        now[i] = a; ever[i] = e;
+        // the step rewards of the episode as one word per env: k_returns_from_okbits turns it into the env's
+        // G row (policy_gradient/rollout.py:255-258)
+        if (okbits_out) okbits_out[i] = okb;
+    }
+    if (ca.count && lane < 64) {
         const unsigned long long nb = (unsigned long long)__popcll(__ballot(active && (e >> 31) != 0));
-        if (lane == 0 && nb) atomicAdd(count, nb);
+        if (lane == 0) shard_count_add(nb, ca);
     }
     if (ep_g) {
         // episode['g']: T copies of the constant goal row per env (rollout.py:151)
@@ -1605,7 +1816,7 @@ k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__rest
 // rollout.py:163-167 as its own launch: <= 256 blocks of 1024 lanes, 16-byte
 // loads, block reduction, one atomic per block.
 __global__ void __launch_bounds__(1024)
-k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long *__restrict__ count)
+k_success_count(const uint32_t *__restrict__ ever, int64_t n, CountArgs ca)
 {
     const int64_t nvec = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1616,7 +1827,7 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
         c += (e.x >> 31) + (e.y >> 31) + (e.z >> 31) + (e.w >> 31);
     }
     if (gtid < n - (nvec << 2)) c += ever[(nvec << 2) + gtid] >> 31;
-    block_count_add(c, count);
+    block_count_add(c, ca);
 }
 
 // ------------------------------ discounted return ---------------------------
@@ -1637,28 +1848,12 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, unsigned long long
 //   both halves of the wave (t - t_ = s - 2i either way): one instruction stream, uniform (SGPR)
 //   constants, 25 instead of 50 accumulators per lane -> ~100 VGPRs, 3-4 waves per SIMD.
 // Products are issued DR_W at a time into their own registers before the DR_W additions.
-constexpr int DR_TMAX_REG = 64;
 constexpr int DR_W = 16;
-struct PowTable { double v[DR_TMAX_REG]; };
-
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>());
-        static_for<I + 1, N>(f);
-    }
-}
 
 // The waves of a block work on consecutive 32-env groups and never exchange anything: their LDS tiles
 // are private and synchronised at wave scope, the block only makes the four waves' 128-byte pieces of a
 // reward row arrive at the memory side together.
 constexpr int DR_WPB = 4;
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // STAGE: the rewards wait in LDS instead of registers.  Lane (e, q) fetches the rows t = 2i + q of env e
 // (NI requests instead of TT: each reward is requested once per wave, not once per half) into a
@@ -1833,6 +2028,221 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int64_t ld, 
     }
 }
 
+// ---- lane = env return kernels (T = 50 / 25 / 10) --------------------------------------------------------
+// EXACT: the reference's float64 result bit for bit.  Every reward this env produces is -1.0f or -0.0f
+// (fetch_env.py:141-143), and for those the reference's product-then-sum is exactly a conditional
+// subtraction of gamma**k (returns_from_okbits above): a wave whose 64 x T rewards all lie in {-1.0f, -0.0f}
+// takes that path -- half the float64 operations of the general one and no per-lane reward operand --, any
+// other wave re-reads its rewards (they are L2-resident by then) and runs the general unfused product + sum,
+// in the reference's order.  The choice is per wave and changes no result bit.
+// SCAN: SURVEY 8(f3)'s O(T) reverse scan G[t] = fma(gamma, G[t+1], r[t]) -- NOT the reference's summation
+// order: |G_scan - G_ref| <= 4 T 2^-53 sum_k gamma^k |r[t+k]| (include/bpgym.h states the bound).
+enum { DRM_EXACT = 0, DRM_SCAN = 1 };
+constexpr int DR_LANE_WPB = 4;              // waves per block (each wave: 64 envs, a private 16-row LDS tile)
+
+template <int TT, int MODE, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
+                         double *__restrict__ G)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][G_TILE_ROWS * TT * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
+    if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
+    const bool live = base + lane < n;
+    // one 32-bit byte offset per lane (the host guarantees 4 * ld * T < 2^32 per row step: ld < 2^28)
+    const int64_t e = live ? base + lane : n - 1;
+    const uint32_t *rp = reinterpret_cast<const uint32_t *>(reward_tb) + e;
+    uint32_t r[TT];
+    static_for<0, TT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        r[t] = __builtin_nontemporal_load(rp + (int64_t)t * ld);          // read once
+    });
+    double acc[TT];
+    if constexpr (MODE == DRM_SCAN) {
+        acc[TT - 1] = (double)__uint_as_float(r[TT - 1]);
+        static_for<1, TT>([&](auto tc) {
+            constexpr int t = TT - 1 - decltype(tc)::value;
+            acc[t] = __fma_rn(gamma, acc[t + 1], (double)__uint_as_float(r[t]));
+        });
+    } else {
+        bool plain = true;                    // every reward of this env is -1.0f or -0.0f
+        uint64_t ok = 0ull;
+        static_for<0, TT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const bool isok = r[t] == RBITS_OK;
+            plain &= isok | (r[t] == RBITS_FAIL);
+            ok |= (uint64_t)isok << t;
+        });
+        if (__all(plain)) {
+            returns_from_okbits<TT>(ok, acc);                // reads gamma**k from kernarg offset 0 (= pw)
+        } else {
+            // general rewards: the reference's loop nest (OUTER over the step t that brings a reward, INNER over
+            // the returns t_ < t), product and sum rounded separately.  Same two passes over the lag as above
+            // (per accumulator the additions still come in increasing t); the rewards are read again, step by
+            // step and a few steps ahead (they are L2-resident by now), so that neither T reward registers nor
+            // the whole gamma**k table stay alive beside the T accumulators.
+            constexpr int KA = TT / 2, AHEAD = 4, GW = 6;     // GW: products in flight (their temporaries are registers)
+            {
+                KernargDouble *pwk = kernarg_pow();
+                double ck[KA + 1];
+                static_for<1, KA + 1>([&](auto kc) { ck[decltype(kc)::value] = pwk[decltype(kc)::value]; });
+                static_for<1, KA + 1>([&](auto kc) { pin_sgpr(ck[decltype(kc)::value]); });
+                // a running pointer, advanced one row per read: with T independent row addresses the compiler
+                // computes all of them up front (2 VGPRs each)
+                const uint32_t *rq = rp;
+                asm volatile("" : "+v"(rq));
+                float ahead[AHEAD];
+                static_for<0, AHEAD>([&](auto uc) {
+                    ahead[decltype(uc)::value] = __uint_as_float(*rq);
+                    if constexpr (decltype(uc)::value + 1 < TT) rq += ld;
+                    asm volatile("" : "+v"(rq));
+                });
+                static_for<0, TT>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    const double rt = (double)ahead[t % AHEAD];
+                    if constexpr (t + AHEAD < TT) {
+                        ahead[t % AHEAD] = __uint_as_float(*rq);
+                        if constexpr (t + AHEAD + 1 < TT) rq += ld;
+                        asm volatile("" : "+v"(rq));
+                    }
+                    acc[t] = rt;                                            // G[t] starts as r[t]
+                    constexpr int lo = t > KA ? t - KA : 0;
+                    static_for<0, (t - lo + GW - 1) / GW>([&](auto gc) {       // GW products, then their GW sums
+                        constexpr int g0 = lo + decltype(gc)::value * GW;
+                        static_for<g0, (g0 + GW < t ? g0 + GW : t)>([&](auto uc) {
+                            constexpr int t_ = decltype(uc)::value;
+                            acc[t_] = acc[t_] + ck[t - t_] * rt;
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+            if constexpr (KA + 1 < TT) {
+                KernargDouble *pwk = kernarg_pow();
+                double ck[TT];
+                static_for<KA + 1, TT>([&](auto kc) { ck[decltype(kc)::value] = pwk[decltype(kc)::value]; });
+                static_for<KA + 1, TT>([&](auto kc) { pin_sgpr(ck[decltype(kc)::value]); });
+                const uint32_t *rq = rp + (int64_t)(KA + 1) * ld;
+                asm volatile("" : "+v"(rq));
+                float ahead[AHEAD];
+                static_for<0, AHEAD>([&](auto uc) {
+                    ahead[decltype(uc)::value] = __uint_as_float(*rq);
+                    if constexpr (KA + 1 + decltype(uc)::value + 1 < TT) rq += ld;
+                    asm volatile("" : "+v"(rq));
+                });
+                static_for<KA + 1, TT>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    const double rt = (double)ahead[(t - KA - 1) % AHEAD];
+                    if constexpr (t + AHEAD < TT) {
+                        ahead[(t - KA - 1) % AHEAD] = __uint_as_float(*rq);
+                        if constexpr (t + AHEAD + 1 < TT) rq += ld;
+                        asm volatile("" : "+v"(rq));
+                    }
+                    static_for<0, (t - KA + GW - 1) / GW>([&](auto gc) {
+                        constexpr int g0 = decltype(gc)::value * GW;
+                        static_for<g0, (g0 + GW < t - KA ? g0 + GW : t - KA)>([&](auto uc) {
+                            constexpr int t_ = decltype(uc)::value;
+                            acc[t_] = acc[t_] + ck[t - t_] * rt;
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+        }
+    }
+    wave_store_returns<TT>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+}
+
+// G rows from the step-ok words of a rollout launch (k_rollout<..., OKB>, k_episode): same arithmetic as above,
+// 8 bytes read and 8 T bytes written per env.
+template <int TT, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
+k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
+                           int64_t n)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][G_TILE_ROWS * TT * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
+    if (base >= n) return;
+    const int64_t e = base + lane < n ? base + lane : n - 1;
+    const uint64_t ok = okbits[e];
+    double acc[TT];
+    returns_from_okbits<TT>(ok, acc);
+    wave_store_returns<TT>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+}
+
+// any T <= 64: the rows accumulate in an LDS tile, one env per lane
+__global__ void __launch_bounds__(64)
+k_returns_from_okbits(const uint64_t *__restrict__ okbits, double *__restrict__ G, int64_t n, int T, int R, PowTable pw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tile = reinterpret_cast<double *>(smem);   // [64][R]
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        const uint64_t ok = okbits[base + lane];
+        double *my = tile + lane * R;
+        for (int t = 0; t < T; t++) my[t] = ((ok >> t) & 1ull) ? -0.0 : -1.0;
+        for (int t = 1; t < T; t++) {
+            if (!((ok >> t) & 1ull))
+                for (int t_ = 0; t_ < t; t_++) my[t_] = my[t_] - pw.v[t - t_];
+        }
+    }
+    __syncthreads();
+    double *o = G + base * (int64_t)T;
+    const int total = nvalid * T;
+    int e = 0, rem = lane;
+    while (rem >= T) { rem -= T; e++; }
+    for (int f = lane; f < total; f += 64) {
+        o[f] = tile[e * R + rem];
+        rem += 64;
+        while (rem >= T) { rem -= T; e++; }
+    }
+}
+
+// any T <= DR_TMAX: O(T) reverse scan, rows in an LDS tile
+__global__ void __launch_bounds__(64)
+k_discounted_return_scan(const float *__restrict__ reward_tb, int64_t n, int64_t ld, int T, int R, double gamma,
+                         double *__restrict__ G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tile = reinterpret_cast<double *>(smem);   // [64][R]
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+    if (lane < nvalid) {
+        double *my = tile + lane * R;
+        const float *p = reward_tb + base + lane;
+        double g = 0.0;
+        for (int t1 = T; t1 > 0; t1 -= 8) {            // steps t1-8 .. t1-1, eight requests in flight
+            float r8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (t1 - 1 - u >= 0) r8[u] = p[(int64_t)(t1 - 1 - u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t1 - 1 - u;
+                if (t >= 0) {
+                    g = (t == T - 1) ? (double)r8[u] : __fma_rn(gamma, g, (double)r8[u]);
+                    my[t] = g;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double *o = G + base * (int64_t)T;
+    const int total = nvalid * T;
+    int e = 0, rem = lane;
+    while (rem >= T) { rem -= T; e++; }
+    for (int f = lane; f < total; f += 64) {
+        o[f] = tile[e * R + rem];
+        rem += 64;
+        while (rem >= T) { rem -= T; e++; }
+    }
+}
+
 // np.isnan(o_new).any() of the rollout worker (rollout.py:139-142) without a host round trip:
 // ORs 1 into *flag when any of rows x cols float32 values (row stride ld) is a NaN.
 // FLAT: the rows are one contiguous, 16-byte aligned run -> float4 loads, four in flight per lane.
@@ -1906,7 +2316,34 @@ StepConst step_const(const bpg_batch *b)
     c.want_touch = b->info.want_touch;
     c.want_never = b->info.want_never;
     c.max_steps = (uint32_t)b->max_steps;
+    // Variation: matrix side 6, num_objs 4..6 per episode (fetch_env.py:649) -> pairs with an index >= n are
+    // never demoted (:154-157).  Every other variant: num_objs == side, nothing is sticky.
+    c.sticky_on = b->info.is_variation ? 1u : 0u;
+    for (int n = 0; n < BPG_MAX_OBJS; n++) {
+        uint32_t demoted = 0;
+        for (int i = 0; i < n && i < b->info.side; i++)
+            for (int j = i; j < n && j < b->info.side; j++) demoted |= 1u << host_pair_index(i, j);
+        c.sticky_by_n[n] = b->info.valid_pairs & ~demoted;
+    }
     return c;
+}
+
+CountArgs count_args(const bpg_batch *b, unsigned long long *count, unsigned long long *zero_next)
+{
+    CountArgs ca;
+    ca.count = count;
+    ca.zero_next = zero_next;
+    ca.shards = b->d_count_shards;
+    return ca;
+}
+
+// gamma ** k as Python's float pow (C pow), k < DR_TMAX_REG
+PowTable pow_table(double gamma, int T)
+{
+    PowTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    for (int k = 0; k < T && k < DR_TMAX_REG; k++) tab.v[k] = std::pow(gamma, (double)k);
+    return tab;
 }
 
 SynthConst synth_const(const bpg_batch *b)
@@ -1963,7 +2400,8 @@ int fat_grid(int64_t work_items)
 // "Shifted rows": the row stride bpg_row_stride() recommends (profiles/r02_tune_row_stride.log).
 // 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
 // 4-per-lane instantiation.  One success-count atomic per block (block_count_add).
-struct RolloutGeometry { int epl, block, grid; bool pipe; };
+constexpr int64_t ROLLOUT_UNROLL5_FROM = 98304, ROLLOUT_EPL2_FROM = 196608;
+struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
                                  const void *flags)
@@ -1973,6 +2411,7 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
     const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
                      ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0;
     RolloutGeometry g;
+    g.unroll = 5;
     if (ok2 && n >= 131072 && !masks) {
         // contacts generated in-kernel: write-only and co-limited by the generator's arithmetic.  One
         // short-lived 256-lane block per 512 envs (no grid cap: blocks start in address order as
@@ -1981,21 +2420,28 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
         g.epl = 2;
         g.block = 256;
         g.pipe = false;
+        g.unroll = 10;
         g.grid = (int)((n / 2 + 255) / 256);
         return g;
     }
-    if (ok2 && n >= 131072) {
+    if (ok2 && n >= ROLLOUT_EPL2_FROM) {
+        // 2 envs per lane, plain loop.  From 524 288 envs on in 1024-lane blocks (one per CU, 16 waves cover
+        // the round trips); below that -- and from 4 M envs on when the rows are a power of two apart -- in
+        // 256-lane blocks.  (Round 2 ran a software-pipelined 2-per-lane loop here whose ping-pong buffers
+        // spilled to scratch under the 1024-lane register bound it was compiled with; with an honest bound it
+        // needs 200 VGPRs and is no faster than the plain loop: profiles/r03_tune_mid_shapes.log.)
         g.epl = 2;
-        // from 4 M envs on, contiguous power-of-two rows run best as many small pipelined blocks; rows
-        // shifted against each other (bpg_row_stride) keep the fat shape best at every size measured
         const bool aliased = ld_masks % 4096 == 0 || ld_out % 4096 == 0;
         const bool fat = n >= 524288 && (n < 4194304 || !aliased);
         g.block = fat ? 1024 : 256;
-        g.pipe = !fat;
+        g.pipe = false;
     } else {
+        // 1 env per lane, software-pipelined requests (latency-bound sizes): 10 rows in flight per lane below
+        // ~100 K envs, 5 above (profiles/r03_tune_mid_shapes.log)
         g.epl = 1;
         g.block = 256;
         g.pipe = true;
+        g.unroll = n < ROLLOUT_UNROLL5_FROM ? 10 : 5;
     }
     const int64_t lanes = n / g.epl;
     int64_t grid = (lanes + g.block - 1) / g.block;
@@ -2114,17 +2560,23 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     b->d_reset_counter = nullptr;
     b->now = b->ever = nullptr;
     b->d_id2obj = nullptr;
+    b->d_count_shards = nullptr;
+    b->d_okbits = nullptr;
     std::memset(b->ngeom, 0, sizeof(b->ngeom));
     const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
     hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
     hipError_t e3 = hipMalloc(&b->d_id2obj, BPG_MAX_MODELS * BPG_MAX_GEOMS);
     if (e3 == hipSuccess) e3 = hipMalloc(&b->d_reset_counter, 2 * sizeof(uint32_t));
+    const size_t shard_bytes = (size_t)COUNT_SHARDS * COUNT_SHARD_STRIDE * sizeof(unsigned long long);
+    if (e3 == hipSuccess) e3 = hipMalloc(&b->d_count_shards, shard_bytes);
+    if (e3 == hipSuccess) e3 = hipMalloc(&b->d_okbits, (size_t)((n_envs + 1) & ~(int64_t)1) * sizeof(uint64_t));
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         bpg_destroy(b);
         return fail(BPG_ERR_HIP, "hipMalloc failed for the packed state");
     }
     hipError_t e4 = hipMemset(b->d_id2obj, 0xFF, BPG_MAX_MODELS * BPG_MAX_GEOMS);
     if (e4 == hipSuccess) e4 = hipMemset(b->d_reset_counter, 0, 2 * sizeof(uint32_t));
+    if (e4 == hipSuccess) e4 = hipMemset(b->d_count_shards, 0, shard_bytes);
     hipLaunchKernelGGL(k_init, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, b->now, b->ever, n_envs,
                        (uint32_t)b->info.num_objs);
     hipError_t e5 = hipDeviceSynchronize();
@@ -2144,6 +2596,8 @@ int bpg_destroy(bpg_batch *b)
     if (b->ever) (void)hipFree(b->ever);
     if (b->d_id2obj) (void)hipFree(b->d_id2obj);
     if (b->d_reset_counter) (void)hipFree(b->d_reset_counter);
+    if (b->d_count_shards) (void)hipFree(b->d_count_shards);
+    if (b->d_okbits) (void)hipFree(b->d_okbits);
     delete b;
     return BPG_OK;
 }
@@ -2620,6 +3074,25 @@ int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever, uin
     return check_launch("k_compute_reward_packed");
 }
 
+static int launch_returns_from_okbits(const uint64_t *d_okbits, double *d_G, int64_t n, int T, double gamma, hipStream_t st)
+{
+    const PowTable tab = pow_table(gamma, T);
+    constexpr int WPB = DR_LANE_WPB;
+    const dim3 pgrid((unsigned)((n + 64 * WPB - 1) / (64 * WPB))), pblock(64 * WPB);
+    if (T == 50 && aligned16(d_G))
+        hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n);
+    else if (T == 25)
+        hipLaunchKernelGGL((k_returns_from_okbits_lane<25, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n);
+    else if (T == 10 && aligned16(d_G))
+        hipLaunchKernelGGL((k_returns_from_okbits_lane<10, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n);
+    else {
+        const int R = T | 1;
+        hipLaunchKernelGGL(k_returns_from_okbits, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)64 * R * sizeof(double), st,
+                           d_okbits, d_G, n, T, R, tab);
+    }
+    return check_launch("k_returns_from_okbits");
+}
+
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
 {
     if (!b || !a) return fail(BPG_ERR_ARG, "NULL argument");
@@ -2635,43 +3108,65 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     const ResetConst rc = reset_const(b, a->reset_first ? 1 : 0, a->d_num_grey);
     hipStream_t st = (hipStream_t)stream;
     uint32_t *rw = reinterpret_cast<uint32_t *>(a->d_reward_tb);
-    unsigned long long *cnt = a->d_success_count, *znext = a->d_zero_count;
+    const CountArgs ca = count_args(b, a->d_success_count, a->d_zero_count);
     const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
     const int64_t ldm = a->ld_masks ? a->ld_masks : b->n, ldo = a->ld_out ? a->ld_out : b->n;
     if (ldm < b->n || ldo < b->n) return fail(BPG_ERR_ARG, "ld_masks / ld_out must be 0 or >= n_envs");
+    // The policy-gradient return (policy_gradient/rollout.py:255-258).  Up to 64 steps the step rewards of an
+    // env are one 64-bit word: the rollout launch stores it (8 bytes per env, handle-owned) and a second launch
+    // on the same stream expands the words into the G rows -- no reward stream is written or read.  Longer
+    // horizons go through the reward stream.
+    enum { G_NONE, G_OKBITS, G_FROM_REWARD } gmode = G_NONE;
+    if (a->d_G) {
+        if (!(a->gamma == a->gamma)) return fail(BPG_ERR_ARG, "gamma is NaN");
+        if (((uintptr_t)a->d_G & 7u) != 0) return fail(BPG_ERR_ARG, "d_G must be 8-byte aligned");
+        if (a->T <= 64) gmode = G_OKBITS;
+        else if (a->T > DR_TMAX) return fail(BPG_ERR_ARG, "d_G needs T <= 319");
+        else if (!a->d_reward_tb) return fail(BPG_ERR_ARG, "d_G with T > 64 needs d_reward_tb (the return is computed from the reward stream)");
+        else gmode = G_FROM_REWARD;
+    }
+    uint64_t *okbits = gmode == G_OKBITS ? b->d_okbits : nullptr;
     int rcode = BPG_OK;
     if (!episode) {
+        const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
         const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb);
         const dim3 grid(geo.grid), block(geo.block);
-#define BPG_LAUNCH_ROLLOUT(SRC, EPL, OUT, UNR, PIPE)                                                          \
+#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB)                                           \
+        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB>), grid, block, 0, st,  \
+                           b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits)
+#define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
         do {                                                                                                  \
-            if (a->reset_first)                                                                               \
-                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, true, UNR, PIPE, true>), grid, block, 0, st,   \
-                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, cnt, znext); \
-            else                                                                                              \
-                hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, false, UNR, PIPE, true>), grid, block, 0, st,  \
-                                   b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, cnt, znext); \
+            if (a->reset_first) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, OKB);                 \
+            else BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, false, UNR, PIPE, LB, OKB);                               \
         } while (0)
-#define BPG_LAUNCH_ROLLOUT_OUT(SRC, EPL, UNR, PIPE)                                                           \
+#define BPG_LAUNCH_ROLLOUT_1(SRC, EPL, OUT, UNR, PIPE, LB)                                                     \
+        do {                                                                                                  \
+            if (okbits) BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, true);                              \
+            else BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, false);                                    \
+        } while (0)
+#define BPG_LAUNCH_ROLLOUT(SRC, EPL, UNR, PIPE, LB)                                                            \
         do {                                                                                                  \
             switch (out) {                                                                                    \
-            case 0: BPG_LAUNCH_ROLLOUT(SRC, EPL, 0, UNR, PIPE); break;                                        \
-            case 1: BPG_LAUNCH_ROLLOUT(SRC, EPL, 1, UNR, PIPE); break;                                        \
-            case 2: BPG_LAUNCH_ROLLOUT(SRC, EPL, 2, UNR, PIPE); break;                                        \
-            default: BPG_LAUNCH_ROLLOUT(SRC, EPL, 3, UNR, PIPE); break;                                       \
+            case 0: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 0, UNR, PIPE, LB); break;                                  \
+            case 1: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 1, UNR, PIPE, LB); break;                                  \
+            case 2: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 2, UNR, PIPE, LB); break;                                  \
+            default: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 3, UNR, PIPE, LB); break;                                 \
             }                                                                                                 \
         } while (0)
-        const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
+        // the instantiations below are the only ones: LB is the block size the shape is launched with
         if (a->d_masks) {
-            if (geo.epl == 2 && geo.pipe) BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 2, 10, true);
-            else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 2, 5, false);
-            else BPG_LAUNCH_ROLLOUT_OUT(SRC_MASKS, 1, 10, true);
+            if (geo.epl == 2 && geo.block == 1024) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 1024);
+            else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 256);
+            else if (geo.unroll == 5) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 5, true, 256);
+            else BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 10, true, 256);
         } else {                                   // nothing to request: the plain loop
-            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 2, 10, false);
-            else BPG_LAUNCH_ROLLOUT_OUT(SRC_SYNTH, 1, 5, false);
+            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 2, 10, false, 256);
+            else BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 1, 5, false, 256);
         }
-#undef BPG_LAUNCH_ROLLOUT_OUT
 #undef BPG_LAUNCH_ROLLOUT
+#undef BPG_LAUNCH_ROLLOUT_1
+#undef BPG_LAUNCH_ROLLOUT_2
+#undef BPG_LAUNCH_ROLLOUT_3
         rcode = check_launch("k_rollout");
     } else {
         if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
@@ -2705,15 +3200,18 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
             if (synth)
                 hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
-                                   tab, rc, cnt, znext);
+                                   tab, rc, ca, okbits);
             else
                 hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
-                                   tab, rc, cnt, znext);
+                                   tab, rc, ca, okbits);
             return BPG_OK;
         });
         if (rcode == BPG_OK) rcode = check_launch("k_episode");
     }
+    if (rcode == BPG_OK && gmode == G_OKBITS) rcode = launch_returns_from_okbits(b->d_okbits, a->d_G, b->n, a->T, a->gamma, st);
+    if (rcode == BPG_OK && gmode == G_FROM_REWARD)
+        rcode = bpg_discounted_return_ld(a->d_reward_tb, b->n, ldo, a->T, a->gamma, a->d_G, b->device, stream);
     if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey) {
         hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, st, b->d_reset_counter);
         rcode = check_launch("k_bump_counter");
@@ -2726,7 +3224,7 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream)
     if (!b || !d_count) return fail(BPG_ERR_ARG, "NULL argument");
     DeviceGuard guard(b->device);
     hipLaunchKernelGGL(k_success_count, dim3(fat_grid((b->n + 3) / 4)), dim3(1024), 0, (hipStream_t)stream,
-                       b->ever, b->n, d_count);
+                       b->ever, b->n, count_args(b, d_count, nullptr));
     return check_launch("k_success_count");
 }
 
@@ -2743,22 +3241,20 @@ int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, in
     if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
     if (ld < n) return fail(BPG_ERR_ARG, "ld must be >= n");
     DeviceGuard guard(device_id);
-    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if ((T == 50 || T == 25 || T == 10) && ld < ((int64_t)1 << 28)) {
-        // register-resident fast path for the horizons in use (T = max_episode_steps = 50): 32 envs per
-        // one-wave block, two lanes per env
-        const dim3 pgrid((unsigned)((n + 32 * DR_WPB - 1) / (32 * DR_WPB))), pblock(64 * DR_WPB);
-        PowTable tab;
-        std::memset(&tab, 0, sizeof(tab));
-        for (int k = 0; k < T; k++) tab.v[k] = std::pow(gamma, (double)k);   // gamma ** k as Python's float pow (C pow)
+    if ((T == 50 || T == 25 || T == 10) && ld < ((int64_t)1 << 28) && aligned16(d_G)) {
+        // register-resident path for the horizons in use (T = max_episode_steps = 50): one env per lane
+        const PowTable tab = pow_table(gamma, T);
+        const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
+        hipStream_t st = (hipStream_t)stream;
         if (T == 50)
-            hipLaunchKernelGGL(k_discounted_return_reg<50>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
+            hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
         else if (T == 25)
-            hipLaunchKernelGGL(k_discounted_return_reg<25>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
+            hipLaunchKernelGGL((k_discounted_return_lane<25, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
         else
-            hipLaunchKernelGGL(k_discounted_return_reg<10>, pgrid, pblock, 0, (hipStream_t)stream, d_reward_tb, n, ld, tab, d_G);
-        return check_launch("k_discounted_return_reg");
+            hipLaunchKernelGGL((k_discounted_return_lane<10, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
+        return check_launch("k_discounted_return_lane");
     }
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     PowTableBig big;
     std::memset(&big, 0, sizeof(big));
     for (int k = 0; k < T; k++) big.v[k] = std::pow(gamma, (double)k);
@@ -2769,6 +3265,32 @@ int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, in
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_discounted_return, grid, block, lds, (hipStream_t)stream, d_reward_tb, n, ld, T, R, big, d_G);
     return check_launch("k_discounted_return");
+}
+
+int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma, double *d_G,
+                               int device_id, void *stream)
+{
+    if (!d_reward_tb || !d_G) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 1 || T < 1 || T > DR_TMAX) return fail(BPG_ERR_ARG, "n must be >= 1 and T in 1..319");
+    if (ld == 0) ld = n;
+    if (ld < n) return fail(BPG_ERR_ARG, "ld must be 0 or >= n");
+    DeviceGuard guard(device_id);
+    if (T == 50 && ld < ((int64_t)1 << 28) && aligned16(d_G)) {
+        PowTable none;
+        std::memset(&none, 0, sizeof(none));
+        const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
+        hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, DR_LANE_WPB>), pgrid, pblock, 0, (hipStream_t)stream,
+                           none, d_reward_tb, n, ld, gamma, d_G);
+        return check_launch("k_discounted_return_lane<scan>");
+    }
+    const int R = T | 1;
+    const size_t lds = (size_t)64 * R * sizeof(double);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_discounted_return_scan),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_discounted_return_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
+                       d_reward_tb, n, ld, T, R, gamma, d_G);
+    return check_launch("k_discounted_return_scan");
 }
 
 int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint32_t *d_flag, int device_id,

@@ -65,6 +65,21 @@ def discounted_return(reward_tb, gamma, out=None):
     return out
 
 
+def discounted_return_scan(reward_tb, gamma, out=None):
+    """The same return as an O(T) reverse scan G[t] = fma(gamma, G[t+1], r[t]): NOT the
+    reference's summation order -- within 4 T 2^-53 sum_k gamma^k |r[t+k]| of it (include/bpgym.h)."""
+    assert reward_tb.dim() == 2 and reward_tb.dtype == torch.float32 and reward_tb.is_cuda
+    if reward_tb.stride(1) != 1 or reward_tb.stride(0) < reward_tb.shape[1]:
+        reward_tb = reward_tb.contiguous()
+    T, B = reward_tb.shape
+    if out is None:
+        out = torch.empty(B, T, dtype=torch.float64, device=reward_tb.device)
+    _lib.check(_lib.lib().bpg_discounted_return_scan(_ptr(reward_tb), B, int(reward_tb.stride(0)) if T > 1 else B, T,
+                                                     float(gamma), _ptr(out), reward_tb.device.index,
+                                                     _stream(reward_tb.device)))
+    return out
+
+
 class RolloutStudent:
 
     def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1,
@@ -318,14 +333,17 @@ class RolloutStudent:
         return self._finish(dict(self._graph_ep), self._graph_Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
-                                want_reward=False, materialize_constants=False):
+                                want_reward=False, materialize_constants=False, gamma=None):
         """Whole rollout in ONE kernel launch (no policy between steps): contacts
         come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
         source when None.  Same episode dict as generate_rollouts; `o` is the
         env's physics-less observation repeated, `u` = `actions` or zeros.
         The arrays that are constant over the episode (`g`, and `o` without a physics
         backend) are returned as stride-0 expanded views unless materialize_constants=True,
-        which makes the kernel write contiguous float32 copies of them as well."""
+        which makes the kernel write contiguous float32 copies of them as well.
+        gamma: also return `G` (B, T) float64, the policy-gradient return of the rollout
+        (policy_gradient/rollout.py:255-258, bit-identical), computed by the same call from the
+        step-ok bits of the launch -- no reward stream is written or read for it."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
@@ -338,7 +356,9 @@ class RolloutStudent:
         if actions is not None:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device))               # stored as given (rollout.py:147)
         reward = time_major_empty(T, B, torch.float32, self.device) if want_reward else None
+        G = torch.empty((B, T), dtype=torch.float64, device=self.device) if gamma is not None else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
+                                d_G=None if G is None else G.data_ptr(), gamma=0.0 if gamma is None else float(gamma),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
                                 d_ep_ag=ep['ag'].data_ptr(),
                                 d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
@@ -352,6 +372,8 @@ class RolloutStudent:
         out = self._finish(ep)
         if want_reward:
             out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
+        if G is not None:
+            out['G'] = G if self.output == 'torch' else G.cpu().numpy()
         return out
 
     # -- rollout.py:174-210 -----------------------------------------------
@@ -405,6 +427,14 @@ class PGRolloutStudent(RolloutStudent):
 
     def anneal(self):
         self.time += 1.0
+
+    def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None, want_reward=False,
+                                materialize_constants=False, gamma=None):
+        """The whole pg rollout in one call without a policy between the steps: the episode arrays and
+        the return `G` for this worker's gamma (policy_gradient/rollout.py:255-258, :283-288)."""
+        return super().generate_rollouts_fused(test=test, masks=masks, num_grey=num_grey, actions=actions,
+                                               want_reward=want_reward, materialize_constants=materialize_constants,
+                                               gamma=self.gamma if gamma is None else gamma)
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference

@@ -295,6 +295,14 @@ typedef struct {
     unsigned long long *d_zero_count;    /* optional second counter the launch sets to 0 (ping-pong) */
     int64_t ld_masks;          /* row stride of d_masks in elements; 0 = n_envs (contiguous rows) */
     int64_t ld_out;            /* row stride of d_reward_tb and d_flags_tb in elements; 0 = n_envs */
+    double *d_G;               /* (n_envs, T) float64 batch-major: the policy-gradient return of the rollout
+                                  (policy_gradient/rollout.py:217-231, :255-258), bit-identical to the reference's
+                                  float64 accumulation, WITHOUT a reward stream: for T <= 64 the rollout launch keeps
+                                  each env's step rewards as one 64-bit step-ok word (8 bytes per env, handle-owned)
+                                  and a second launch enqueued by the same call expands the words into the rows;
+                                  64 < T <= 319: computed from d_reward_tb, which is then required.  8-byte aligned
+                                  (16 for the fast T = 50 / 10 forms).  NULL = not produced */
+    double gamma;              /* discount of d_G (config.py:83: 1 - 1/T) */
 } bpg_rollout_args;
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 
@@ -309,9 +317,18 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream);
  * in the kernel arguments, so the call only enqueues a launch (hipGraph-capturable). */
 int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma,
                           double *d_G, int device_id, void *stream);
-/* Same for a reward stream with row stride ld >= n (the padded rows bpg_rollout writes). */
+/* Same for a reward stream with row stride ld >= n (the padded rows bpg_rollout writes).
+ * T = 50 / 25 / 10: one env per lane; a wave whose rewards are all -1.0f / -0.0f (the only values
+ * compute_reward produces, fetch_env.py:141-143) replaces product + sum by a conditional subtraction of
+ * gamma**k -- exact for those rewards, same bits --, any other wave runs the general product + sum. */
 int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma,
                              double *d_G, int device_id, void *stream);
+/* the same return as an O(T) reverse scan G[t] = fma(gamma, G[t+1], r[t]) instead of the
+ * reference's O(T^2) loop (policy_gradient/rollout.py:255-258).  NOT the reference's summation order, so
+ * tolerance-based:  |G_scan[t] - G_reference[t]| <= 4 T 2^-53 * sum_{k>=0} gamma^k |r[t+k]|  (0 <= gamma <= 1).
+ * bpg_discounted_return stays the default (bit-exact).  ld = row stride of d_reward_tb (0 = n). */
+int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma,
+                               double *d_G, int device_id, void *stream);
 
 /* `np.isnan(o_new).any()` of the rollout worker (rollout.py:139-142) as a device-side flag:
  * *d_flag |= 1 when any of the rows x cols float32 values at d_x (row stride ld) is a NaN.  The

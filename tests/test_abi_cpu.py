@@ -133,4 +133,4 @@ def test_row_stride_helper_is_a_pure_host_function():
         assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
-    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16 + 16

@@ -71,3 +71,30 @@ def test_two_rank_sharded_rollout_equals_single_batch():
         np.testing.assert_array_equal(all_ret, ret.cpu().numpy())
         np.testing.assert_array_equal(all_succ, succ.cpu().numpy())
         assert rate == pytest.approx(float(cnt.item()) / TOTAL, abs=1e-12)
+
+
+def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
+    """`python bench.py --gpus 2` with no WORLD_SIZE set: the parent (which never touches the GPU) starts
+    two fresh rank processes -- the reference's mpi_fork, train.py:113-119 -- here both on cuda:0 with gloo
+    (one card on the box), relays rank 0's JSON line and exits 0.  --total-envs = BASELINE configs[3]'s
+    per-GPU shard size x 1 (524 288 envs over the two ranks), all-gather of the per-env final flag bytes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-device', '--backend', 'gloo',
+           '--total-envs', '524288', '--steps', '4', '--warmup', '2', '--prewarm', '4', '--collective', 'allgather',
+           '--reduce-every', '2', '--no-extras', '--no-cpu-baseline', '--launch-timeout', '500']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert 'error' not in line
+    assert line['n_gpus'] == 2 and line['rccl_world_size'] == 2 and line['backend'] == 'gloo'
+    assert line['scaling'] == 'strong' and line['config']['total_envs'] == 524288
+    assert line['config']['envs_per_gpu'] == 262144
+    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 524288
+    km = line['kernel_ms_per_rank']
+    assert len(km['all']) == 2 and 0 < km['min'] <= km['max']
+    assert line['launcher']['rank_exit_codes'] == [0, 0]
+    assert line['value'] > 0 and 0 <= line['config']['success_rate'] <= 1

@@ -800,8 +800,12 @@ def test_worker_streams_use_the_recommended_row_stride():
     env = w.env
     masks = torch.empty((T, B + 256), dtype=torch.int32, device=DEV)[:, :B]      # rows of the caller's choosing
     bpg._lib.check(bpg._lib.lib().bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(masks.data_ptr()), masks.stride(0), None))
-    ep1 = w.generate_rollouts_fused(masks=masks, want_reward=True)
-    ep2 = w.generate_rollouts_fused(masks=masks.contiguous(), want_reward=True)
+    # the same explicit block counts for both rollouts: the masks were generated for the episode that was current
+    # then, and a pair of an object the NEXT episode does not have would (as in the reference, fetch_env.py:154-157)
+    # stay set -- the two rollouts would differ for a reason that has nothing to do with the row stride
+    ng = env.num_objs_per_env().to(torch.int32) - 4
+    ep1 = w.generate_rollouts_fused(masks=masks, want_reward=True, num_grey=ng)
+    ep2 = w.generate_rollouts_fused(masks=masks.contiguous(), want_reward=True, num_grey=ng)
     assert ep1['reward_tb'].stride(0) == bpg._lib.lib().bpg_row_stride(B)
     assert torch.equal(ep1['reward_tb'].view(torch.int32), ep2['reward_tb'].view(torch.int32))
     assert torch.equal(ep1['ag'], ep2['ag'])

@@ -1,0 +1,306 @@
+"""Round-3 GPU tests (through the C-ABI, bit-exact unless a tolerance is written in the test):
+the policy-gradient return produced by the rollout call itself (step-ok words, no reward stream),
+the lane-per-env return kernels (plain -1.0 / -0.0 rewards and general rewards in one launch), the
+O(T) scan form, raw masks that carry pairs of absent objects (kept exactly as the reference keeps
+them), the sharded success counter, and the reference-owned seed arithmetic."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import blockpuzzle_gym_amd as bpg
+from oracle import bpg_oracle as O
+from util import GOLDEN, VARIANTS, ENV_IDS, short, legal_masks, fixture_masks, valid_by_n
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = bpg._lib.lib()
+P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+
+
+def i32(a):
+    return torch.as_tensor(np.ascontiguousarray(a).view(np.int32), device=DEV)
+
+
+def dims_of(env_id):
+    v = VARIANTS[env_id]
+    return dict(o=v['dimo'], u=4, g=v['dimg'], info_is_success=1)
+
+
+def oracle_G(reward_tb, gamma):
+    """(T, B) float32 rewards -> (B, T) float64 returns, the reference's loop (oracle/bpg_oracle.c)."""
+    r = np.asarray(reward_tb)
+    return np.stack([O.discounted_return(r[:, b].astype(np.float64), gamma) for b in range(r.shape[1])])
+
+
+def same_bits(a, b):
+    np.testing.assert_array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+# ------------------------------------------------------------------ return kernels
+@pytest.mark.parametrize('T', [50, 25, 10])
+def test_lane_return_kernel_plain_and_general_rewards_in_one_launch(T):
+    """T = 50 / 25 / 10 run one env per lane.  Waves whose rewards are all -1.0f / -0.0f take the conditional-
+    subtraction path, any other wave the general product + sum: both must give the reference's bits, in the
+    same launch, including +0.0f (NOT in the plain set), a partial last wave and padded rows."""
+    rng = np.random.RandomState(T)
+    B = 64 * 5 + 37
+    r = np.where(rng.rand(T, B) < 0.6, -1.0, -0.0).astype(np.float32)
+    r[:, 64:128] = rng.normal(size=(T, 64)).astype(np.float32)            # a wave of arbitrary floats
+    r[3, 130] = 0.0                                                        # +0.0f: one odd value in a plain wave
+    r[:, 200] = np.float32(-0.5)                                           # ... and one odd env in another
+    r[:, 320:] = rng.choice(np.array([-1.0, -0.0, 2.5], np.float32), size=(T, B - 320))   # the partial wave
+    gamma = 1.0 - 1.0 / 50
+    want = oracle_G(r, gamma)
+    same_bits(bpg.discounted_return(torch.as_tensor(r, device=DEV), gamma).cpu().numpy(), want)
+    padded = bpg.time_major_empty(T, B, torch.float32, DEV)
+    big = torch.empty((T, B + 24), dtype=torch.float32, device=DEV)[:, :B]
+    for dst in (padded, big):
+        dst.copy_(torch.as_tensor(r))
+        same_bits(bpg.discounted_return(dst, gamma).cpu().numpy(), want)
+    # all-plain input: every wave on the fast path
+    r2 = np.where(rng.rand(T, B) < 0.9, -1.0, -0.0).astype(np.float32)
+    same_bits(bpg.discounted_return(torch.as_tensor(r2, device=DEV), gamma).cpu().numpy(), oracle_G(r2, gamma))
+
+
+def test_scan_return_is_within_its_stated_bound():
+    """bpg_discounted_return_scan: G[t] = fma(gamma, G[t+1], r[t]); include/bpgym.h promises
+    |G_scan - G_ref| <= 4 T 2^-53 sum_k gamma^k |r[t+k]| -- checked against the oracle (the reference's
+    order) for env rewards and for arbitrary floats, register (T = 50) and LDS (other T) forms."""
+    rng = np.random.RandomState(5)
+    for T, B in [(50, 300), (50, 64), (7, 70), (100, 65), (319, 3)]:
+        gamma = 1.0 - 1.0 / T
+        for kind in ('env', 'float'):
+            r = (np.where(rng.rand(T, B) < 0.7, -1.0, -0.0) if kind == 'env' else rng.normal(size=(T, B))).astype(np.float32)
+            got = bpg.discounted_return_scan(torch.as_tensor(r, device=DEV), gamma).cpu().numpy()
+            want = oracle_G(r, gamma)
+            pw = gamma ** np.arange(T)
+            bound = np.stack([[4 * T * 2.0 ** -53 * float(np.sum(pw[:T - t] * np.abs(r[t:, b].astype(np.float64))))
+                               for t in range(T)] for b in range(B)])
+            assert np.all(np.abs(got - want) <= bound), (T, kind, float(np.max(np.abs(got - want) - bound)))
+    assert L.bpg_discounted_return_scan(None, 4, 4, 5, 0.9, None, 0, None) != 0
+    x = torch.zeros((320, 4), device=DEV)
+    with pytest.raises(bpg._lib.BpgError):
+        bpg.discounted_return_scan(x, 0.9)
+
+
+# ------------------------------------------------------------------ G from the rollout call
+def _rollout_with_G(env, T, gamma, masks=None, num_grey=None, reset_first=1, want=('reward', 'flags'), episode=False):
+    B = env.num_envs
+    out = {}
+    G = torch.full((B, T), float('nan'), dtype=torch.float64, device=DEV)
+    args = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_G=G.data_ptr(), gamma=gamma)
+    keep = []
+    if masks is not None:
+        args.d_masks, args.ld_masks = masks.data_ptr(), int(masks.stride(0)) if T > 1 else B
+    if num_grey is not None:
+        ng = torch.as_tensor(np.asarray(num_grey, np.int32), device=DEV)
+        keep.append(ng)
+        args.d_num_grey = ng.data_ptr()
+    if 'reward' in want:
+        out['reward'] = bpg.time_major_empty(T, B, torch.float32, DEV)
+        args.d_reward_tb, args.ld_out = out['reward'].data_ptr(), int(out['reward'].stride(0))
+    if 'flags' in want:
+        out['flags'] = torch.empty((T, int(L.bpg_row_stride(B))), dtype=torch.uint8, device=DEV)[:, :B]
+        args.d_flags_tb, args.ld_out = out['flags'].data_ptr(), int(out['flags'].stride(0))
+    if episode:
+        out['ag'] = torch.empty((B, T + 1, env.dimg), dtype=torch.float32, device=DEV)
+        args.d_ep_ag = out['ag'].data_ptr()
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+    torch.cuda.synchronize()
+    out['G'] = G
+    return out
+
+
+@pytest.mark.parametrize('env_id', ['BlocksTouchVariation-v0', 'ToppleTower-v0', 'BlocksTouch-v0'])
+@pytest.mark.parametrize('T', [50, 25, 10, 7, 33, 64, 1])
+def test_rollout_call_produces_the_pg_return(env_id, T):
+    """bpg_rollout(d_G): G from the step-ok words of the launch == the reference's loop over the step rewards
+    the same call wrote (those are pinned to the oracle elsewhere), for every horizon class (lane kernels 50 /
+    25 / 10, the LDS form for the others), odd batches, with and without the in-launch reset, masks and the
+    synthetic source, stream path and episode path."""
+    rng = np.random.RandomState(T)
+    gamma = 1.0 - 1.0 / max(T, 2)
+    for B in (193, 2048, 1):
+        env = bpg.make(env_id, num_envs=B, device=DEV, seed=3)
+        ng = rng.randint(3, size=B)
+        nobj = (4 + ng) if env.info.is_variation else env.num_objs
+        m = i32(legal_masks(rng, T, B, nobj, density=2))
+        for kw in (dict(masks=m, num_grey=ng), dict(masks=m, num_grey=ng, reset_first=0), dict(masks=None),
+                   dict(masks=m, num_grey=ng, episode=True), dict(masks=m, num_grey=ng, want=('reward',))):
+            o = _rollout_with_G(env, T, gamma, **kw)
+            r = o['reward'].cpu().numpy()
+            assert set(np.unique(r.view(np.uint32))) <= {0xBF800000, 0x80000000}
+            same_bits(o['G'].cpu().numpy(), oracle_G(r, gamma))
+            if 'flags' in o:      # bit 2 of the flags byte is the step reward
+                np.testing.assert_array_equal((o['flags'].cpu().numpy() >> 2) & 1, (r.view(np.uint32) == 0x80000000))
+    # no stream at all: G alone, from the same state
+    env = bpg.make(env_id, num_envs=130, device=DEV, seed=3)
+    env.reset(num_grey=np.arange(130) % 3)
+    sd = env.state_dict()
+    o = _rollout_with_G(env, T, gamma, masks=None, reset_first=0, want=('reward',))
+    env.load_state_dict(sd)
+    o2 = _rollout_with_G(env, T, gamma, masks=None, reset_first=0, want=())
+    same_bits(o2['G'].cpu().numpy(), o['G'].cpu().numpy())
+
+
+def test_rollout_return_at_every_launch_shape():
+    """The step-ok words are written by every launch shape of the fused rollout (1 / 2 envs per lane, pipelined /
+    plain loop, 256- / 1024-lane blocks) and by the contacts-in-kernel forms."""
+    T, gamma = 50, 0.98
+    for B in (65536, 131074, 262144, 524288 + 2, 131073):
+        env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=11)
+        ng = (np.arange(B) * 5) % 3
+        m = bpg.time_major_empty(T, B, torch.int32, DEV)
+        bpg._lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), int(m.stride(0)), None))
+        env.reset(num_grey=ng)
+        for kw in (dict(masks=m, num_grey=ng), dict(masks=None)):
+            o = _rollout_with_G(env, T, gamma, want=('reward', 'flags'), **kw)
+            r = o['reward'].cpu().numpy()
+            G = o['G'].cpu().numpy()
+            idx = np.r_[0:70, B // 2 - 40:B // 2 + 40, B - 70:B]
+            same_bits(G[idx], oracle_G(r[:, idx], gamma))
+            # every row: G[:, T-1] is the last reward itself, and G[:, 0] <= ... plain sanity over the whole batch
+            np.testing.assert_array_equal(G[:, T - 1].view(np.uint64), r[T - 1].astype(np.float64).view(np.uint64))
+            assert np.isfinite(G).all()
+
+
+def test_rollout_return_for_long_horizons_goes_through_the_reward_stream():
+    T, B, gamma = 100, 70, 0.99
+    env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=1, max_episode_steps=200)
+    o = _rollout_with_G(env, T, gamma, masks=None, want=('reward',))
+    same_bits(o['G'].cpu().numpy(), oracle_G(o['reward'].cpu().numpy(), gamma))
+    G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_G=G.data_ptr(), gamma=gamma)
+    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'd_reward_tb' in L.bpg_last_error()
+    a = bpg._lib.RolloutArgs(T=50, reset_first=1, d_G=G.data_ptr() + 4, gamma=gamma)
+    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
+
+
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower', 'GripperTouch', 'BlocksTouchChoose'])
+def test_golden_pg_return_from_the_fused_call(name):
+    """The reference's float64 G (policy_gradient/rollout.py, golden fixtures) from ONE fused call: contacts ->
+    masks, episode arrays and G out, no reward stream anywhere."""
+    env_id = name + '-v0'
+    d = np.load(os.path.join(GOLDEN, 'pg_rollout_%s.npz' % name))
+    B, T = int(d['B']), int(d['T'])
+    worker = bpg.PGRolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None, None,
+                                  dims_of(env_id), None, T, rollout_batch_size=B, gamma=1. - 1. / T)
+    for r in range(len(d['modes'])):
+        masks = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
+        ep = worker.generate_rollouts_fused(masks=i32(masks), num_grey=d['r%d_num_objs' % r] - 4)
+        assert ep['G'].dtype == np.float64
+        same_bits(ep['G'], d['r%d_G' % r])
+        np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
+        np.testing.assert_array_equal(ep['info_is_success'], d['r%d_info_is_success' % r])
+    # stream path on a fresh env, first golden rollout
+    env = bpg.make(env_id, num_envs=B, device=DEV)
+    masks = fixture_masks(env_id, d['r0_contacts'], d['r0_ncon'], d['r0_model_idx'])
+    o = _rollout_with_G(env, T, 1. - 1. / T, masks=i32(masks), num_grey=d['r0_num_objs'] - 4, want=('flags',))
+    same_bits(o['G'].cpu().numpy(), d['r0_G'])
+
+
+def test_return_inside_the_rollout_launch_variant():
+    """BPG_G_IN_LAUNCH=1 (read once per process): the bench shape computes its G rows inside the rollout launch.
+    Run in a child process; must give the same bits as the two-launch form and the oracle."""
+    code = r'''
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import blockpuzzle_gym_amd as bpg
+from oracle import bpg_oracle as O
+L = bpg._lib.lib()
+T, gamma = 50, 0.98
+for B in (2048, 131072 + 128, 524288):
+    env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device='cuda:0', seed=4)
+    ng = torch.as_tensor(((np.arange(B) * 5) %% 3).astype(np.int32), device='cuda:0')
+    m = bpg.time_major_empty(T, B, torch.int32, 'cuda:0')
+    env.reset(num_grey=ng)
+    bpg._lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(m.data_ptr()), int(m.stride(0)), None))
+    fl = bpg.time_major_empty(T, B, torch.uint8, 'cuda:0')
+    G = torch.full((B, T), float('nan'), dtype=torch.float64, device='cuda:0')
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=int(m.stride(0)),
+                             d_flags_tb=fl.data_ptr(), ld_out=int(fl.stride(0)), d_G=G.data_ptr(), gamma=gamma)
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    torch.cuda.synchronize()
+    f = fl.cpu().numpy(); g = G.cpu().numpy()
+    r = np.where((f >> 2) & 1, np.float32(-0.0), np.float32(-1.0)).astype(np.float32)
+    idx = np.r_[0:130, B // 2 - 65:B // 2 + 65, B - 130:B]
+    for b in idx:
+        assert (g[b].view(np.uint64) == O.discounted_return(r[:, b].astype(np.float64), gamma).view(np.uint64)).all(), b
+    assert np.isfinite(g).all()
+    np.testing.assert_array_equal(g[:, T - 1].view(np.uint64), r[T - 1].astype(np.float64).view(np.uint64))
+print('in-launch ok')
+''' % (ROOT, os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, BPG_G_IN_LAUNCH='1')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and 'in-launch ok' in out.stdout, out.stderr[-3000:]
+
+
+# ------------------------------------------------------------------ raw masks with pairs of absent objects
+def test_masks_with_pairs_of_absent_objects_behave_as_in_the_reference():
+    """fetch_env.py:154-157 demotes 1 -> 0 only for i, j < num_objs, while Variation's matrix is always 6 x 6:
+    a raw mask bit for a pair with an object >= num_objs (no id2obj table produces one) is set and then stays 1.
+    Per-step kernels, every fused launch shape and the episode writer must keep it exactly as the oracle's
+    matrix form does."""
+    rng = np.random.RandomState(77)
+    env_id, T = 'BlocksTouchVariation-v0', 12
+    for B in (193, 131074):
+        ng = rng.randint(3, size=B)
+        m = rng.randint(0, 1 << 21, size=(T, B)).astype(np.uint32) & rng.randint(0, 1 << 21, size=(T, B)).astype(np.uint32)
+        illegal = ~valid_by_n()[4 + ng] & 0x1FFFFF
+        assert (m & illegal[None, :]).any()
+        nb = min(B, 193)
+        ref, _ = O.generate_rollouts(env_id, nb, T, m[:, :nb], num_grey=ng[:nb])
+        # fused, stream + episode path
+        worker = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
+                                    dims_of(env_id), None, T, rollout_batch_size=B)
+        ep = worker.generate_rollouts_fused(masks=i32(m), num_grey=ng, want_reward=True)
+        np.testing.assert_array_equal(ep['ag'][:nb], ref['ag'])
+        np.testing.assert_array_equal(ep['info_is_success'][:nb], ref['info_is_success'])
+        np.testing.assert_array_equal(ep['reward_tb'][:, :nb].view(np.uint32), ref['reward'].view(np.uint32))
+        # stream path (k_rollout shapes) == single steps (k_step_vec4) == the same rewards
+        env = bpg.make(env_id, num_envs=B, device=DEV)
+        rew = bpg.time_major_empty(T, B, torch.float32, DEV)
+        dm = i32(m)
+        ngt = torch.as_tensor(ng.astype(np.int32), device=DEV)
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ngt.data_ptr(), d_masks=dm.data_ptr(),
+                                 d_reward_tb=rew.data_ptr(), ld_out=int(rew.stride(0)))
+        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        np.testing.assert_array_equal(rew.cpu().numpy()[:, :nb].view(np.uint32), ref['reward'].view(np.uint32))
+        env2 = bpg.make(env_id, num_envs=B, device=DEV)
+        env2.reset(num_grey=ng)
+        for t in range(T):
+            obs, r, done, info = env2.step(np.zeros((B, 4), np.float32), contact_masks=dm[t])
+            np.testing.assert_array_equal(r.cpu().numpy().view(np.uint32), rew[t].cpu().numpy().view(np.uint32))
+        assert torch.equal(env.state_now, env2.state_now) and torch.equal(env.state_ever, env2.state_ever)
+        np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy()[:nb], ref['ag'][:, T])
+
+
+# ------------------------------------------------------------------ sharded success counter
+def test_success_count_is_exact_at_every_grid_size_and_over_repeated_launches():
+    """One returning atomic per block on a sharded counter, the last arrival of a shard forwards the sum and
+    clears the shard: the count must equal the popcount of the final success flags for every grid size
+    (fewer blocks than shards, non-multiples, thousands of blocks) and stay exact launch after launch."""
+    T = 5
+    for B in (64, 300, 4096, 65536, 70001, 262144, 1 << 20):
+        env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=B)
+        cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+        fl = bpg.time_major_empty(T, B, torch.uint8, DEV)
+        for it in range(3):
+            a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr(), ld_out=int(fl.stride(0)),
+                                     d_success_count=cnt.data_ptr() + 8 * (it % 2), d_zero_count=cnt.data_ptr() + 8 * ((it + 1) % 2))
+            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            torch.cuda.synchronize()
+            want = int((fl[T - 1] & 1).sum().item())
+            assert int(cnt[it % 2].item()) == want and int(cnt[(it + 1) % 2].item()) == 0, (B, it)
+            assert int(env.success_count().item()) == want
+        # the episode writer counts through the same shards
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make('BlocksTouchVariation-v0', num_envs=num_envs, device=DEV, seed=B),
+                               None, dims_of('BlocksTouchVariation-v0'), None, T, rollout_batch_size=min(B, 70001), output='torch')
+        ep = w.generate_rollouts_fused()
+        assert w.success_history[-1] == pytest.approx(float(ep['info_is_success'][:, -1, 0].double().mean().item()), abs=1e-12)

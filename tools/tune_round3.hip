@@ -1,0 +1,199 @@
+// Standalone tuning harness of round 3 (not part of the product): includes the library source and times
+//   A  the 2-envs-per-lane pipelined shape with an honest register budget: rows in flight per lane (UNROLL),
+//      against 1 env per lane, at the mid batch sizes;
+//   B  the success count at small batches: none / one atomic per block on one word / sharded (the library's);
+//   C  the policy-gradient path at 1 M envs: rollout + reward stream + return kernel (round 2) against rollout +
+//      step-ok words + expansion kernel;
+//   D  the return kernels on their own: round 2's two-lanes-per-env form, the lane-per-env exact form, the scan.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/tune_round3 tools/tune_round3.hip
+//   ./tools/tune_round3 A 131072 262144 | B 65536 | C 1048576 | D 1048576
+#include "../blockpuzzle-gym_amd/csrc/bpgym.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Bufs {
+    int64_t B, LD;
+    int T, NB;
+    uint32_t *now, *ever;
+    std::vector<uint32_t *> masks, reward;
+    std::vector<uint8_t *> flags;
+    std::vector<double *> G;
+    uint64_t *okbits;
+    unsigned long long *cnt, *shards;
+    uint32_t *d_counter;
+    hipEvent_t e0, e1;
+};
+
+static int setup(Bufs &b, int64_t B, int T, bool withG)
+{
+    b.B = B; b.T = T;
+    b.LD = bpg_row_stride(B) + (getenv("LDPAD") ? atoll(getenv("LDPAD")) : 0);
+    const size_t set_bytes = (size_t)b.LD * T * 9 + (withG ? (size_t)B * T * 8 : 0);
+    b.NB = (int)((size_t)640 * 1024 * 1024 / set_bytes) + 1;
+    if (b.NB < 3) b.NB = 3;
+    if (b.NB > 48) b.NB = 48;
+    CK(hipMalloc(&b.now, B * 4)); CK(hipMalloc(&b.ever, B * 4)); CK(hipMalloc(&b.okbits, B * 8));
+    b.masks.resize(b.NB); b.reward.resize(b.NB); b.flags.resize(b.NB); b.G.assign(b.NB, nullptr);
+    for (int k = 0; k < b.NB; k++) {
+        CK(hipMalloc(&b.masks[k], (size_t)b.LD * T * 4)); CK(hipMalloc(&b.reward[k], (size_t)b.LD * T * 4));
+        CK(hipMalloc(&b.flags[k], (size_t)b.LD * T));
+        if (withG) CK(hipMalloc(&b.G[k], (size_t)B * T * 8));
+    }
+    SynthConst s{}; s.seed = 1; s.env_base = 0;
+    for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; }
+    hipLaunchKernelGGL(k_init, dim3(2048), dim3(256), 0, 0, b.now, b.ever, B, 6u);
+    for (int k = 0; k < b.NB; k++) {
+        s.seed = 1 + k;
+        for (int t = 0; t < T; t++)
+            hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, b.ever, B, t, 1, b.masks[k] + (int64_t)t * b.LD, b.LD, s);
+    }
+    CK(hipMalloc(&b.d_counter, 8)); CK(hipMemset(b.d_counter, 0, 8));
+    CK(hipMalloc(&b.cnt, 16)); CK(hipMemset(b.cnt, 0, 16));
+    CK(hipMalloc(&b.shards, COUNT_SHARDS * COUNT_SHARD_STRIDE * 8)); CK(hipMemset(b.shards, 0, COUNT_SHARDS * COUNT_SHARD_STRIDE * 8));
+    CK(hipEventCreate(&b.e0)); CK(hipEventCreate(&b.e1));
+    CK(hipDeviceSynchronize());
+    return 0;
+}
+
+static void teardown(Bufs &b)
+{
+    (void)hipFree(b.now); (void)hipFree(b.ever); (void)hipFree(b.okbits);
+    for (int k = 0; k < b.NB; k++) { (void)hipFree(b.masks[k]); (void)hipFree(b.reward[k]); (void)hipFree(b.flags[k]); if (b.G[k]) (void)hipFree(b.G[k]); }
+    (void)hipFree(b.d_counter); (void)hipFree(b.cnt); (void)hipFree(b.shards);
+}
+
+static int rot = 0;
+#define REPS 40
+// per-launch time from an event pair around each launch (median) AND from a train of REPS launches
+#define TIME(name, bytes, launch)                                                                  \
+    do {                                                                                           \
+        std::vector<float> ts;                                                                     \
+        for (int r = 0; r < REPS + 3; r++) {                                                       \
+            rot++; CK(hipEventRecord(b.e0, 0)); launch; CK(hipEventRecord(b.e1, 0));               \
+            CK(hipEventSynchronize(b.e1));                                                         \
+            float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));                                    \
+            if (r >= 3) ts.push_back(ms);                                                          \
+        }                                                                                          \
+        std::sort(ts.begin(), ts.end());                                                           \
+        CK(hipEventRecord(b.e0, 0));                                                               \
+        for (int r = 0; r < REPS; r++) { rot++; launch; }                                          \
+        CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));                                \
+        float tot; CK(hipEventElapsedTime(&tot, b.e0, b.e1));                                      \
+        const double med = ts[ts.size() / 2], train = tot / REPS;                                  \
+        printf("%-58s %8.2f us (%4.1f%%)   train %8.2f us (%6.1f GB/s, %4.1f%% of 8 TB/s)\n", name, med * 1e3, \
+               (bytes) / med / 1e6 / 80.0, train * 1e3, (bytes) / train / 1e6, (bytes) / train / 1e6 / 80.0); \
+        fflush(stdout);                                                                            \
+    } while (0)
+#define M b.masks[rot % b.NB]
+#define R b.reward[rot % b.NB]
+#define F b.flags[rot % b.NB]
+#define GG b.G[rot % b.NB]
+
+static StepConst mk_c() { StepConst c{}; c.valid = 0x1FFFFF; c.want_touch = 1u << 12; c.want_never = 0; c.max_steps = 50; c.sticky_on = 1; return c; }
+static SynthConst mk_s() { SynthConst s{}; s.seed = 1; for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; } return s; }
+static ResetConst mk_rc(Bufs &b) { ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1; rc.reset_counter = b.d_counter; return rc; }
+static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k++) p.v[k] = std::pow(0.98, (double)k); return p; }
+
+// COUNT: 0 none, 1 one plain atomic per block, 2 sharded.  OKB: 1 = the launch also stores the step-ok words
+#define ROLL(EPL, BLOCK, UNR, PIPE, OUT, COUNT, CAPMUL, OKB, LBV)                                              \
+    do {                                                                                                       \
+        const int64_t lanes = B / EPL;                                                                         \
+        int64_t grid = (lanes + BLOCK - 1) / BLOCK;                                                            \
+        const int64_t cap = (int64_t)CAPMUL * 256 * (1024 / BLOCK);                                            \
+        if (cap && grid > cap) grid = cap;                                                                     \
+        CountArgs ca{COUNT ? b.cnt : nullptr, COUNT ? b.cnt + 1 : nullptr, COUNT == 2 ? b.shards : nullptr};   \
+        char nm[120];                                                                                          \
+        snprintf(nm, 120, "epl%d block%-4d grid%-5lld unr%-2d %s out%d %s %s", EPL, BLOCK, (long long)grid, UNR, \
+                 PIPE ? "pipe " : "plain", OUT, COUNT == 0 ? "nocount" : (COUNT == 1 ? "atomic " : "shards "),  \
+                 OKB ? "+okbits" : "");                                                                        \
+        const double bytes = (double)B * (T * (4 + ((OUT & 1) ? 4 : 0) + ((OUT & 2) ? 1 : 0)) + 12 + (OKB ? 8 : 0)); \
+        TIME(nm, bytes, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, OUT, true, UNR, PIPE, true, LBV, (OKB != 0)>), dim3((unsigned)grid), \
+                                    dim3(BLOCK), 0, 0, b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca,  \
+                                    OKB ? b.okbits : nullptr));                                                \
+    } while (0)
+
+static int run(char mode, int64_t B)
+{
+    const int T = 50;
+    Bufs b;
+    if (setup(b, B, T, mode == 'C' || mode == 'D')) return 1;
+    const StepConst c = mk_c(); const SynthConst s = mk_s(); const ResetConst rc = mk_rc(b); const PowTable pw = mk_pw(T);
+    printf("== mode %c  B = %lld envs, T = %d, LD = %lld, %d rotating buffer sets\n", mode, (long long)B, T, (long long)b.LD, b.NB);
+    if (mode == 'A') {
+        for (int rep = 0; rep < 2; rep++) {
+            ROLL(1, 256, 10, true, 3, 2, 1, 0, 256); ROLL(1, 256, 5, true, 3, 2, 1, 0, 256);
+            ROLL(2, 256, 5, false, 3, 2, 1, 0, 256); ROLL(2, 256, 5, false, 3, 2, 0, 0, 256);
+            ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); ROLL(2, 512, 5, false, 3, 2, 1, 0, 1024);
+            ROLL(2, 256, 10, true, 3, 2, 1, 0, 256);
+        }
+    } else if (mode == 'B') {
+        TIME("empty kernel (launch floor)", 1.0, hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, b.d_counter));
+        for (int rep = 0; rep < 2; rep++) {
+            ROLL(1, 256, 10, true, 3, 0, 1, 0, 256); ROLL(1, 256, 10, true, 3, 1, 1, 0, 256); ROLL(1, 256, 10, true, 3, 2, 1, 0, 256);
+            ROLL(1, 128, 10, true, 3, 0, 1, 0, 256); ROLL(1, 128, 10, true, 3, 1, 1, 0, 256); ROLL(1, 128, 10, true, 3, 2, 1, 0, 256);
+            ROLL(1, 64, 10, true, 3, 0, 1, 0, 256); ROLL(1, 64, 10, true, 3, 1, 1, 0, 256); ROLL(1, 64, 10, true, 3, 2, 1, 0, 256);
+            ROLL(1, 256, 5, true, 3, 2, 1, 0, 256); ROLL(1, 128, 5, true, 3, 2, 1, 0, 256);
+        }
+    } else if (mode == 'C') {
+        const double gbytes = (double)B * (8 + 8 * T), rbytes = (double)B * T * 12;
+        constexpr int WPB = DR_LANE_WPB;
+        const dim3 lg((unsigned)((B + 64 * WPB - 1) / (64 * WPB))), lb(64 * WPB);
+        const dim3 og((unsigned)((B + 32 * DR_WPB - 1) / (32 * DR_WPB))), ob(64 * DR_WPB);
+        for (int rep = 0; rep < 2; rep++) {
+            ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024);                       // round 2: reward + flags streams ...
+            TIME("  + k_discounted_return_reg<50> (round 2)", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_reg<50>), og, ob, 0, 0, (const float *)R, B, b.LD, pw, GG));
+            TIME("  + k_discounted_return_lane<50, exact>", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+            ROLL(2, 1024, 5, false, 2, 2, 1, 1, 1024);                       // flags + step-ok words ...
+            ROLL(2, 1024, 5, false, 0, 2, 1, 1, 1024);                       // (G alone: no per-step stream at all)
+            TIME("  + k_returns_from_okbits_lane<50>", gbytes,
+                 hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), lg, lb, 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+        }
+    } else if (mode == 'D') {
+        const double rbytes = (double)B * T * 12;
+        constexpr int WPB = DR_LANE_WPB;
+        const dim3 lg((unsigned)((B + 64 * WPB - 1) / (64 * WPB))), lb(64 * WPB);
+        const dim3 og((unsigned)((B + 32 * DR_WPB - 1) / (32 * DR_WPB))), ob(64 * DR_WPB);
+        // rewards of a real rollout in every buffer set
+        for (int k = 0; k < b.NB; k++) { rot = k; ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); }
+        for (int rep = 0; rep < 3; rep++) {
+            TIME("k_discounted_return_reg<50> (round 2, two lanes per env)", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_reg<50>), og, ob, 0, 0, (const float *)R, B, b.LD, pw, GG));
+            TIME("k_discounted_return_lane<50, exact> (plain rewards)", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+            TIME("k_discounted_return_lane<50, scan>", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+            TIME("k_discounted_return_lane<50, exact> (masks as floats: general path)", rbytes,
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG));
+            TIME("k_returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),
+                 hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), lg, lb, 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+#define WPBV(W)                                                                                                                    \
+            do {                                                                                                                   \
+                const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
+                TIME("  waves/block " #W ": lane<50, exact>", rbytes,                                                              \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG)); \
+                TIME("  waves/block " #W ": lane<50, scan>", rbytes,                                                               \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));  \
+                TIME("  waves/block " #W ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),                                 \
+                     hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
+            } while (0)
+            if (rep == 0) { WPBV(1); WPBV(2); WPBV(8); WPBV(16); }
+        }
+    }
+    teardown(b);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { printf("usage: tune_round3 A|B|C|D envs...\n"); return 1; }
+    for (int i = 2; i < argc; i++)
+        if (run(argv[1][0], atoll(argv[i]))) return 1;
+    return 0;
+}
