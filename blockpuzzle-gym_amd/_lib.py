@@ -94,6 +94,8 @@ SIGNATURES = {
     'bpg_compute_reward_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_int, C.c_void_p]),
     'bpg_compute_reward_f32_goal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'bpg_compute_reward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'bpg_compute_reward_f64_goal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_compute_reward_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_rollout': (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.c_void_p]),

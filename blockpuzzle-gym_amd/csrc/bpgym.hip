@@ -209,8 +209,7 @@ __device__ __forceinline__ uint32_t sticky_of(const StepConst &c, uint32_t ever)
 }
 
 struct SynthConst {
-    uint32_t seed;         // folded 64 -> 32 on the host
-    uint32_t env_base;     // global id of env 0 (low 32 bits)
+    uint64_t seed0;        // seed of env 0 of this handle: seed + 1000 * env_id_base (mod 2^64), see env_key()
     uint32_t valid_by_n[8];   // off-diagonal pairs among the first n objects
     uint32_t forced_by_n[8];  // table-block pairs (1,k), k = 2..n-1
 };
@@ -257,9 +256,15 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x)
     return x;
 }
 
-__device__ __forceinline__ uint32_t synth_key(uint32_t seed, uint32_t env_id)
+// Per-env key of every generator-drawn quantity.  The reference seeds env idx of a worker with
+// seed + 1000 * idx (RolloutStudent.seed, rollout.py:206-210) -- that arithmetic is reference-owned and is
+// mirrored here on the GLOBAL env index: env i of a batch seeded s draws exactly what env 0 of a batch seeded
+// s + 1000 i draws (what gym then does with the number -- a SHA-512 hash into MT19937 -- is third-party and
+// replaced by the counter-based generator below).  salt separates the streams (contacts, num_grey, placement).
+__device__ __forceinline__ uint32_t env_key(uint64_t seed0, uint32_t local_env, uint32_t salt)
 {
-    return hash32(seed ^ hash32(env_id + 0x9E3779B9U));
+    const uint64_t es = seed0 + 1000ull * local_env;
+    return hash32(((uint32_t)es ^ salt) ^ hash32((uint32_t)(es >> 32) + 0x9E3779B9U));
 }
 
 __device__ __forceinline__ uint32_t mulfold(uint32_t x, uint32_t k)
@@ -276,7 +281,7 @@ struct SynthLane {
 __device__ __forceinline__ SynthLane synth_lane(const SynthConst &s, uint32_t local_env, uint32_t nobj)
 {
     SynthLane l;
-    l.ka = synth_key(s.seed, s.env_base + local_env);
+    l.ka = env_key(s.seed0, local_env, 0u);
     l.kb = hash32(l.ka ^ 0x85EBCA6BU);
     // compare-select over the eight table rows (they sit in SGPRs): indexing the kernel-argument
     // array with a per-lane value would be a memory load that depends on the state load
@@ -381,7 +386,7 @@ struct ResetConst {
     int32_t enabled;        // apply the reset before step 0 (fused rollouts)
     int32_t is_variation;
     uint32_t base_nobj;
-    uint32_t seed, env_base;
+    uint64_t seed0;                  // as SynthConst
     const uint32_t *reset_counter;   // device word, read (uniformly) by every lane
     const int32_t *num_grey;   // explicit variates for np_random.randint(3) (:647) or NULL
 };
@@ -395,7 +400,7 @@ __device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_
             g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
         } else {
             // counter-based stand-in for np_random.randint(3)
-            g = hash32(synth_key(rc.seed ^ 0xA511E9B3U, rc.env_base + (uint32_t)i) + *rc.reset_counter) % 3u;
+            g = hash32(env_key(rc.seed0, (uint32_t)i, 0xA511E9B3U) + *rc.reset_counter) % 3u;
         }
         now = 0u;
         ever = (4u + g) << NOBJ_SHIFT;
@@ -851,16 +856,16 @@ __device__ __forceinline__ void wave_lds_sync()
 // wave-private LDS tile of 16 rows -- the tile is the output image itself, so every quarter of the wave's
 // rows streams out as one contiguous 16 * TT * 8-byte piece with 16-byte stores.
 constexpr int G_TILE_ROWS = 16;
-template <int TT>
+template <int TT, int TR = G_TILE_ROWS>
 __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], double *tile, double *__restrict__ G,
                                                    int64_t e0, int64_t n, int lane)
 {
     constexpr bool PAIRS = TT % 2 == 0;          // rows are whole 16-byte pieces: 16-byte LDS and global accesses
 #pragma unroll
-    for (int c = 0; c < 64 / G_TILE_ROWS; c++) {
+    for (int c = 0; c < 64 / TR; c++) {
         if (c) wave_lds_sync();                                          // previous quarter streamed out
-        if ((lane / G_TILE_ROWS) == c) {
-            double *row = tile + (lane % G_TILE_ROWS) * TT;
+        if ((lane / TR) == c) {
+            double *row = tile + (lane % TR) * TT;
             if constexpr (PAIRS) {
                 static_for<0, TT / 2>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
@@ -874,9 +879,9 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
             }
         }
         wave_lds_sync();
-        const int64_t first = e0 + c * G_TILE_ROWS;
+        const int64_t first = e0 + c * TR;
         const int64_t left = n - first;
-        const int rows = left >= G_TILE_ROWS ? G_TILE_ROWS : (left > 0 ? (int)left : 0);
+        const int rows = left >= TR ? TR : (left > 0 ? (int)left : 0);
         double *o = G + first * TT;
         if constexpr (PAIRS) {
             const double2 *t2 = reinterpret_cast<const double2 *>(tile);
@@ -947,7 +952,10 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         const Vec *mrow = reinterpret_cast<const Vec *>(masks) + v;
         Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + v;
         Fl *frow = reinterpret_cast<Fl *>(flags_tb) + v;
-        auto one_step = [&](int t, const uint32_t *mt) {
+        // ubit = 1 << (step within its batch of UNROLL): the step-ok bits of a batch collect in a 32-bit word with
+        // compile-time masks and join the 64-bit word once per batch (OKB)
+        uint32_t okpart[EPL] = {};
+        auto one_step = [&](int t, const uint32_t *mt, uint32_t ubit) {
             uint32_t rb[EPL], fl[EPL];
 #pragma unroll
             for (int k = 0; k < EPL; k++) {
@@ -958,7 +966,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 const uint32_t bad = (c.want_touch & ~cm[k]) | (c.want_never & ev[k]);    // < 2^21
                 const uint32_t okm = (uint32_t)((int32_t)(bad - 1u) >> 31);               // ~0 iff bad == 0
                 lat[k] |= okm;
-                if (OKB) okb[k] |= (uint64_t)(okm & 1u) << t;
+                if (OKB) okpart[k] |= okm & ubit;
                 el[k] = min(el[k] + 1u, ELAPSED_MAX);
                 const uint32_t dn = ((c.max_steps - 1u - el[k]) >> 30) & (uint32_t)BPG_FLAG_DONE;   // el >= max_steps
                 rb[k] = RBITS_FAIL ^ (okm & (RBITS_FAIL ^ RBITS_OK));
@@ -970,6 +978,20 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 #pragma unroll
                 for (int k = 1; k < EPL; k++) f |= fl[k] << (8 * k);
                 st_1<NT>(&frow[(int64_t)t * ldo], (Fl)f);
+            }
+            // The contacts-in-kernel form is arithmetic-co-limited and lives on occupancy.  Left alone, the
+            // scheduler interleaves the generators of all UNROLL steps (47 VGPRs in one build, 107-140 in the next,
+            // depending on which side of the SGPR limit a few unrelated kernel arguments push it); a scheduling
+            // fence per step keeps every step's ~70 instructions together: 50 VGPRs, 7-8 waves per SIMD.
+            if (SRC == SRC_SYNTH) __builtin_amdgcn_sched_barrier(0);
+        };
+        auto flush_ok = [&](int t0) {
+            if (OKB) {
+#pragma unroll
+                for (int k = 0; k < EPL; k++) {
+                    okb[k] |= (uint64_t)okpart[k] << t0;
+                    okpart[k] = 0u;
+                }
             }
         };
         // Steps run in batches of UNROLL.  The masks of batch b+1 are requested BEFORE the rewards /
@@ -994,8 +1016,9 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 for (int u = 0; u < UNROLL; u++) {
                     uint32_t mt[EPL];
                     unpack<EPL>(cur[u], mt);
-                    one_step(t0 + u, mt);
+                    one_step(t0 + u, mt, 1u << u);
                 }
+                flush_ok(t0);
             };
             // Two batches per trip with ping-pong register buffers (a register copy cur = nxt would
             // have to wait for the prefetch it copies), and the tail peeled so that every batch in
@@ -1023,15 +1046,17 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 for (int u = 0; u < UNROLL; u++) {
                     uint32_t mt[EPL] = {};
                     if (SRC == SRC_MASKS) unpack<EPL>(cur[u], mt);
-                    one_step(b * UNROLL + u, mt);
+                    one_step(b * UNROLL + u, mt, 1u << u);
                 }
+                flush_ok(b * UNROLL);
             }
         }
         for (int t = nb * UNROLL; t < T; t++) {          // T % UNROLL leftover steps
             uint32_t mt[EPL] = {};
             if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * ldm], mt);
-            one_step(t, mt);
+            one_step(t, mt, 1u << (t - nb * UNROLL));
         }
+        flush_ok(nb * UNROLL);
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
             an[k] = cm[k] | (el[k] << ELAPSED_SHIFT);
@@ -1439,7 +1464,7 @@ struct PlaceConst {
     double grip_x, grip_y, obj_range, max_obj_range, wrong_obj_range;
     const double *eu, *gz, *gu;
     int32_t n_eu, n_gz, n_gu;
-    uint32_t seed, env_base;
+    uint64_t seed0;
     const uint32_t *reset_counter;
     const uint8_t *env_mask;      // partial resets: only envs with a non-zero byte are placed
 };
@@ -1530,7 +1555,7 @@ k_randomize_objects(const uint32_t *__restrict__ ever, int64_t n, PlaceConst pc,
         d.n_eu = pc.n_eu; d.n_gz = pc.n_gz; d.n_gu = pc.n_gu;
         d.ie = d.iz = d.iu = d.fail = 0;
         d.has_spare = false; d.z_spare = 0.0;
-        d.key = hash32(synth_key(pc.seed ^ 0x51ED270BU, pc.env_base + (uint32_t)i) + *pc.reset_counter);
+        d.key = hash32(env_key(pc.seed0, (uint32_t)i, 0x51ED270BU) + *pc.reset_counter);
         double *o = xy + i * pc.nb_max * 2;
         const double gx = pc.grip_x, gy = pc.grip_y;
         double x, y;
@@ -1729,6 +1754,51 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 // ------------------------------ compute_reward ------------------------------
 // fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
 // staged through LDS with coalesced loads (row stride padded odd).
+// NumPy's float add-reduction over a contiguous axis is a PAIRWISE sum (numpy/_core/src/umath/loops_utils.h.src,
+// third-party; pinned by tests/golden/compute_reward_order.npz recorded from NumPy): below 8 elements a plain
+// loop; up to 128 elements eight strided accumulators combined as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) and the
+// n % 8 tail added one by one; above 128 the block is split at n/2 rounded down to a multiple of 8.  fetch_env.py:141
+// sums achieved_goal * goal that way, in the arrays' own precision, so for rows that are not ternary the ORDER
+// decides whether d == c.  Products and sums are rounded separately (FP_CONTRACT off).
+template <typename F>
+__device__ __forceinline__ F cr_block_dot(const F *ra, const F *rg, int n)          // n <= 128
+{
+    if (n < 8) {
+        F res = (F)0;
+        for (int i = 0; i < n; i++) res = res + ra[i] * rg[i];
+        return res;
+    }
+    F r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = ra[j] * rg[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = r[j] + ra[i + j] * rg[i + j];
+    }
+    F res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + ra[i] * rg[i];
+    return res;
+}
+
+template <typename F>
+__device__ __forceinline__ F cr_half_dot(const F *ra, const F *rg, int n)           // n <= 256: at most one more split
+{
+    if (n <= 128) return cr_block_dot(ra, rg, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return cr_block_dot(ra, rg, n2) + cr_block_dot(ra + n2, rg + n2, n - n2);
+}
+
+template <typename F>
+__device__ __forceinline__ F cr_row_dot(const F *ra, const F *rg, int n)            // n <= 256
+{
+    if (n <= 128) return cr_block_dot(ra, rg, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return cr_half_dot(ra, rg, n2) + cr_half_dot(ra + n2, rg + n2, n - n2);
+}
+
 constexpr int CR_ROWS_MAX = 128;
 // BCAST: one goal row for every row of ag (env.compute_reward(ag, env.goal), fetch_env.py:135-143 with
 // NumPy broadcasting): staged once per block, read by every lane at the same LDS address.
@@ -1791,12 +1861,9 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
     __syncthreads();
     if ((int)threadIdx.x < rows) {
         const float *ra = s_ag + threadIdx.x * ldp, *rg = BCAST ? s_g : s_g + threadIdx.x * ldp;
-        float d = 0.0f;
         int cnt = 0;
-        for (int k = 0; k < len; k++) {
-            d = d + ra[k] * rg[k];                         // FP_CONTRACT is off: separate mul / add
-            cnt += (rg[k] != 0.0f) ? 1 : 0;
-        }
+        for (int k = 0; k < len; k++) cnt += (rg[k] != 0.0f) ? 1 : 0;
+        const float d = cr_row_dot<float>(ra, rg, len);    // NumPy's float32 summation order
         out[row0 + threadIdx.x] = (d != (float)cnt) ? RBITS_FAIL : RBITS_OK;
     }
 }
@@ -1809,6 +1876,38 @@ k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__rest
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t bad = (want_touch & ~now[i]) | (want_never & ever[i]);
         out[i] = bad ? RBITS_FAIL : RBITS_OK;
+    }
+}
+
+// The same on float64 rows (env.step's own call: achieved_goal float64, goal int64 / float64 -> a float64 sum,
+// fetch_env.py:141-143).  64 rows per block staged through LDS with coalesced loads, one row per lane.
+template <bool BCAST>
+__global__ void __launch_bounds__(64)
+k_compute_reward_f64(const double *__restrict__ ag, const double *__restrict__ g, int64_t n, int len, int ldp,
+                     uint32_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_ag = reinterpret_cast<double *>(smem);
+    double *s_g = s_ag + 64 * ldp;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
+    const double *pa = ag + row0 * len, *pg = BCAST ? g : g + row0 * len;
+    if (BCAST) {
+        for (int k = threadIdx.x; k < len; k += 64) s_g[k] = pg[k];
+    }
+    const int total = rows * len;
+    for (int f = threadIdx.x; f < total; f += 64) {
+        const int r = f / len, k = f - r * len;
+        s_ag[r * ldp + k] = pa[f];
+        if (!BCAST) s_g[r * ldp + k] = pg[f];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+        const double *ra = s_ag + threadIdx.x * ldp, *rg = BCAST ? s_g : s_g + threadIdx.x * ldp;
+        int cnt = 0;
+        for (int k = 0; k < len; k++) cnt += (rg[k] != 0.0) ? 1 : 0;
+        const double d = cr_row_dot<double>(ra, rg, len);
+        out[row0 + threadIdx.x] = (d != (double)cnt) ? RBITS_FAIL : RBITS_OK;
     }
 }
 
@@ -2040,12 +2139,12 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int64_t ld, 
 enum { DRM_EXACT = 0, DRM_SCAN = 1 };
 constexpr int DR_LANE_WPB = 4;              // waves per block (each wave: 64 envs, a private 16-row LDS tile)
 
-template <int TT, int MODE, int WPB>
+template <int TT, int MODE, int WPB, int TR = G_TILE_ROWS>
 __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
                          double *__restrict__ G)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][G_TILE_ROWS * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
     if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
@@ -2151,17 +2250,17 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
             }
         }
     }
-    wave_store_returns<TT>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+    wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
 }
 
 // G rows from the step-ok words of a rollout launch (k_rollout<..., OKB>, k_episode): same arithmetic as above,
 // 8 bytes read and 8 T bytes written per env.
-template <int TT, int WPB>
+template <int TT, int WPB, int TR = G_TILE_ROWS>
 __global__ void __launch_bounds__(64 * WPB)
 k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
                            int64_t n)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][G_TILE_ROWS * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
     if (base >= n) return;
@@ -2169,7 +2268,7 @@ k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__re
     const uint64_t ok = okbits[e];
     double acc[TT];
     returns_from_okbits<TT>(ok, acc);
-    wave_store_returns<TT>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+    wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
 }
 
 // any T <= 64: the rows accumulate in an LDS tile, one env per lane
@@ -2349,8 +2448,7 @@ PowTable pow_table(double gamma, int T)
 SynthConst synth_const(const bpg_batch *b)
 {
     SynthConst s;
-    s.seed = (uint32_t)(b->seed ^ (b->seed >> 32));
-    s.env_base = (uint32_t)b->env_base;
+    s.seed0 = b->seed + 1000ull * (uint64_t)b->env_base;        // rollout.py:209-210 on the global env index
     for (int n = 0; n < 8; n++) {
         uint32_t valid = 0, forced = 0;
         const int m = n > BPG_MAX_OBJS ? BPG_MAX_OBJS : n;
@@ -2370,8 +2468,7 @@ ResetConst reset_const(const bpg_batch *b, int enabled, const int32_t *d_num_gre
     rc.enabled = enabled;
     rc.is_variation = b->info.is_variation;
     rc.base_nobj = (uint32_t)b->info.num_objs;
-    rc.seed = s.seed;
-    rc.env_base = s.env_base;
+    rc.seed0 = s.seed0;
     rc.reset_counter = b->d_reset_counter;
     rc.num_grey = d_num_grey;
     return rc;
@@ -2400,7 +2497,7 @@ int fat_grid(int64_t work_items)
 // "Shifted rows": the row stride bpg_row_stride() recommends (profiles/r02_tune_row_stride.log).
 // 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
 // 4-per-lane instantiation.  One success-count atomic per block (block_count_add).
-constexpr int64_t ROLLOUT_UNROLL5_FROM = 98304, ROLLOUT_EPL2_FROM = 196608;
+constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
 struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
@@ -2996,7 +3093,7 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
     pc.eu = explicit_draws ? a->d_eu : nullptr;
     pc.gz = a->d_gz; pc.gu = a->d_gu;
     pc.n_eu = a->n_eu; pc.n_gz = a->n_gz; pc.n_gu = a->n_gu;
-    pc.seed = s.seed; pc.env_base = s.env_base; pc.reset_counter = b->d_reset_counter + 1;
+    pc.seed0 = s.seed0; pc.reset_counter = b->d_reset_counter + 1;
     pc.env_mask = a->d_env_mask;
     hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        b->n, pc, d_xy, d_status);
@@ -3060,6 +3157,39 @@ static int compute_reward_f32(const float *d_ag, const float *d_g, bool bcast, i
     else if (bcast) hipLaunchKernelGGL((k_compute_reward_f32<false, true>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
     else hipLaunchKernelGGL((k_compute_reward_f32<false, false>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
     return check_launch("k_compute_reward_f32");
+}
+
+static int compute_reward_f64(const double *d_ag, const double *d_g, bool bcast, int64_t n, int len, float *d_out,
+                              int device_id, void *stream)
+{
+    if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
+    if (((uintptr_t)d_ag & 7u) || ((uintptr_t)d_g & 7u)) return fail(BPG_ERR_ARG, "float64 rows must be 8-byte aligned");
+    if (n == 0) return BPG_OK;
+    DeviceGuard guard(device_id);
+    const int ldp = len | 1;
+    const size_t lds = (size_t)2 * 64 * ldp * sizeof(double);          // two 64-row tiles: 160 KB of LDS hold rows of <= 159
+    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "float64 rows: len must be <= 159");
+    const void *fn = bcast ? reinterpret_cast<const void *>(k_compute_reward_f64<true>)
+                           : reinterpret_cast<const void *>(k_compute_reward_f64<false>);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    uint32_t *o = reinterpret_cast<uint32_t *>(d_out);
+    if (bcast) hipLaunchKernelGGL(k_compute_reward_f64<true>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp, o);
+    else hipLaunchKernelGGL(k_compute_reward_f64<false>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp, o);
+    return check_launch("k_compute_reward_f64");
+}
+
+int bpg_compute_reward_f64(const double *d_ag, const double *d_g, int64_t n, int len, float *d_out, int device_id,
+                           void *stream)
+{
+    return compute_reward_f64(d_ag, d_g, false, n, len, d_out, device_id, stream);
+}
+
+int bpg_compute_reward_f64_goal(const double *d_ag, const double *d_goal_row, int64_t n, int len, float *d_out,
+                                int device_id, void *stream)
+{
+    return compute_reward_f64(d_ag, d_goal_row, true, n, len, d_out, device_id, stream);
 }
 
 int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever, uint32_t want_touch,

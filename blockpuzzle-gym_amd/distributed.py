@@ -45,12 +45,24 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def make_sharded(env_id, total_envs, rank, world_size, device=None, seed=0, **kw):
-    """This rank's shard of a `total_envs`-env job.  The synthetic generator is
-    keyed by the GLOBAL env index (env_id_base), so results do not depend on
-    how the batch is sharded (mirrors seed + 1000*idx, rollout.py:209-210)."""
+def rank_seed(seed, rank):
+    """train.py:132-133: `rank_seed = seed + 1000000 * rank`."""
+    return int(seed) + 1000000 * int(rank)
+
+
+def make_sharded(env_id, total_envs, rank, world_size, device=None, seed=0, reference_launch=False, **kw):
+    """This rank's shard of a `total_envs`-env job.  Env i of the job is keyed by seed + 1000 * i with i
+    the GLOBAL env index (env_id_base = first index of the shard; the reference's
+    `env.seed(seed + 1000 * idx)`, rollout.py:209-210), so results do not depend on how the batch is
+    sharded.
+    reference_launch=True mirrors the reference's own launch instead (train.py:132-133 +
+    rollout.py:206-210): every rank seeds its worker with seed + 1000000 * rank and numbers its envs from 0,
+    i.e. env j of rank r is keyed by seed + 1000000 * r + 1000 * j -- as in the reference, that depends on the
+    number of ranks, and from 1000 envs per rank on the streams of neighbouring ranks overlap."""
     from .registration import make
     start, stop = shard_range(total_envs, rank, world_size)
+    if reference_launch:
+        return make(env_id, num_envs=stop - start, device=device, seed=rank_seed(seed, rank), env_id_base=0, **kw)
     return make(env_id, num_envs=stop - start, device=device, seed=seed, env_id_base=start, **kw)
 
 

@@ -361,7 +361,9 @@ class BatchedBlocksEnv:
 
     # ------------------------------------------------------------ gym API
     def seed(self, seed=None):
-        """robot_env.py:53-55 (returns [seed]); re-keys the counter-based generator."""
+        """robot_env.py:53-55 (returns [seed]); re-keys the counter-based generator.  Env i of the batch
+        (global index env_id_base + i) is keyed by seed + 1000 * i -- the per-env seeds RolloutStudent.seed
+        hands out (rollout.py:206-210): env i seeded s draws what env 0 seeded s + 1000 * i draws."""
         self._seed_value = 0 if seed is None else int(seed)
         _lib.check(self._L.bpg_seed(self._h, C.c_uint64(self._seed_value & (2**64 - 1))))
         self.action_space.seed(seed)
@@ -628,27 +630,33 @@ def mat2euler(mat, device=None):
 
 def compute_reward(achieved_goal, goal, device=None):
     """Stateless BlocksEnv.compute_reward on the GPU.  numpy in -> numpy float32 out,
-    torch in -> torch float32 out (on `device`)."""
+    torch in -> torch float32 out (on `device`).  The products and their sum are taken in the precision NumPy
+    would use for `achieved_goal * goal` (fetch_env.py:141): float64 unless both arrays are float32 (the
+    reference's own call passes a float64 matrix, robot_env.py:66; HER's replay arrays are float32), and in
+    NumPy's summation order -- for the ternary rows of the env any order is exact."""
     L = _lib.lib()
     np_in = not torch.is_tensor(achieved_goal)
     dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
-    ag = torch.as_tensor(np.asarray(achieved_goal) if np_in else achieved_goal).to(dev, torch.float32)
-    g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal).to(dev, torch.float32)
-    ag = ag.contiguous()
+    ag = torch.as_tensor(np.asarray(achieved_goal) if np_in else achieved_goal)
+    g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal)
+    wide = not (ag.dtype == torch.float32 and g.dtype == torch.float32) and ag.shape[-1] <= 159
+    ft = torch.float64 if wide else torch.float32
+    ag = ag.to(dev, ft).contiguous()
+    g = g.to(dev, ft)
     lead = ag.shape[:-1]
     n = int(np.prod(lead, dtype=np.int64)) if len(lead) else 1
     out = torch.empty(n, dtype=torch.float32, device=dev)
+    fn_row, fn_rows = (L.bpg_compute_reward_f64_goal, L.bpg_compute_reward_f64) if wide else \
+        (L.bpg_compute_reward_f32_goal, L.bpg_compute_reward_f32)
     # one goal row for every row (a 1-D goal, or leading axes that are all broadcast: size 1 / stride 0)
     # goes to the kernel as ONE row; anything else row by row
     one_row = g.shape[-1] == ag.shape[-1] and all(sz == 1 or st == 0 for sz, st in zip(g.shape[:-1], g.stride()[:-1]))
     if n and one_row:
         row = g.reshape(-1)[:ag.shape[-1]] if g.dim() == 1 else g[(0,) * (g.dim() - 1)]
         row = row.contiguous()
-        _lib.check(L.bpg_compute_reward_f32_goal(_ptr(ag), _ptr(row), n, int(ag.shape[-1]), _ptr(out),
-                                                 dev.index, _stream(dev)))
+        _lib.check(fn_row(_ptr(ag), _ptr(row), n, int(ag.shape[-1]), _ptr(out), dev.index, _stream(dev)))
     elif n:
         g = g.expand_as(ag).contiguous()
-        _lib.check(L.bpg_compute_reward_f32(_ptr(ag), _ptr(g), n, int(ag.shape[-1]), _ptr(out),
-                                            dev.index, _stream(dev)))
+        _lib.check(fn_rows(_ptr(ag), _ptr(g), n, int(ag.shape[-1]), _ptr(out), dev.index, _stream(dev)))
     out = out.reshape(lead)
     return out.cpu().numpy() if np_in else out

@@ -401,8 +401,8 @@ class RolloutStudent:
         return logs
 
     def seed(self, seed):
-        """rollout.py:206-210 seeds env idx with seed + 1000*idx; the batched
-        generator is keyed by (seed, global env index) instead."""
+        """rollout.py:206-210 seeds env idx with seed + 1000 * idx: the batched env keys env idx of the
+        batch by exactly that number (on the global env index), see BatchedBlocksEnv.seed."""
         for env in self.envs:
             env.seed(seed)
 

@@ -264,13 +264,23 @@ int bpg_state_ptrs(bpg_batch *b, uint32_t **d_now, uint32_t **d_ever);
  * checkpoint of the batch needs (the reference never checkpoints env state). */
 int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters);
 
-/* BlocksEnv.compute_reward (fetch_env.py:135-143), stateless and vectorised as
- * HER calls it (config.py:110-111): n rows of `len` floats each, len in 1..256. */
+/* BlocksEnv.compute_reward (fetch_env.py:135-143), stateless and vectorised as HER calls it
+ * (config.py:110-111): n rows of `len` floats each, len in 1..256; reward = -(sum(ag * g) != count_nonzero(g)).
+ * Every row the env or a replay buffer can hold is ternary ({-1, 0, 1}: any summation order is exact); for
+ * arbitrary rows the sum is taken in NumPy's order for that precision -- products rounded on their own, then the
+ * pairwise add-reduction (third-party NumPy; pinned by tests/golden/compute_reward_order.npz) -- so the result
+ * is NumPy's for float32 arrays (_f32) and for float64 arrays (_f64, len <= 159), not that of a mixed call. */
 int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len,
                            float *d_out, int device_id, void *stream);
 /* Same against ONE goal row of `len` floats shared by every row of d_ag -- env.compute_reward(ag,
  * env.goal) with NumPy broadcasting (fetch_env.py:135-143; the goal is constant per variant, :260-273). */
 int bpg_compute_reward_f32_goal(const float *d_ag, const float *d_goal_row, int64_t n, int len,
+                                float *d_out, int device_id, void *stream);
+/* float64 rows: what env.step itself passes (achieved_goal float64, goal int64 or float64 -> float64 products
+ * and sum, fetch_env.py:141-143 / robot_env.py:66). */
+int bpg_compute_reward_f64(const double *d_ag, const double *d_g, int64_t n, int len,
+                           float *d_out, int device_id, void *stream);
+int bpg_compute_reward_f64_goal(const double *d_ag, const double *d_goal_row, int64_t n, int len,
                                 float *d_out, int device_id, void *stream);
 /* Same on packed states against packed goal planes. */
 int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,

@@ -181,17 +181,68 @@ int orc_check_goal(const orc_env *e)
     return 1;
 }
 
-/* fetch_env.py:141-143: d = sum(ag*g); c = count_nonzero(g);
- * -(d != c).astype(float32): -1.0f on mismatch, -0.0f on match (quirk Q2). */
+/* np.sum over the last axis of a float array = NumPy's pairwise add-reduction (third-party NumPy,
+ * numpy/_core/src/umath/loops_utils.h.src, restated; tests/test_oracle_golden.py checks this restatement against
+ * NumPy itself and against tests/golden/compute_reward_order.npz): below 8 elements a plain loop; up to 128
+ * elements eight strided partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the n % 8 tail; above
+ * that a split at n/2 rounded down to a multiple of 8.  The order only matters for rows that are not ternary. */
+static double orc_pairwise_f64(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        int i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return orc_pairwise_f64(a, n2) + orc_pairwise_f64(a + n2, n - n2);
+}
+
+static float orc_pairwise_f32(const float *a, int n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        int i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return orc_pairwise_f32(a, n2) + orc_pairwise_f32(a + n2, n - n2);
+}
+
+/* fetch_env.py:141-143: d = np.sum(ag * g, axis=-1); c = np.count_nonzero(g, axis=-1);
+ * -(d != c).astype(float32): -1.0f on mismatch, -0.0f on match (quirk Q2).  float64 arrays. */
 float orc_compute_reward(const double *ag, const double *g, int len)
 {
-    double d = 0.0;
+    double prod[1024];
     long long c = 0;
+    if (len > 1024) len = 1024;
     for (int k = 0; k < len; k++) {
-        d += ag[k] * g[k];
+        prod[k] = ag[k] * g[k];
         if (g[k] != 0.0)
             c++;
     }
+    const double d = orc_pairwise_f64(prod, len);
     float ne = (d != (double)c) ? 1.0f : 0.0f;
     return -ne;
 }
@@ -200,6 +251,36 @@ void orc_compute_reward_batch(const double *ag, const double *g, int n, int len,
 {
     for (int r = 0; r < n; r++)
         out[r] = orc_compute_reward(ag + (size_t)r * len, g + (size_t)r * len, len);
+}
+
+/* the same on float32 arrays (HER's replay buffers, config.py:110-111): float32 products, float32 pairwise sum;
+ * d (float32) != c (int64) compares in float64 */
+void orc_compute_reward_f32_batch(const float *ag, const float *g, int n, int len, float *out, float *dsum)
+{
+    float prod[1024];
+    if (len > 1024) len = 1024;
+    for (int r = 0; r < n; r++) {
+        long long c = 0;
+        for (int k = 0; k < len; k++) {
+            prod[k] = ag[(size_t)r * len + k] * g[(size_t)r * len + k];
+            if (g[(size_t)r * len + k] != 0.0f)
+                c++;
+        }
+        const float d = orc_pairwise_f32(prod, len);
+        if (dsum) dsum[r] = d;
+        out[r] = -(((double)d != (double)c) ? 1.0f : 0.0f);
+    }
+}
+
+/* the sums themselves (for pinning the order against NumPy) */
+void orc_rowsum_f64(const double *a, int n, int len, double *out)
+{
+    for (int r = 0; r < n; r++) out[r] = orc_pairwise_f64(a + (size_t)r * len, len);
+}
+
+void orc_rowsum_f32(const float *a, int n, int len, float *out)
+{
+    for (int r = 0; r < n; r++) out[r] = orc_pairwise_f32(a + (size_t)r * len, len);
 }
 
 /* fetch_env.py:220 / Variation :610-613 (padding to 36 is empty: side is 6) */
@@ -455,18 +536,35 @@ static uint32_t orc_mulfold(uint32_t x, uint32_t k)
 
 static uint32_t orc_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
+/* Per-env key of the build-defined generator.  The reference seeds env idx with seed + 1000 * idx
+ * (RolloutStudent.seed, gym_blocks/rollout.py:206-210): that arithmetic is mirrored on the global env index
+ * (64-bit, wrapping); gym's seeding behind it (SHA-512 into MT19937) is third-party and replaced by
+ *   key(es, salt) = h((lo32(es) ^ salt) ^ h(hi32(es) + 0x9E3779B9)),   es = seed + 1000 * env   (h = lowbias32) */
+uint32_t orc_env_key(uint64_t seed, uint64_t env_id, uint32_t salt)
+{
+    const uint64_t es = seed + 1000ull * env_id;
+    return orc_hash32(((uint32_t)es ^ salt) ^ orc_hash32((uint32_t)(es >> 32) + 0x9E3779B9U));
+}
+
+/* np_random.randint(3) stand-in of the Variation reset (fetch_env.py:647): generator-drawn reset number
+ * `counter` of the handle */
+int orc_num_grey_draw(uint64_t seed, uint64_t env_id, uint32_t counter)
+{
+    return (int)(orc_hash32(orc_env_key(seed, env_id, 0xA511E9B3U) + counter) % 3u);
+}
+
 /* The spec of the source, stated here independently of the kernels:
- *   ka = h(seed ^ h(env + 0x9E3779B9)),  kb = h(ka ^ 0x85EBCA6B)            (h = lowbias32)
+ *   ka = key(seed + 1000 * env, 0),  kb = h(ka ^ 0x85EBCA6B)
  *   u  = ka + (t + 1) * 0x9E3779B9
  *   a  = fold((u      ^ (u      >> 15)) * 0xD6E8FEB9)     fold(p) = hi32(p) ^ lo32(p) of the
  *   b  = fold(((u^kb) ^ ((u^kb) >> 15)) * 0xCA5A8263)     64-bit product
  *   pair j touches iff U_j < 5 for the bit-sliced 5-bit uniform U_j whose "digit is zero" bits are
  *   A_j = a[j], B_j = b[j], C_j = (a >> 21 | (b >> 21) << 11)[j], D_j = rotl(a,7)[j] & rotl(b,13)[j]:
  *   A & B & (C | D)  ->  exactly 5/32 per pair.                                              */
-uint32_t orc_synth_mask(uint32_t seed, uint32_t env_id, uint32_t t, int num_objs)
+uint32_t orc_synth_mask(uint64_t seed, uint64_t env_id, uint32_t t, int num_objs)
 {
     const uint32_t M21 = (1u << 21) - 1;
-    uint32_t ka = orc_hash32(seed ^ orc_hash32(env_id + 0x9E3779B9U));
+    uint32_t ka = orc_env_key(seed, env_id, 0u);
     uint32_t kb = orc_hash32(ka ^ 0x85EBCA6BU);
     uint32_t u = ka + (t + 1u) * 0x9E3779B9U;
     uint32_t x = u ^ (u >> 15);
@@ -525,7 +623,7 @@ double orc_generate_rollouts(orc_env *envs, int B, int T, const uint32_t *masks,
     return succ_sum / B;
 }
 
-uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed)
+uint64_t orc_bench_rollout(int variant, int B, int T, uint64_t seed)
 {
     uint64_t sum = 0;
     orc_env e;
@@ -534,7 +632,7 @@ uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed)
         orc_env_reset(&e, 2);
         for (int t = 0; t < T; t++) {
             float r; int done, succ;
-            uint32_t m = orc_synth_mask(seed, (uint32_t)b, (uint32_t)t, e.num_objs);
+            uint32_t m = orc_synth_mask(seed, (uint64_t)b, (uint32_t)t, e.num_objs);
             orc_env_step_mask(&e, m, &r, &done, &succ);
             sum += (uint64_t)(r == 0) + 2u * (uint64_t)succ + 4u * (uint64_t)done;
         }
@@ -542,11 +640,11 @@ uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed)
     return sum;
 }
 
-void orc_fill_masks(uint32_t seed, uint32_t env_base, int B, int T, int num_objs, uint32_t *masks)
+void orc_fill_masks(uint64_t seed, uint64_t env_base, int B, int T, int num_objs, uint32_t *masks)
 {
     for (int t = 0; t < T; t++)
         for (int b = 0; b < B; b++)
-            masks[(size_t)t * B + b] = orc_synth_mask(seed, env_base + (uint32_t)b, (uint32_t)t, num_objs);
+            masks[(size_t)t * B + b] = orc_synth_mask(seed, env_base + (uint64_t)b, (uint32_t)t, num_objs);
 }
 
 uint64_t orc_bench_rollout_masks(int variant, int B, int T, int num_grey, const uint32_t *masks,

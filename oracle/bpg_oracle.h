@@ -91,6 +91,11 @@ int orc_check_goal(const orc_env *e);
 float orc_compute_reward(const double *ag, const double *g, int len);
 /* vectorised over n rows of `len` (config.py:110-111 call shape). */
 void orc_compute_reward_batch(const double *ag, const double *g, int n, int len, float *out);
+/* float32 arrays: float32 products and NumPy's float32 pairwise sum; dsum (optional) receives the sums */
+void orc_compute_reward_f32_batch(const float *ag, const float *g, int n, int len, float *out, float *dsum);
+/* NumPy-order row sums (np.sum(a, axis=-1)) */
+void orc_rowsum_f64(const double *a, int n, int len, double *out);
+void orc_rowsum_f32(const float *a, int n, int len, float *out);
 
 /* fetch_env.py:275-281: recompute from own state, latch. */
 int orc_is_success(orc_env *e);
@@ -156,8 +161,11 @@ int orc_randomize_objects(const orc_env *e, const orc_placement *p, double *xy, 
  * Stand-in for the physics in throughput runs.  Counter-based:
  * a pure function of (seed, env_id, t).  Table-block pairs (1,k) forced on,
  * every other pair of the variant's objects Bernoulli(5/32).               */
-uint32_t orc_synth_mask(uint32_t seed, uint32_t env_id, uint32_t t, int num_objs);
+uint32_t orc_synth_mask(uint64_t seed, uint64_t env_id, uint32_t t, int num_objs);
 uint32_t orc_hash32(uint32_t x);
+/* per-env generator key: the reference's seed + 1000 * idx (rollout.py:206-210) on the global env index */
+uint32_t orc_env_key(uint64_t seed, uint64_t env_id, uint32_t salt);
+int orc_num_grey_draw(uint64_t seed, uint64_t env_id, uint32_t counter);
 
 /* rollout.py:75-172 for B envs and T steps with mask contacts (time-major
  * masks[t*B+b]).  Outputs float32 episode arrays in batch-major layout:
@@ -170,11 +178,11 @@ double orc_generate_rollouts(orc_env *envs, int B, int T, const uint32_t *masks,
 
 /* cpu_baseline leg: B envs x T steps of the matrix-form step on synthetic
  * masks, no episode buffers.  Returns a checksum so the work is not elided. */
-uint64_t orc_bench_rollout(int variant, int B, int T, uint32_t seed);
+uint64_t orc_bench_rollout(int variant, int B, int T, uint64_t seed);
 /* Same workload as the GPU headline: the (T, B) masks are generated beforehand
  * (orc_fill_masks, untimed) and READ from memory by the timed loop, which also
  * writes the per-step reward (float32) and flags byte like the kernel does. */
-void orc_fill_masks(uint32_t seed, uint32_t env_base, int B, int T, int num_objs, uint32_t *masks);
+void orc_fill_masks(uint64_t seed, uint64_t env_base, int B, int T, int num_objs, uint32_t *masks);
 uint64_t orc_bench_rollout_masks(int variant, int B, int T, int num_grey, const uint32_t *masks,
                                  float *reward_tb, uint8_t *flags_tb);
 

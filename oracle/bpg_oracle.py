@@ -75,6 +75,9 @@ def lib():
         L.orc_compute_reward.argtypes = [P(C.c_double), P(C.c_double), C.c_int]
         L.orc_compute_reward.restype = C.c_float
         L.orc_compute_reward_batch.argtypes = [P(C.c_double), P(C.c_double), C.c_int, C.c_int, P(C.c_float)]
+        L.orc_compute_reward_f32_batch.argtypes = [P(C.c_float), P(C.c_float), C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
+        L.orc_rowsum_f64.argtypes = [P(C.c_double), C.c_int, C.c_int, P(C.c_double)]
+        L.orc_rowsum_f32.argtypes = [P(C.c_float), C.c_int, C.c_int, P(C.c_float)]
         L.orc_is_success.argtypes = [P(Env)]
         L.orc_env_step.argtypes = [P(Env), P(C.c_int), P(C.c_int), C.c_int,
                                    P(C.c_float), P(C.c_int), P(C.c_int)]
@@ -88,16 +91,20 @@ def lib():
         L.orc_contacts_to_mask.restype = C.c_uint32
         L.orc_discounted_return.argtypes = [P(C.c_double), C.c_int, C.c_double, P(C.c_double)]
         L.orc_out_of_table.argtypes = [C.c_double, C.c_double]
-        L.orc_synth_mask.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_synth_mask.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
         L.orc_synth_mask.restype = C.c_uint32
         L.orc_hash32.argtypes = [C.c_uint32]
         L.orc_hash32.restype = C.c_uint32
         L.orc_generate_rollouts.argtypes = [P(Env), C.c_int, C.c_int, P(C.c_uint32), P(C.c_int),
                                             P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]
         L.orc_generate_rollouts.restype = C.c_double
-        L.orc_bench_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_env_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.orc_env_key.restype = C.c_uint32
+        L.orc_num_grey_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.orc_num_grey_draw.restype = C.c_int
+        L.orc_bench_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.orc_bench_rollout.restype = C.c_uint64
-        L.orc_fill_masks.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, P(C.c_uint32)]
+        L.orc_fill_masks.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, P(C.c_uint32)]
         L.orc_bench_rollout_masks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_uint32), P(C.c_float),
                                               P(C.c_uint8)]
         L.orc_bench_rollout_masks.restype = C.c_uint64
@@ -186,6 +193,28 @@ def compute_reward(ag, g):
     return out
 
 
+def compute_reward_f32(ag, g):
+    """float32 arrays: float32 products, NumPy's float32 summation order."""
+    ag = np.ascontiguousarray(ag, np.float32)
+    g = np.ascontiguousarray(np.broadcast_to(g, ag.shape), np.float32)
+    out = np.zeros(ag.shape[:-1], np.float32)
+    lib().orc_compute_reward_f32_batch(_p(ag, C.c_float), _p(g, C.c_float), int(np.prod(ag.shape[:-1], dtype=np.int64)),
+                                       ag.shape[-1], _p(out, C.c_float), None)
+    return out
+
+
+def rowsum(a):
+    """np.sum(a, axis=-1) as the oracle restates NumPy's pairwise order (float32 or float64 rows)."""
+    a = np.ascontiguousarray(a)
+    out = np.zeros(a.shape[:-1], a.dtype)
+    n = int(np.prod(a.shape[:-1], dtype=np.int64))
+    if a.dtype == np.float32:
+        lib().orc_rowsum_f32(_p(a, C.c_float), n, a.shape[-1], _p(out, C.c_float))
+    else:
+        lib().orc_rowsum_f64(_p(a, C.c_double), n, a.shape[-1], _p(out, C.c_double))
+    return out
+
+
 def contacts_to_mask(id2obj, contacts):
     id2obj = np.ascontiguousarray(id2obj, np.int32)
     con = np.ascontiguousarray(contacts, np.int32).reshape(-1, 2)
@@ -195,12 +224,12 @@ def contacts_to_mask(id2obj, contacts):
 def synth_masks(seed, env_ids, T, num_objs):
     """(T, B) uint32 masks of the build-defined synthetic contact source."""
     L = lib()
-    env_ids = np.asarray(env_ids, np.uint32)
+    env_ids = np.asarray(env_ids, np.uint64)
     num_objs = np.broadcast_to(np.asarray(num_objs, np.int32), env_ids.shape)
     out = np.zeros((T, len(env_ids)), np.uint32)
     for t in range(T):
         for b, (eid, n) in enumerate(zip(env_ids, num_objs)):
-            out[t, b] = L.orc_synth_mask(seed, int(eid), t, int(n))
+            out[t, b] = L.orc_synth_mask(int(seed) & (2**64 - 1), int(eid), t, int(n))
     return out
 
 

@@ -330,6 +330,57 @@ def compute_reward_cases(rng):
     return out
 
 
+def compute_reward_order_cases():
+    """The reference's compute_reward (fetch_env.py:135-143) on rows that are NOT ternary, float32 and
+    float64: np.sum's pairwise order then decides whether d == c.  Every row's exact sum equals
+    count_nonzero(g); large cancelling products at random positions make a sequential sum, NumPy's pairwise
+    sum and the exact sum disagree on a good share of the rows.  (The env and HER only ever produce ternary
+    rows, for which any order is exact; this fixture pins the order for everything else.)"""
+    rng = np.random.RandomState(314159)
+    env = H.make('BlocksTouchVariation-v0')
+    env.reset()
+    out = {}
+    for dt, big_exp in ((np.float32, (24, 28)), (np.float64, (53, 57))):
+        for L in (7, 16, 36, 100, 129, 159):
+            n = 150
+            g = rng.choice(np.array([0, 0, 1, -1, 2, -2, 0.5, -0.5]), size=(n, L))
+            prod = np.zeros((n, L))
+            for r in range(n):
+                nz = np.flatnonzero(g[r])
+                c = len(nz)
+                if c < 4:
+                    g[r, :4] = [1, -1, 2, 0.5]
+                    nz = np.flatnonzero(g[r])
+                    c = len(nz)
+                k = int(rng.randint(1, max(2, min(4, c // 2))))            # cancelling pairs
+                pos = rng.permutation(nz)
+                for j in range(k):
+                    b = float(2.0 ** rng.randint(*big_exp)) * rng.choice([1.0, 3.0])
+                    prod[r, pos[2 * j]], prod[r, pos[2 * j + 1]] = b, -b
+                rest = pos[2 * k:]
+                if len(rest):
+                    # small exact values that add up to c (multiples of 1/4)
+                    v = rng.randint(-8, 9, size=len(rest)) / 4.0
+                    v[-1] += c - v.sum()
+                    prod[r, rest] = v
+                else:
+                    prod[r, pos[0]] += c
+            ag = np.where(g != 0, prod / np.where(g != 0, g, 1.0), rng.normal(size=(n, L)))
+            ag, gg = ag.astype(dt), g.astype(dt)
+            assert np.array_equal((ag.astype(np.float64) * gg.astype(np.float64))[g != 0], prod[g != 0])   # exact products
+            key = '%s_%d' % (np.dtype(dt).name, L)
+            out[key + '_ag'], out[key + '_g'] = ag, gg
+            r = env.compute_reward(ag, gg, None)
+            assert r.dtype == np.float32
+            out[key + '_rbits'] = f32bits(r)
+            seq = np.zeros(n, dt)
+            for kk in range(L):
+                seq = (seq + ag[:, kk] * gg[:, kk]).astype(dt)
+            c_all = np.count_nonzero(gg, axis=-1)
+            out[key + '_differs_from_sequential'] = np.array(int(((seq != c_all) != (r != 0)).sum()))
+    return out
+
+
 class RandomPolicy:
     """Seeded random-action policy with the call signature rollout.py:92-97 uses."""
 
@@ -456,6 +507,7 @@ def main(HERE=HERE):
         np.savez_compressed(os.path.join(HERE, 'trace_%s.npz' % eid.split('-')[0]), **tr)
 
     np.savez_compressed(os.path.join(HERE, 'compute_reward.npz'), **compute_reward_cases(rng))
+    np.savez_compressed(os.path.join(HERE, 'compute_reward_order.npz'), **compute_reward_order_cases())
     for k, eid in enumerate(ENV_IDS):
         np.savez_compressed(os.path.join(HERE, 'obs_%s.npz' % eid.split('-')[0]), **obs_trace(eid, 300 + k))
     for k, eid in enumerate(ENV_IDS):

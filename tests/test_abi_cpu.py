@@ -134,3 +134,39 @@ def test_row_stride_helper_is_a_pure_host_function():
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
     assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16 + 16
+
+
+def test_every_kernel_stub_has_a_device_kernel_of_the_same_name():
+    """hipcc mangles a kernel's name twice (host stub, device symbol).  A type without linkage in the signature
+    (an unnamed enum in a template argument, say) is numbered differently by the two passes and the launch dies
+    at run time with "Cannot find Symbol" -- only on the GPU box.  Check the built library here."""
+    data = open(_lib.LIB_PATH, 'rb').read()
+    stubs = set(re.findall(rb'_ZN4bpgk\d+__device_stub__([A-Za-z0-9_$.]+)', data))
+    assert len(stubs) > 100
+    missing = []
+    for name in stubs:
+        # the device symbol is _ZN4bpgk<len><name...>: same text after the length-prefixed function name
+        m = re.match(rb'(k_[a-z0-9_]+?)(I.*|E.*)$', name)
+        base, rest = m.group(1), m.group(2)
+        dev = b'_ZN4bpgk' + str(len(base)).encode() + base + rest
+        if dev not in data:
+            missing.append(name[:120])
+    assert not missing, missing[:3]
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Register spills to scratch are silent performance bugs (round 2 shipped seven k_rollout instantiations
+    with 36-328 bytes per lane because their launch bound promised 1024-lane blocks they were never launched
+    with).  Compile the device code with -Rpass-analysis=kernel-resource-usage and require ScratchSize == 0."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kernel_resources', os.path.join(ROOT, 'tools', 'kernel_resources.py'))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = kr.resources()
+    assert len(rows) > 100
+    bad = [(r['name'], r['scratch']) for r in rows if r['scratch']]
+    assert not bad, bad[:5]
+    # the fused rollout is never launched with more lanes than its launch bound, and holds its registers
+    for r in rows:
+        if 'k_rollout<' in r['name']:
+            assert r['vgpr'] <= 128, r

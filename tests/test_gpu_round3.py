@@ -304,3 +304,88 @@ def test_success_count_is_exact_at_every_grid_size_and_over_repeated_launches():
                                None, dims_of('BlocksTouchVariation-v0'), None, T, rollout_batch_size=min(B, 70001), output='torch')
         ep = w.generate_rollouts_fused()
         assert w.success_history[-1] == pytest.approx(float(ep['info_is_success'][:, -1, 0].double().mean().item()), abs=1e-12)
+
+
+# ------------------------------------------------------------------ reference-owned seed arithmetic
+def _draws(env, steps=4):
+    env.reset()
+    ng = (env.num_objs_per_env() - 4).cpu().numpy()
+    m = torch.empty((steps, env.num_envs), dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks(env._h, 0, steps, P(m), None))
+    xy, _ = env.randomize_objects()
+    return ng, m.cpu().numpy().view(np.uint32), xy.nan_to_num().cpu().numpy()
+
+
+def test_env_i_seeded_s_draws_what_env_0_seeded_s_plus_1000_i_draws():
+    """RolloutStudent.seed (rollout.py:206-210): `env.seed(seed + 1000 * idx)`.  The arithmetic is the
+    reference's own and is mirrored on the global env index: env i of a batch seeded s draws exactly what env 0
+    of a batch seeded s + 1000 i draws (num_grey, synthetic contacts, cube placement), also across shards
+    (env_id_base), across the 64-bit wrap, and as the oracle states the key.  What gym does with the number
+    (SHA-512 -> MT19937) is third-party: the draws themselves are the build-defined generator's."""
+    env_id, B, s = 'BlocksTouchVariation-v0', 300, 123456789
+    ng, m, xy = _draws(bpg.make(env_id, num_envs=B, device=DEV, seed=s))
+    for i in (0, 1, 7, 64, 299):
+        one = _draws(bpg.make(env_id, num_envs=1, device=DEV, seed=s + 1000 * i))
+        assert one[0][0] == ng[i]
+        np.testing.assert_array_equal(one[1][:, 0], m[:, i])
+        np.testing.assert_array_equal(one[2][0].view(np.uint64), xy[i].view(np.uint64))
+    # a shard that starts at global index 100 == the same envs of the whole batch
+    part = _draws(bpg.make(env_id, num_envs=50, device=DEV, seed=s, env_id_base=100))
+    np.testing.assert_array_equal(part[0], ng[100:150])
+    np.testing.assert_array_equal(part[1], m[:, 100:150])
+    np.testing.assert_array_equal(part[2].view(np.uint64), xy[100:150].view(np.uint64))
+    # 64-bit wrap of seed + 1000 * i
+    top = 2 ** 64 - 2500
+    w = _draws(bpg.make(env_id, num_envs=8, device=DEV, seed=top))
+    w5 = _draws(bpg.make(env_id, num_envs=1, device=DEV, seed=(top + 5000) % 2 ** 64))
+    assert w5[0][0] == w[0][5] and (w5[1][:, 0] == w[1][:, 5]).all()
+    # the oracle's statement of the same key (oracle/bpg_oracle.c: orc_env_key)
+    OL = O.lib()
+    assert [OL.orc_num_grey_draw(s, i, 0) for i in range(B)] == list(ng)
+    np.testing.assert_array_equal(m, O.synth_masks(s, np.arange(B), 4, 4 + ng))
+    # reference_launch: rank r seeds its worker with seed + 10^6 r (train.py:132-133) and numbers its envs from 0
+    from blockpuzzle_gym_amd import distributed as D
+    assert D.rank_seed(7, 3) == 3000007
+    r1 = _draws(D.make_sharded(env_id, 40, 1, 2, device=DEV, seed=s, reference_launch=True))
+    e = _draws(bpg.make(env_id, num_envs=1, device=DEV, seed=s + 1000000 + 1000 * 13))
+    assert e[0][0] == r1[0][13] and (e[1][:, 0] == r1[1][:, 13]).all()
+
+
+# ------------------------------------------------------------------ compute_reward on rows that are not ternary
+def test_compute_reward_follows_numpys_summation_order_in_both_precisions():
+    """tests/golden/compute_reward_order.npz: the reference's compute_reward on float32 and float64 rows whose exact
+    sum equals count_nonzero(g) but where the ORDER of the float additions decides d == c.  The float32 and float64
+    entry points must reproduce NumPy's outcome row by row (a sequential sum gets ~100 of these rows wrong), for the
+    row-by-row and the broadcast-goal forms, through the C-ABI and through the Python surface."""
+    d = np.load(os.path.join(GOLDEN, 'compute_reward_order.npz'))
+    for key in sorted(k[:-3] for k in d.files if k.endswith('_ag')):
+        ag, g, want = d[key + '_ag'], d[key + '_g'], d[key + '_rbits']
+        got = bpg.compute_reward(ag, g)
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got.view(np.uint32), want, err_msg=key)
+        tg = bpg.compute_reward(torch.as_tensor(ag, device=DEV), torch.as_tensor(g, device=DEV))
+        np.testing.assert_array_equal(tg.cpu().numpy().view(np.uint32), want, err_msg=key)
+        # one goal row broadcast over many ag rows: compare with NumPy live (numpy is on the box; the order is
+        # pinned by the fixture above)
+        rows = np.repeat(ag[:5], 30, axis=0)
+        rows[::3] *= ag.dtype.type(0.5)
+        for r in range(3):
+            ref = -(np.sum(rows * g[r], axis=-1) != np.count_nonzero(g[r])).astype(np.float32)
+            np.testing.assert_array_equal(bpg.compute_reward(rows, g[r]).view(np.uint32), ref.view(np.uint32))
+    # mixed precision follows NumPy's promotion: float32 * float64 (or * int64) is a float64 sum
+    ag32, g64 = d['float32_36_ag'], d['float32_36_g'].astype(np.float64)
+    ref = -(np.sum(ag32 * g64, axis=-1) != np.count_nonzero(g64, axis=-1)).astype(np.float32)
+    np.testing.assert_array_equal(bpg.compute_reward(ag32, g64).view(np.uint32), ref.view(np.uint32))
+    # the ternary rows of the env: both precisions agree with the oracle
+    rng = np.random.RandomState(0)
+    ag = rng.randint(-1, 2, size=(1000, 36)).astype(np.float64)
+    g = rng.randint(-1, 2, size=(1000, 36)) * (rng.rand(1000, 36) < 0.2)
+    ag[::2] = np.where(g[::2] != 0, g[::2], ag[::2])
+    want = O.compute_reward(ag, g.astype(np.float64)).view(np.uint32)
+    np.testing.assert_array_equal(bpg.compute_reward(ag, g).view(np.uint32), want)                       # float64 * int64
+    np.testing.assert_array_equal(bpg.compute_reward(ag.astype(np.float32), g.astype(np.float32)).view(np.uint32), want)
+    # argument checks of the float64 entry point
+    x = torch.zeros((4, 160), dtype=torch.float64, device=DEV)
+    o = torch.zeros(4, dtype=torch.float32, device=DEV)
+    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 160, P(o), 0, None) == bpg._lib.ERR_ARG
+    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 159, P(o), 0, None) == 0

@@ -244,3 +244,34 @@ def test_fixture_generator_is_deterministic():
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'regenerates bit-identically' in out.stdout
+
+
+def test_compute_reward_summation_order_matches_numpy_and_the_reference_fixture():
+    """fetch_env.py:141 sums achieved_goal * goal with np.sum: NumPy's pairwise order, in the arrays' precision.
+    The oracle restates that order (third-party NumPy); here it is checked against NumPy itself on random rows
+    and against the reference's compute_reward on rows whose outcome depends on the order
+    (tests/golden/compute_reward_order.npz: every row's exact sum equals count_nonzero(g))."""
+    rng = np.random.RandomState(3)
+    for dt in (np.float32, np.float64):
+        for n in (1, 5, 8, 9, 36, 100, 128, 129, 255, 256, 300):
+            a = (rng.normal(size=(50, n)) * 10 ** rng.uniform(-4, 4, size=(50, n))).astype(dt)
+            np.testing.assert_array_equal(O.rowsum(a), np.sum(a, axis=-1))
+    d = np.load(os.path.join(G, 'compute_reward_order.npz'))
+    flips = 0
+    for key in sorted(k[:-3] for k in d.files if k.endswith('_ag')):
+        ag, g, want = d[key + '_ag'], d[key + '_g'], d[key + '_rbits']
+        got = O.compute_reward_f32(ag, g) if ag.dtype == np.float32 else O.compute_reward(ag, g)
+        np.testing.assert_array_equal(got.view(np.uint32), want, err_msg=key)
+        flips += int(d[key + '_differs_from_sequential'])
+    assert flips > 50          # the fixture does separate NumPy's order from a sequential sum
+
+
+def test_env_key_mirrors_the_reference_seed_arithmetic():
+    """rollout.py:206-210 `env.seed(seed + 1000 * idx)`: the oracle's statement of the per-env key is a function
+    of seed + 1000 * idx alone (64-bit wrap included)."""
+    L = O.lib()
+    for s, i in ((5, 3), (2 ** 40 + 17, 123456), (2 ** 64 - 2500, 5)):
+        assert L.orc_env_key(s, i, 0) == L.orc_env_key((s + 1000 * i) % 2 ** 64, 0, 0)
+        assert L.orc_synth_mask(s, i, 7, 6) == L.orc_synth_mask((s + 1000 * i) % 2 ** 64, 0, 7, 6)
+        assert L.orc_num_grey_draw(s, i, 2) == L.orc_num_grey_draw((s + 1000 * i) % 2 ** 64, 0, 2)
+    assert L.orc_env_key(5, 3, 0) != L.orc_env_key(5, 3, 1) and L.orc_env_key(5, 3, 0) != L.orc_env_key(6, 3, 0)

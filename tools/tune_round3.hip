@@ -44,11 +44,11 @@ static int setup(Bufs &b, int64_t B, int T, bool withG)
         CK(hipMalloc(&b.flags[k], (size_t)b.LD * T));
         if (withG) CK(hipMalloc(&b.G[k], (size_t)B * T * 8));
     }
-    SynthConst s{}; s.seed = 1; s.env_base = 0;
+    SynthConst s{}; s.seed0 = 1;
     for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; }
     hipLaunchKernelGGL(k_init, dim3(2048), dim3(256), 0, 0, b.now, b.ever, B, 6u);
     for (int k = 0; k < b.NB; k++) {
-        s.seed = 1 + k;
+        s.seed0 = 1 + k;
         for (int t = 0; t < T; t++)
             hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, b.ever, B, t, 1, b.masks[k] + (int64_t)t * b.LD, b.LD, s);
     }
@@ -95,8 +95,8 @@ static int rot = 0;
 #define GG b.G[rot % b.NB]
 
 static StepConst mk_c() { StepConst c{}; c.valid = 0x1FFFFF; c.want_touch = 1u << 12; c.want_never = 0; c.max_steps = 50; c.sticky_on = 1; return c; }
-static SynthConst mk_s() { SynthConst s{}; s.seed = 1; for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; } return s; }
-static ResetConst mk_rc(Bufs &b) { ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed = 1; rc.reset_counter = b.d_counter; return rc; }
+static SynthConst mk_s() { SynthConst s{}; s.seed0 = 1; for (int n = 0; n < 8; n++) { s.valid_by_n[n] = 0x1FFFFF; s.forced_by_n[n] = 0; } return s; }
+static ResetConst mk_rc(Bufs &b) { ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed0 = 1; rc.reset_counter = b.d_counter; return rc; }
 static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k++) p.v[k] = std::pow(0.98, (double)k); return p; }
 
 // COUNT: 0 none, 1 one plain atomic per block, 2 sharded.  OKB: 1 = the launch also stores the step-ok words
@@ -183,7 +183,17 @@ static int run(char mode, int64_t B)
                 TIME("  waves/block " #W ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),                                 \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
-            if (rep == 0) { WPBV(1); WPBV(2); WPBV(8); WPBV(16); }
+#define TRV(W, TRR)                                                                                                                \
+            do {                                                                                                                   \
+                const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
+                TIME("  waves/block " #W " tile rows " #TRR ": lane<50, exact>", rbytes,                                            \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG)); \
+                TIME("  waves/block " #W " tile rows " #TRR ": lane<50, scan>", rbytes,                                             \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));  \
+                TIME("  waves/block " #W " tile rows " #TRR ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),               \
+                     hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W, TRR>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
+            } while (0)
+            if (rep == 0) { WPBV(2); WPBV(8); TRV(4, 32); TRV(2, 32); TRV(1, 64); TRV(2, 64); TRV(4, 8); }
         }
     }
     teardown(b);
