@@ -70,6 +70,8 @@ def parse():
     p.add_argument('--contiguous-rows', action='store_true',
                    help='time-major streams with rows exactly B elements apart (default: bpg_row_stride(B))')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
+    p.add_argument('--no-stride-probe', action='store_true',
+                   help='skip the set-up probe of the headline launch at row strides B, B + 256, B + 768')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
     p.add_argument('--launch-timeout', type=float, default=900.0,
@@ -340,6 +342,42 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Row-stride probe (set-up, untimed part of the run; `value` always uses LD above): the headline launch at
+    # rows B, B + 256 and B + 768 elements apart on THIS box -- DESIGN.md 3 derives bpg_row_stride from a handful
+    # of boxes, this records what the box the bench ran on says.
+    stride_probe = None
+    if rank == 0 and not a.no_stride_probe and B >= (1 << 19):
+        stride_probe = {}
+        for pad in (0, 256, 768):
+            ldp = B + pad
+            try:
+                pm = [torch.empty((T, ldp), dtype=torch.int32, device=dev)[:, :B] for _ in range(NBUF)]
+                pr = torch.empty((T, ldp), dtype=torch.float32, device=dev)[:, :B]
+                pf = torch.empty((T, ldp), dtype=torch.uint8, device=dev)[:, :B]
+                for k in range(NBUF):
+                    env.seed(a.seed + k)
+                    _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(pm[k].data_ptr()), ldp, stream))
+                env.seed(a.seed)
+                sc = torch.zeros(2, dtype=torch.int64, device=dev)
+                pa = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=pm[k].data_ptr(),
+                                       d_reward_tb=pr.data_ptr(), d_flags_tb=pf.data_ptr(), ld_masks=ldp, ld_out=ldp,
+                                       d_success_count=sc.data_ptr()) for k in range(NBUF)]
+                for i in range(60):
+                    _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                for i in range(60):
+                    _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                p1.record()
+                torch.cuda.synchronize(dev)
+                ms = p0.elapsed_time(p1) / 60
+                stride_probe['ld_B_plus_%d' % pad] = {'kernel_ms': ms, 'frac_hbm_peak': B * (T * 9 + 12) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del pm, pr, pf, pa
+            except Exception as e:  # noqa: BLE001
+                stride_probe['ld_B_plus_%d' % pad] = {'error': repr(e)[:200]}
+        stride_probe['library_choice'] = int(L.bpg_row_stride(B)) - B
+        torch.cuda.empty_cache()
+
     if a.prewarm > 0:                      # set-up, not measurement: same launch, scratch statistics row
         scratch = torch.zeros(2, dtype=torch.int64, device=dev)
         pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
@@ -391,7 +429,9 @@ def run(a):
     # rocprofv3 --kernel-trace --stats means of the committed profile of this same command
     # (tools/collect_profiles.sh -> profiles/r02_pmc/kernel_means.json), quoted beside the live HIP-event figures
     prof_means = {}
-    mf = os.path.join(ROOT, 'profiles', 'r02_pmc', 'kernel_means.json')
+    mf = os.path.join(ROOT, 'profiles', 'r03_pmc', 'kernel_means.json')
+    if not os.path.exists(mf):
+        mf = os.path.join(ROOT, 'profiles', 'r02_pmc', 'kernel_means.json')
     if os.path.exists(mf):
         prof_means = json.load(open(mf))
 
@@ -400,7 +440,7 @@ def run(a):
         if not m:
             return None
         return {'mean_us': m['mean_us'], 'calls': m['calls'],
-                'frac_hbm_peak': nbytes / (m['mean_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'source': 'profiles/r02_pmc/kernel_means.json'}
+                'frac_hbm_peak': nbytes / (m['mean_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'source': os.path.relpath(mf, ROOT)}
 
     out = {
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
@@ -424,12 +464,14 @@ def run(a):
                                          (world * B if a.collective == 'allgather' else 16)),
         'gathered_bytes_per_rollout': (world * B if (multi and a.collective == 'allgather') else None),
         'kernel_ms_per_rank': {'min': min(rank_kernel_ms), 'max': max(rank_kernel_ms), 'all': rank_kernel_ms},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, 2 envs/lane, reward+flags, reset>', 'achieved': achieved,
+        'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, %s, reward+flags, reset>' % ('2 envs/lane x 1024 lanes' if B >= 524288 else ('2 envs/lane x 256 lanes' if B >= 229376 else '1 env/lane x 256 lanes, pipelined')), 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms,
                      'rocprofv3_committed': rocprof_of('k_rollout_masks_bench', bytes_per_launch) if B == (1 << 20) and T == 50 else None},
     }
+    if stride_probe is not None:
+        out['row_stride_probe'] = stride_probe
 
     if rank == 0 and world == 1 and not a.no_extras:
         out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
@@ -638,6 +680,48 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     for _ in range(NDR):          # first touch of the fresh buffers is not part of the figure
         dr()
     res['discounted_return_f64'] = line(timed(dr, 4 * NDR), B * T * 12, B * T)
+
+    # (3e') the O(T) scan form of the same return (tolerance-based, include/bpgym.h)
+    def drs():
+        k = dr_it[0] % NDR
+        dr_it[0] += 1
+        _lib.check(L.bpg_discounted_return_scan(C.c_void_p(dr_in[k].data_ptr()), B, LD, T, 1.0 - 1.0 / T,
+                                                C.c_void_p(dr_out[k].data_ptr()), dev.index, stream))
+    res['discounted_return_scan_f64'] = line(timed(drs, 4 * NDR), B * T * 12, B * T)
+
+    # (3f) the policy-gradient path (policy_gradient/rollout.py): one rollout + its return G (B, T) float64.
+    # round-2 form: reward + flags streams, then the return kernel on the reward stream (9 + 12 = 21 B/env-step);
+    # round-3 form: ONE bpg_rollout call with d_G -- flags stream + 8-byte step-ok words, expanded by a second
+    # launch of the same call (5 + 8 + 0.3 B/env-step), no reward stream.
+    try:
+        m_sets = [masks] + [torch.empty((T, LD), dtype=torch.int32, device=dev)[:, :B] for _ in range(2)]
+        for m_ in m_sets[1:]:
+            m_.copy_(masks)
+        pg_it = [0]
+        ngp = ((torch.arange(B, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
+        a_old = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ngp.data_ptr(), d_masks=m_.data_ptr(), ld_masks=LD,
+                                  d_reward_tb=dr_in[k].data_ptr(), d_flags_tb=flags.data_ptr(), ld_out=LD)
+                 for k, m_ in enumerate(m_sets)]
+        a_new = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ngp.data_ptr(), d_masks=m_.data_ptr(), ld_masks=LD,
+                                  d_flags_tb=flags.data_ptr(), ld_out=LD, d_G=dr_out[k].data_ptr(), gamma=1.0 - 1.0 / T)
+                 for k, m_ in enumerate(m_sets)]
+
+        def pg_old():
+            k = pg_it[0] % NDR
+            pg_it[0] += 1
+            _lib.check(L.bpg_rollout(env._h, C.byref(a_old[k]), stream))
+            _lib.check(L.bpg_discounted_return_ld(C.c_void_p(dr_in[k].data_ptr()), B, LD, T, 1.0 - 1.0 / T,
+                                                  C.c_void_p(dr_out[k].data_ptr()), dev.index, stream))
+
+        def pg_new():
+            k = pg_it[0] % NDR
+            pg_it[0] += 1
+            _lib.check(L.bpg_rollout(env._h, C.byref(a_new[k]), stream))
+        res['pg_rollout_plus_return_via_reward_stream'] = line(timed(pg_old, 4 * NDR), B * (T * 21 + 12), B * T)
+        res['pg_rollout_with_return_from_step_ok_words'] = line(timed(pg_new, 4 * NDR), B * (T * 13 + 12 + 16), B * T)
+        del m_sets, a_old, a_new
+    except Exception as e:  # noqa: BLE001
+        res['pg_rollout_with_return_from_step_ok_words'] = {'error': repr(e)[:300]}
     del dr_in, dr_out
 
     # (4) episode writer: float32 episode['ag'] (B,T+1,36), ['g'] (B,T,36), ['info_is_success'] (B,T,1)

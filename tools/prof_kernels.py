@@ -5,8 +5,10 @@ rocprofv3 (kernel trace or one --pmc counter set per invocation):
     rocprofv3 --kernel-trace --stats -d out -- python3 tools/prof_kernels.py return rollout synth
     rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
 
-kernels: rollout (fused, masks), rollout64k, rollout512k, synth (fused, in-kernel contacts),
-step (13 batches round-robin), record, return, episode, reward, assemble (+ set_action, placement), nan, reset
+kernels: rollout (fused, masks, 1 M envs), rollout64k / rollout128k / rollout256k / rollout512k (the other launch shapes),
+rollout4m (4 M envs, rows a power of two apart), synth (fused, in-kernel contacts), pg (rollout + the policy-gradient
+return from the step-ok words, one call), step (13 batches round-robin), record, return, scan, episode, reward,
+assemble (+ set_action, placement), nan, reset
 """
 import ctypes as C
 import os
@@ -26,24 +28,27 @@ P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 TM = lambda B, dtype: bpg.time_major_empty(T, B, dtype, DEV)   # noqa: E731  (T, B) stream, rows bpg_row_stride(B) apart
 
 
-def rollout(B, reps, synth=False):
+def rollout(B, reps, synth=False, contiguous=False, pg=False):
     env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
     ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 7) % 3
     env.reset(num_grey=ng)
-    nset = int(2.5 * 256 * 2**20 // (B * T * 9)) + 1
+    nset = min(int(2.5 * 256 * 2**20 // (B * T * 9)) + 1, 24)
+    tm = (lambda dtype: torch.empty((T, B), dtype=dtype, device=DEV)) if contiguous else (lambda dtype: TM(B, dtype))
     sets = []
-    for k in range(max(nset, 4)):
+    for k in range(max(nset, 3 if B > (1 << 21) else 4)):
         env.seed(k)
-        m = TM(B, torch.int32)
+        m = tm(torch.int32)
         _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), m.stride(0), None))
-        sets.append((m, TM(B, torch.float32), TM(B, torch.uint8)))
+        sets.append((m, None if pg else tm(torch.float32), tm(torch.uint8),
+                     torch.empty((B, T), dtype=torch.float64, device=DEV) if pg else None))
     cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
     for i in range(reps):
-        m, r, f = sets[i % len(sets)]
+        m, r, f, G = sets[i % len(sets)]
         a = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=None if synth else ng.data_ptr(), ld_masks=m.stride(0),
-                             ld_out=r.stride(0),
-                             d_masks=None if synth else m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
-                             d_success_count=None if synth else cnt.data_ptr())
+                             ld_out=f.stride(0),
+                             d_masks=None if synth else m.data_ptr(), d_reward_tb=None if r is None else r.data_ptr(),
+                             d_flags_tb=f.data_ptr(), d_success_count=None if synth else cnt.data_ptr(),
+                             d_G=None if G is None else G.data_ptr(), gamma=0.98)
         _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
     torch.cuda.synchronize()
 
@@ -56,8 +61,16 @@ def main():
             rollout(B, 20)
         elif w == 'rollout64k':
             rollout(65536, 60)
+        elif w == 'rollout128k':
+            rollout(131072, 40)
+        elif w == 'rollout256k':
+            rollout(262144, 30)
         elif w == 'rollout512k':
             rollout(524288, 20)
+        elif w == 'rollout4m':
+            rollout(4194304, 8, contiguous=True)
+        elif w == 'pg':
+            rollout(B, 20, pg=True)
         elif w == 'synth':
             rollout(B, 20, synth=True)
         elif w == 'step':
@@ -72,7 +85,7 @@ def main():
                 e, m, r, f = sets[i % 13]
                 _lib.check(L.bpg_step_masks(e._h, P(m), P(r), P(f), None))
             torch.cuda.synchronize()
-        elif w in ('record', 'return', 'episode', 'reward'):
+        elif w in ('record', 'return', 'scan', 'episode', 'reward'):
             env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
             env.reset()
             m, r, f = TM(B, torch.int32), TM(B, torch.float32), TM(B, torch.uint8)
@@ -86,10 +99,15 @@ def main():
                 sf = torch.empty(B, dtype=torch.float32, device=DEV)
                 for i in range(20):
                     _lib.check(L.bpg_step_record(env._h, P(m[i]), P(r[i]), P(f[i]), P(sf), P(ag), 36, None, None, None))
-            elif w == 'return':
-                G = torch.empty((B, T), dtype=torch.float64, device=DEV)
-                for i in range(10):
-                    _lib.check(L.bpg_discounted_return_ld(P(r), B, LD, T, 0.98, P(G), 0, None))
+            elif w in ('return', 'scan'):
+                # three (reward, G) pairs round-robin: nothing of the previous launch is left in the 256 MiB cache
+                rs = [r] + [TM(B, torch.float32) for _ in range(2)]
+                for r_ in rs[1:]:
+                    r_.copy_(r)
+                Gs = [torch.empty((B, T), dtype=torch.float64, device=DEV) for _ in range(3)]
+                fn = L.bpg_discounted_return_ld if w == 'return' else L.bpg_discounted_return_scan
+                for i in range(15):
+                    _lib.check(fn(P(rs[i % 3]), B, LD, T, 0.98, P(Gs[i % 3]), 0, None))
             elif w == 'episode':
                 ag = torch.empty((B, T + 1, 36), dtype=torch.float32, device=DEV)
                 gg = torch.empty((B, T, 36), dtype=torch.float32, device=DEV)

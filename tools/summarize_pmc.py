@@ -34,21 +34,39 @@ CAL = {
     'cal_write<unsigned char, true': (GIB // 8, 'WRITE_SIZE', 'write1nt'),
     'cal_write<double, false': (GIB, 'WRITE_SIZE', 'write8f64'),
 }
-# kernel name fragment -> (label, read width key, algorithmic read bytes, algorithmic write bytes) at 1 M envs, T = 50
+# (kernel name fragment, grid size in threads or None, label, read width key, algorithmic read bytes, algorithmic
+#  write bytes, collection group).  The grid size tells launch shapes of one instantiation apart; the group is the
+# tools/collect_profiles.sh invocation the launch belongs to ('' = first kernel group / bench, '2' = second group).
 B, T = 1 << 20, 50
+
+
+def roll(n):
+    return n * (4 * T + 4), n * (5 * T + 8)
+
+
+FAT = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false>'
+MID = 'k_rollout<0, true, 2, 3, true, 5, false, true, 256, false>'
 KERNELS = [
-    ('k_rollout<0, true, 2, 3, true, 5, false, true', 'k_rollout_masks', 'read8', B * (4 * T + 4), B * (5 * T + 8)),
-    ('k_rollout<1, true, 2, 3, true, 10, false, true', 'k_rollout_synth', 'read8', 0, B * (5 * T + 8)),
-    ('k_rollout<0, true, 1, 3, true, 10, true, true', 'k_rollout_masks_65536', 'read4', 65536 * (4 * T + 4), 65536 * (5 * T + 8)),
-    ('k_step_vec4<0>', 'k_step_vec4_masks', 'read16', 12 * B, 13 * B),
-    ('k_step_record<6, 0', 'k_step_record', 'read4', 12 * B, (13 + 4 + 144) * B),
-    ('k_discounted_return_reg<50', 'k_discounted_return_reg50', 'read4', 4 * T * B, 8 * T * B),
-    ('k_episode<6, 0', 'k_episode', 'read4', B * (4 * T + 8), B * (8 + 4 * (36 * (2 * T + 1) + T))),
-    ('k_compute_reward_f32<true', 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4),
-    ('k_reset<true>', 'k_reset_obs', 'read4', 8 * B, None),
-    ('k_assemble_obs<float, 4>', 'k_assemble_obs_f32', 'read8', B * (4 + 8 * 58), B * 4 * 87),
-    ('k_set_action', 'k_set_action', 'read16', 16 * B, 72 * B),
-    ('k_nan_flag<true>', 'k_nan_flag', 'read16', B * 4 * 87, 0),
+    (FAT, 256 * 1024, 'k_rollout_masks', 'read8') + roll(B) + ('',),
+    (FAT, 256 * 1024, 'k_rollout_masks_524288', 'read8') + roll(524288) + ('2',),
+    (MID, 262144 // 2, 'k_rollout_masks_262144', 'read8') + roll(262144) + ('',),
+    (MID, 1024 * 256, 'k_rollout_masks_4194304_aliased_rows', 'read8') + roll(4194304) + ('2',),
+    ('k_rollout<0, true, 1, 3, true, 5, true, true, 256, false>', 131072, 'k_rollout_masks_131072', 'read4') + roll(131072) + ('',),
+    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false>', 65536, 'k_rollout_masks_65536', 'read4') + roll(65536) + ('',),
+    ('k_rollout<1, true, 2, 3, true, 10, false, true, 256, false>', None, 'k_rollout_synth', 'read8', 0, B * (5 * T + 8), ''),
+    ('k_rollout<0, true, 2, 2, true, 5, false, true, 1024, true>', None, 'k_rollout_masks_flags_okbits', 'read8',
+     B * (4 * T + 4), B * (T + 8 + 8), ''),
+    ('k_returns_from_okbits_lane<50', None, 'k_returns_from_okbits_lane50', 'read8', 8 * B, 8 * T * B, ''),
+    ('k_step_vec4<0>', None, 'k_step_vec4_masks', 'read16', 12 * B, 13 * B, ''),
+    ('k_step_record<6, 0', None, 'k_step_record', 'read4', 12 * B, (13 + 4 + 144) * B, ''),
+    ('k_discounted_return_lane<50, 0', None, 'k_discounted_return_lane50_exact', 'read4', 4 * T * B, 8 * T * B, ''),
+    ('k_discounted_return_lane<50, 1', None, 'k_discounted_return_lane50_scan', 'read4', 4 * T * B, 8 * T * B, ''),
+    ('k_episode<6, 0', None, 'k_episode', 'read4', B * (4 * T + 8), B * (8 + 4 * (36 * (2 * T + 1) + T)), ''),
+    ('k_compute_reward_f32<true', None, 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4, ''),
+    ('k_reset<true>', None, 'k_reset_obs', 'read4', 8 * B, None, ''),
+    ('k_assemble_obs<float, 4>', None, 'k_assemble_obs_f32', 'read8', B * (4 + 8 * 58), B * 4 * 87, ''),
+    ('k_set_action', None, 'k_set_action', 'read16', 16 * B, 72 * B, ''),
+    ('k_nan_flag<true>', None, 'k_nan_flag', 'read16', B * 4 * 87, 0, ''),
 ]
 
 
@@ -60,11 +78,26 @@ def load(pattern):
 
 
 def per_kernel(rows, counter):
+    """{(kernel name, grid size in threads): [bytes per dispatch]}"""
     out = defaultdict(list)
     for r in rows:
         if r['Counter_Name'] == counter:
-            out[r['Kernel_Name']].append(float(r['Counter_Value']) * 1024.0)
+            out[(r['Kernel_Name'], int(r['Grid_Size']))].append(float(r['Counter_Value']) * 1024.0)
     return out
+
+
+def pick(table, frag, grid):
+    return [v for (name, g), vs in table.items() if frag in name and (grid is None or g == grid) for v in vs]
+
+
+def trace_means(src, sub):
+    """{(kernel name, grid threads): (calls, mean us, min us)} from the per-dispatch kernel trace."""
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(src, sub, '**', '*kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            g = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+            acc[(r['Kernel_Name'], g)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    return acc
 
 
 def main():
@@ -76,22 +109,23 @@ def main():
         for frag, (known, cn, key) in CAL.items():
             if cn != counter:
                 continue
-            vals = [v for name, vs in pk.items() if frag in name for v in vs]
+            vals = pick(pk, frag, None)
             if vals:
                 cal[key] = {'known_bytes': known, 'counter_bytes_median': statistics.median(vals),
                             'factor': known / statistics.median(vals)}
     json.dump(cal, open(os.path.join(dst, 'calibration.json'), 'w'), indent=1)
     res = {}
-    for tag in ('k', 'b'):
+    for tag, group, suffix in (('k', '', ''), ('k2', '2', ''), ('b', '', '_bench')):
         fetch = per_kernel(load(os.path.join(src, tag + '_fetch', '**', '*counter_collection.csv')), 'FETCH_SIZE')
         write = per_kernel(load(os.path.join(src, tag + '_write', '**', '*counter_collection.csv')), 'WRITE_SIZE')
-        for frag, label, rkey, aread, awrite in KERNELS:
-            fv = [v for name, vs in fetch.items() if frag in name for v in vs]
-            wv = [v for name, vs in write.items() if frag in name for v in vs]
+        for frag, grid, label, rkey, aread, awrite, grp in KERNELS:
+            if grp != group:
+                continue
+            fv, wv = pick(fetch, frag, grid), pick(write, frag, grid)
             if not fv or not wv:
                 continue
             rf = cal.get(rkey, {}).get('factor', 2.0 if rkey == 'read16' else 1.0)
-            res['%s%s' % (label, '' if tag == 'k' else '_bench')] = {
+            res[label + suffix] = {
                 'launches': [len(fv), len(wv)], 'read_width_calibration': rkey, 'read_factor': rf,
                 'hbm_read_bytes': statistics.median(fv) * rf, 'hbm_write_bytes': statistics.median(wv),
                 'hbm_bytes_per_launch': statistics.median(fv) * rf + statistics.median(wv),
@@ -102,25 +136,31 @@ def main():
         json.dump({'k_rollout_masks': dict(head, envs=B, T=T,
                                             method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; '
                                                    'FETCH_SIZE scaled by the factor an 8-B-per-lane read stream of known '
-                                                   'size shows in the same session (profiles/r02_pmc/calibration.json)',
+                                                   'size shows in the same session (calibration.json beside this file)',
                                             algorithmic_bytes_per_launch=B * (9 * T + 12))},
                   open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-    # rocprofv3 --kernel-trace --stats means of the same kernels (what bench.py quotes beside its HIP-event figures)
+    # rocprofv3 --kernel-trace means of the same launches, per (kernel, grid) (what bench.py quotes beside its
+    # HIP-event figures)
     means = {}
-    for sub, suffix in (('trace_kernels', ''), ('trace_headline', '_bench')):
-        for f in glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True):
-            for r in csv.DictReader(open(f)):
-                for frag, label, _, aread, awrite in KERNELS:
-                    if frag in r['Name'] and not (label == 'k_rollout_masks' and not suffix):   # that trace mixes 1 M and 512 K launches
-                        means[label + suffix] = {'calls': int(r['Calls']), 'mean_us': float(r['AverageNs']) / 1e3,
-                                                 'min_us': float(r['MinNs']) / 1e3,
-                                                 'algorithmic_bytes': None if awrite is None else aread + awrite}
+    for sub, group, suffix in (('trace_kernels', '', ''), ('trace_kernels2', '2', ''), ('trace_headline', '', '_bench')):
+        tm = trace_means(src, sub)
+        for frag, grid, label, _, aread, awrite, grp in KERNELS:
+            if grp != group:
+                continue
+            d = [v for (name, g), vs in tm.items() if frag in name and (grid is None or g == grid) for v in vs]
+            if d:
+                alg = None if awrite is None else aread + awrite
+                means[label + suffix] = {'calls': len(d), 'mean_us': sum(d) / len(d), 'min_us': min(d), 'algorithmic_bytes': alg,
+                                         'frac_of_8TBs': None if alg is None else alg / (sum(d) / len(d) * 1e-6) / 8e12}
     json.dump(means, open(os.path.join(dst, 'kernel_means.json'), 'w'), indent=1)
     print(json.dumps(cal, indent=1))
     for k, v in res.items():
-        print('%-32s read %8.1f MB (alg %s)  write %8.1f MB (alg %s)' % (
+        print('%-40s read %8.1f MB (alg %s)  write %8.1f MB (alg %s)' % (
             k, v['hbm_read_bytes'] / 1e6, None if v['algorithmic_read'] is None else round(v['algorithmic_read'] / 1e6, 1),
             v['hbm_write_bytes'] / 1e6, None if v['algorithmic_write'] is None else round(v['algorithmic_write'] / 1e6, 1)))
+    for k, v in means.items():
+        print('%-40s %4d calls  mean %9.2f us  min %9.2f us  %s' % (k, v['calls'], v['mean_us'], v['min_us'],
+                                                                  '' if v['frac_of_8TBs'] is None else '%.3f of 8 TB/s' % v['frac_of_8TBs']))
 
 
 if __name__ == '__main__':
