@@ -50,8 +50,14 @@ def rotl(x, r):
     return (x << np.uint32(r)) | (x >> np.uint32(32 - r))
 
 
+def env_key(seed, env):
+    """key(seed + 1000 * env, 0) of DESIGN.md 5a (the reference's per-env seed arithmetic, rollout.py:206-210)"""
+    es = (np.uint64(seed) + np.uint64(1000) * env.astype(np.uint64))
+    return lowbias32(u32(es) ^ lowbias32(u32((es >> np.uint64(32)) + np.uint64(0x9E3779B9))))
+
+
 def keys(seed, env):
-    ka = lowbias32(np.uint32(seed) ^ lowbias32(u32(env.astype(np.uint64) + 0x9E3779B9)))
+    ka = env_key(seed, env)
     kb = lowbias32(ka ^ np.uint32(0x85EBCA6B))
     return ka, kb
 
@@ -77,7 +83,7 @@ def mask_tail(a, b):
 
 
 def mask_cur(seed, env, t):
-    key = lowbias32(np.uint32(seed) ^ lowbias32(u32(env.astype(np.uint64) + 0x9E3779B9)))
+    key = env_key(seed, env)
     w = [lowbias32(u32(key.astype(np.uint64) + np.uint64((4 * t + i) * 0x9E3779B9 + 0x85EBCA6B))) for i in range(4)]
     acc = ((w[0] >> np.uint32(21)) | ((w[1] >> np.uint32(21)) << np.uint32(11))) & M21
     acc &= w[3] & M21
