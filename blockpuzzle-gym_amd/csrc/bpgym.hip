@@ -861,8 +861,20 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
                                                    int64_t e0, int64_t n, int lane)
 {
     constexpr bool PAIRS = TT % 2 == 0;          // rows are whole 16-byte pieces: 16-byte LDS and global accesses
+    if constexpr (TR == 0) {
+        // no tile: every lane writes its own row (400-byte stride between lanes: every store instruction touches
+        // 64 lines; the L2 has to merge the pieces) -- kept for the A/B in tools/tune_round3, not used by the library
+        if (e0 + lane < n) {
+            double2 *row = reinterpret_cast<double2 *>(G + (e0 + lane) * TT);
+            static_for<0, TT / 2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                row[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+            });
+        }
+        return;
+    }
 #pragma unroll
-    for (int c = 0; c < 64 / TR; c++) {
+    for (int c = 0; c < 64 / (TR ? TR : 64); c++) {
         if (c) wave_lds_sync();                                          // previous quarter streamed out
         if ((lane / TR) == c) {
             double *row = tile + (lane % TR) * TT;
@@ -2144,7 +2156,7 @@ __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
                          double *__restrict__ G)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][(TR ? TR : 1) * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
     if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
@@ -2260,15 +2272,17 @@ __global__ void __launch_bounds__(64 * WPB)
 k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
                            int64_t n)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][(TR ? TR : 1) * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
-    if (base >= n) return;
-    const int64_t e = base + lane < n ? base + lane : n - 1;
-    const uint64_t ok = okbits[e];
-    double acc[TT];
-    returns_from_okbits<TT>(ok, acc);
-    wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+    // grid-stride over 64-env tiles (one tile per wave when the grid covers the batch)
+    for (int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64; base < n; base += (int64_t)gridDim.x * WPB * 64) {
+        const int64_t e = base + lane < n ? base + lane : n - 1;
+        const uint64_t ok = okbits[e];
+        double acc[TT];
+        returns_from_okbits<TT>(ok, acc);
+        wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+        wave_lds_sync();                               // the tile is written again by the next trip
+    }
 }
 
 // any T <= 64: the rows accumulate in an LDS tile, one env per lane

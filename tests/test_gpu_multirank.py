@@ -98,3 +98,32 @@ def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
     assert len(km['all']) == 2 and 0 < km['min'] <= km['max']
     assert line['launcher']['rank_exit_codes'] == [0, 0]
     assert line['value'] > 0 and 0 <= line['config']['success_rate'] <= 1
+
+
+def test_bench_under_torchrun_two_ranks_on_one_card():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (WORLD_SIZE set: bench.py is a rank, it must not start ranks of its own).
+    Two ranks on cuda:0 with gloo here; rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-device',
+           '--backend', 'gloo', '--envs', '65536', '--steps', '4', '--warmup', '2', '--prewarm', '4', '--reduce-every', '2',
+           '--no-extras', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = []
+    for ln in out.stdout.splitlines():
+        try:
+            cand = json.loads(ln)
+        except ValueError:
+            continue
+        if isinstance(cand, dict) and 'metric' in cand:
+            lines.append(cand)
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = lines[0]
+    assert 'error' not in line and 'launcher' not in line          # no self-launch under torchrun
+    assert line['n_gpus'] == 2 and line['rccl_world_size'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['total_envs'] == 131072 and line['collective'] == 'allreduce'
+    assert line['collective_bytes_per_rollout'] == 16 and len(line['kernel_ms_per_rank']['all']) == 2

@@ -193,7 +193,21 @@ static int run(char mode, int64_t B)
                 TIME("  waves/block " #W " tile rows " #TRR ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),               \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W, TRR>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
-            if (rep == 0) { WPBV(2); WPBV(8); TRV(4, 32); TRV(2, 32); TRV(1, 64); TRV(2, 64); TRV(4, 8); }
+            if (rep == 0) {
+                // persistent forms of the expansion kernel: a capped grid, every wave loops over tiles
+                for (int cap : {256 * 4, 256 * 3, 256 * 2, 256 * 8}) {
+                    char nm[96]; snprintf(nm, 96, "  returns_from_okbits_lane<50>, grid %d (4 waves/block)", cap);
+                    TIME(nm, (double)B * (8 + 8 * T), hipLaunchKernelGGL((k_returns_from_okbits_lane<50, 4>), dim3(cap), dim3(256), 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+                }
+                for (int cap : {256 * 8, 256 * 4}) {
+                    char nm[96]; snprintf(nm, 96, "  returns_from_okbits_lane<50>, grid %d (2 waves/block)", cap);
+                    TIME(nm, (double)B * (8 + 8 * T), hipLaunchKernelGGL((k_returns_from_okbits_lane<50, 2>), dim3(cap), dim3(128), 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+                }
+                for (int cap : {256 * 16, 256 * 8}) {
+                    char nm[96]; snprintf(nm, 96, "  returns_from_okbits_lane<50>, grid %d (1 wave/block)", cap);
+                    TIME(nm, (double)B * (8 + 8 * T), hipLaunchKernelGGL((k_returns_from_okbits_lane<50, 1>), dim3(cap), dim3(64), 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+                }
+            }
         }
     }
     teardown(b);
