@@ -753,37 +753,6 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, const Count
     }
 }
 
-// Counting wave (small batches).  The block's partial count has to reach the shard word with a RETURNING atomic,
-// and a wave's vector-memory operations return in issue order: issued by a wave that has just stored its last
-// rewards and flags, the atomic's answer queues behind those stores' acknowledgements (1-2 us on a streaming chip),
-// and the launch ends a store round trip PLUS an atomic round trip after its last step.  So the latency-bound shapes
-// carry a fifth wave per block that owns no env and no memory traffic: the working waves leave their partial counts
-// in LDS and cross an LDS-only barrier (no wait for their stores), the counting wave picks them up and its atomic
-// goes out at once -- the two round trips overlap (65 536 envs: profiles/r03_tune_small_batch_count.log).
-__device__ __forceinline__ void lds_only_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-__device__ __forceinline__ void count_worker(uint32_t lane_count, volatile uint32_t *s_part)
-{
-    uint32_t c = lane_count;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
-    lds_only_barrier();
-}
-
-__device__ __forceinline__ void count_wave(int workers, volatile uint32_t *s_part, const CountArgs &ca)
-{
-    lds_only_barrier();
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long tot = 0;
-        for (int w = 0; w < workers; w++) tot += s_part[w];
-        shard_count_add(tot, ca);
-    }
-}
-
 // T steps in one launch, EPL envs per lane, state in registers.  Masks / rewards are
 // time-major (T, n) so every access is an (EPL*4)-byte-per-lane coalesced stream.
 // Optionally resets first (rollout.py:79) and counts the final successes.
@@ -951,9 +920,8 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
 // after a wave's steps, was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs,
 // profiles/r03_tune_pg_path.log -- the memory-bound step phase and the VALU-bound return phase of the same
 // waves do not overlap -- and removed.)
-// CW: the block is launched with 64 lanes more than its LB working lanes: the counting wave above.
-template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false, bool CW = false>
-__global__ void __launch_bounds__(LB + (CW ? 64 : 0))
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false>
+__global__ void __launch_bounds__(LB)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
@@ -963,16 +931,10 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     using Fl = typename LaneVec<EPL>::fl;
     const int64_t nvec = n / EPL;               // the host guarantees n, ld_masks, ld_out % EPL == 0
     const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
-    __shared__ uint32_t s_cw_part[16];
-    const int work = CW ? (int)blockDim.x - 64 : (int)blockDim.x;        // lanes that own envs
-    if (CW && (int)threadIdx.x >= work) {
-        if (ca.count) count_wave(work >> 6, s_cw_part, ca);
-        return;
-    }
-    const int64_t stride = (int64_t)gridDim.x * work;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t nsucc = 0;
     if (ca.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *ca.zero_next = 0ull;
-    for (int64_t v = (int64_t)blockIdx.x * work + threadIdx.x; v < nvec; v += stride) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
         // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
         // no wave starts its episode behind a memory round trip
@@ -1120,10 +1082,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
         }
     }
-    if (ca.count) {
-        if (CW) count_worker(nsucc, s_cw_part);
-        else block_count_add(nsucc, ca);
-    }
+    if (ca.count) block_count_add(nsucc, ca);
 }
 
 // ------------------------------ float views ---------------------------------
@@ -3315,10 +3274,9 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     if (!episode) {
         const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
         const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb);
-        const dim3 grid(geo.grid);
+        const dim3 grid(geo.grid), block(geo.block);
 #define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB)                                           \
-        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, (EPL == 1 && PIPE)>), grid,  \
-                           dim3(geo.block + ((EPL == 1 && PIPE) ? 64 : 0)), 0, st,                             \
+        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB>), grid, block, 0, st,  \
                            b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits)
 #define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
         do {                                                                                                  \

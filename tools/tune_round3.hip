@@ -117,23 +117,6 @@ static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k+
                                     OKB ? b.okbits : nullptr));                                                \
     } while (0)
 
-// the same with the counting wave (block of BLOCK working lanes + 64)
-#define ROLLCW(EPL, BLOCK, UNR, PIPE, OUT, CAPMUL)                                                             \
-    do {                                                                                                       \
-        const int64_t lanes = B / EPL;                                                                         \
-        int64_t grid = (lanes + BLOCK - 1) / BLOCK;                                                            \
-        const int64_t cap = (int64_t)CAPMUL * 256 * (1024 / BLOCK);                                            \
-        if (cap && grid > cap) grid = cap;                                                                     \
-        CountArgs ca{b.cnt, b.cnt + 1, b.shards};                                                              \
-        char nm[120];                                                                                          \
-        snprintf(nm, 120, "epl%d block%-4d grid%-5lld unr%-2d %s out%d shards, counting wave", EPL, BLOCK, (long long)grid, UNR, \
-                 PIPE ? "pipe " : "plain", OUT);                                                               \
-        const double bytes = (double)B * (T * (4 + ((OUT & 1) ? 4 : 0) + ((OUT & 2) ? 1 : 0)) + 12);          \
-        TIME(nm, bytes, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, OUT, true, UNR, PIPE, true, BLOCK, false, true>), dim3((unsigned)grid), \
-                                    dim3(BLOCK + 64), 0, 0, b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca,  \
-                                    (uint64_t *)nullptr));                                                     \
-    } while (0)
-
 static int run(char mode, int64_t B)
 {
     const int T = 50;
@@ -155,7 +138,6 @@ static int run(char mode, int64_t B)
             ROLL(1, 128, 10, true, 3, 0, 1, 0, 256); ROLL(1, 128, 10, true, 3, 1, 1, 0, 256); ROLL(1, 128, 10, true, 3, 2, 1, 0, 256);
             ROLL(1, 64, 10, true, 3, 0, 1, 0, 256); ROLL(1, 64, 10, true, 3, 1, 1, 0, 256); ROLL(1, 64, 10, true, 3, 2, 1, 0, 256);
             ROLL(1, 256, 5, true, 3, 2, 1, 0, 256); ROLL(1, 128, 5, true, 3, 2, 1, 0, 256);
-            ROLLCW(1, 256, 10, true, 3, 1); ROLLCW(1, 256, 5, true, 3, 1); ROLLCW(1, 128, 10, true, 3, 1);
         }
     } else if (mode == 'C') {
         const double gbytes = (double)B * (8 + 8 * T), rbytes = (double)B * T * 12;
