@@ -1,6 +1,8 @@
 """Stateful differential fuzz: one batch of HIP envs and one oracle env per batch slot are
-driven through the same seeded random sequence of API calls -- mask steps, ragged contact-list
-steps (dense and CSR), fused multi-step launches without reset, full and partial resets
+driven through the same seeded random sequence of API calls -- mask steps (legal masks, and RAW 21-bit masks that
+may carry pairs of objects the episode does not have: fetch_env.py:154-157 never demotes those), ragged contact-list
+steps (dense and CSR), fused multi-step launches without reset (with the policy-gradient return of the launch,
+policy_gradient/rollout.py:255-258), full and partial resets
 (with Variation's num_grey draw), state save / restore -- and compared after every call:
 achieved_goal, reward bits, the is_success latch, TimeLimit's done.  Bit-exact throughout.
 The oracle side follows fetch_env.py:148-167 (_step_callback), :135-143 (compute_reward),
@@ -86,6 +88,8 @@ def test_random_api_sequences_vs_oracle(env_id, B):
         ngeom = np.array([len(mir.v['models'][m]['id2obj']) for m in mir.model])
         if op == 'mask':
             m = legal_masks(rng, 1, B, mir.nobj(), density=int(rng.randint(1, 4)))[0]
+            if rng.rand() < 0.3:                    # raw masks: any of the 21 pair bits
+                m = (rng.randint(0, 1 << 21, size=B) & rng.randint(0, 1 << 21, size=B)).astype(np.uint32)
             check_step(env.step(None, contact_masks=m.view(np.int32)), mir.step_masks(m))
         elif op in ('list', 'csr'):
             maxcon = int(rng.choice([1, 4, 11, 12]))
@@ -103,12 +107,20 @@ def test_random_api_sequences_vs_oracle(env_id, B):
         elif op == 'fused':                         # T' steps in one launch, no reset, episode continues
             Tp = int(rng.randint(1, 8))
             masks = legal_masks(rng, Tp, B, mir.nobj(), density=2)
+            if rng.rand() < 0.3:
+                masks = (rng.randint(0, 1 << 21, size=(Tp, B)) & rng.randint(0, 1 << 21, size=(Tp, B))).astype(np.uint32)
             dm = torch.as_tensor(masks.view(np.int32), device=DEV)
             rew = torch.empty((Tp, B), dtype=torch.float32, device=DEV)
             flg = torch.empty((Tp, B), dtype=torch.uint8, device=DEV)
-            a = bpg._lib.RolloutArgs(T=Tp, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr())
+            G = torch.empty((B, Tp), dtype=torch.float64, device=DEV)
+            a = bpg._lib.RolloutArgs(T=Tp, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
+                                     d_G=G.data_ptr(), gamma=0.9)
             bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
             torch.cuda.synchronize()
+            rr = rew.cpu().numpy()
+            for b in range(0, B, 17):
+                np.testing.assert_array_equal(G[b].cpu().numpy().view(np.uint64),
+                                              O.discounted_return(rr[:, b].astype(np.float64), 0.9).view(np.uint64))
             for t in range(Tp):
                 exp = mir.step_masks(masks[t])
                 np.testing.assert_array_equal(bits(rew[t]), exp[1])
