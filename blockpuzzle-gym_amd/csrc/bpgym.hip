@@ -2610,7 +2610,7 @@ using namespace bpgk;
 extern "C" {
 
 const char *bpg_last_error(void) { return g_err.c_str(); }
-int bpg_version(void) { return 100; }
+int bpg_version(void) { return 103; }    // 100 + round
 
 int bpg_variant_from_id(const char *env_id)
 {

@@ -4,6 +4,7 @@
 //         -Lblockpuzzle-gym_amd/lib -lbpgym -Wl,-rpath,$PWD/blockpuzzle-gym_amd/lib && /tmp/c_abi_demo
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -114,6 +115,31 @@ int main()
         }
     std::printf("fused rollout, T = %d: %llu successes; padded rows (ld = %lld; bpg_row_stride(2^20) = %lld) vs contiguous: %d mismatches\n",
                 T, c2[0], (long long)ld, (long long)bpg_row_stride((int64_t)1 << 20), bad2);
+
+    // The policy-gradient return of the same rollout from the same call (policy_gradient/rollout.py:255-258):
+    // d_G + gamma, no reward stream needed -- checked here against the reference's loop on the rewards of the
+    // first launch (float64, gamma ** k as C pow, products and sums rounded separately).
+    double *d_G; HIP(hipMalloc(&d_G, (size_t)B * T * 8));
+    const double gamma = 1.0 - 1.0 / T;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_G = d_G; ra.gamma = gamma;
+    CHECK(bpg_rollout(h, &ra, nullptr));
+    HIP(hipDeviceSynchronize());
+    std::vector<double> G((size_t)B * T), ref(T);
+    HIP(hipMemcpy(G.data(), d_G, G.size() * 8, hipMemcpyDeviceToHost));
+    int bad3 = 0;
+    for (int64_t b = 0; b < B; b++) {
+        for (int t = 0; t < T; t++) {
+            const double r = (double)r0[(size_t)t * B + b];
+            ref[t] = r;
+            for (int t_ = 0; t_ < t; t_++) {
+                volatile double p = std::pow(gamma, (double)(t - t_)) * r;       // no fused multiply-add
+                ref[t_] = ref[t_] + p;
+            }
+        }
+        bad3 += std::memcmp(ref.data(), &G[(size_t)b * T], (size_t)T * 8) != 0;
+    }
+    std::printf("policy-gradient return from the rollout call: %d of %lld rows differ from the reference loop\n", bad3, (long long)B);
     CHECK(bpg_destroy(h));
-    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0) ? 0 : 2;
+    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0 && bad3 == 0) ? 0 : 2;
 }

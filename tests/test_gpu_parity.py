@@ -936,6 +936,7 @@ def test_c_abi_from_plain_cpp_host(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'reward bits 0x80000000' in out.stdout and 'success count 1000 of 1000, mismatches 0' in out.stdout
     assert 'vs contiguous: 0 mismatches' in out.stdout and 'bpg_row_stride(2^20) = 1048832' in out.stdout
+    assert 'return from the rollout call: 0 of 1000 rows differ' in out.stdout
 
 
 def test_contact_list_input_is_sanitised():
