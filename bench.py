@@ -348,34 +348,46 @@ def run(a):
     stride_probe = None
     if rank == 0 and not a.no_stride_probe and B >= (1 << 19):
         stride_probe = {}
-        for pad in (0, 256, 768):
-            ldp = B + pad
-            try:
+        pads = (0, 256, 768)
+        probes = {}
+        try:
+            for pad in pads:
+                ldp = B + pad
                 pm = [torch.empty((T, ldp), dtype=torch.int32, device=dev)[:, :B] for _ in range(NBUF)]
                 pr = torch.empty((T, ldp), dtype=torch.float32, device=dev)[:, :B]
                 pf = torch.empty((T, ldp), dtype=torch.uint8, device=dev)[:, :B]
                 for k in range(NBUF):
                     env.seed(a.seed + k)
                     _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(pm[k].data_ptr()), ldp, stream))
-                env.seed(a.seed)
                 sc = torch.zeros(2, dtype=torch.int64, device=dev)
-                pa = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=pm[k].data_ptr(),
-                                       d_reward_tb=pr.data_ptr(), d_flags_tb=pf.data_ptr(), ld_masks=ldp, ld_out=ldp,
-                                       d_success_count=sc.data_ptr()) for k in range(NBUF)]
-                for i in range(60):
-                    _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
-                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                p0.record()
-                for i in range(60):
-                    _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
-                p1.record()
-                torch.cuda.synchronize(dev)
-                ms = p0.elapsed_time(p1) / 60
-                stride_probe['ld_B_plus_%d' % pad] = {'kernel_ms': ms, 'frac_hbm_peak': B * (T * 9 + 12) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                del pm, pr, pf, pa
-            except Exception as e:  # noqa: BLE001
-                stride_probe['ld_B_plus_%d' % pad] = {'error': repr(e)[:200]}
+                probes[pad] = (pm, pr, pf, sc,
+                               [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=pm[k].data_ptr(),
+                                                 d_reward_tb=pr.data_ptr(), d_flags_tb=pf.data_ptr(), ld_masks=ldp, ld_out=ldp,
+                                                 d_success_count=sc.data_ptr()) for k in range(NBUF)])
+            env.seed(a.seed)
+            best = {pad: [] for pad in pads}
+            for rep in range(3):                     # interleaved, so that clock ramp-up hits every stride alike;
+                for pad in pads:                     # the first repetition is a warm-up
+                    pa = probes[pad][4]
+                    for i in range(40):
+                        _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    p0.record()
+                    for i in range(60):
+                        _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                    p1.record()
+                    torch.cuda.synchronize(dev)
+                    if rep:
+                        best[pad].append(p0.elapsed_time(p1) / 60)
+            for pad in pads:
+                ms = min(best[pad])
+                stride_probe['ld_B_plus_%d' % pad] = {'kernel_ms': ms, 'frac_hbm_peak': B * (T * 9 + 12) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      'runs_ms': best[pad]}
+        except Exception as e:  # noqa: BLE001
+            stride_probe['error'] = repr(e)[:200]
         stride_probe['library_choice'] = int(L.bpg_row_stride(B)) - B
+        stride_probe['how'] = 'three interleaved passes over the pads (first discarded), 60 launches each, HIP events; min of the two kept'
+        del probes
         torch.cuda.empty_cache()
 
     if a.prewarm > 0:                      # set-up, not measurement: same launch, scratch statistics row

@@ -7,7 +7,9 @@
  * interface it replaces (paths relative to the reference root).  Plain C types
  * only, `int` return codes (0 = BPG_OK, negative = error, text via
  * bpg_last_error()), no exceptions, no hidden host syncs in step/reset/rollout
- * (they only enqueue work on `stream`), one caller thread per handle.
+ * (they only enqueue work on `stream`), one caller thread per handle, and the launches of one handle
+ * ordered among themselves (one stream, or streams the caller orders with events): besides the packed state
+ * a handle owns scratch words of the success count and the step-ok words of bpg_rollout_args.d_G.
  *
  * The boundary is "contacts-in": the closed-source physics the reference calls
  * (mujoco_py MjSim.step, robot_env.py:60) is outside; each step takes the set
