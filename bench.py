@@ -70,6 +70,7 @@ def parse():
     p.add_argument('--contiguous-rows', action='store_true',
                    help='time-major streams with rows exactly B elements apart (default: bpg_row_stride(B))')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
+    p.add_argument('--stride-pads', default='0,256,768', help='row pads (elements) of the row-stride probe')
     p.add_argument('--no-stride-probe', action='store_true',
                    help='skip the set-up probe of the headline launch at row strides B, B + 256, B + 768')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -348,21 +349,22 @@ def run(a):
     stride_probe = None
     if rank == 0 and not a.no_stride_probe and B >= (1 << 19):
         stride_probe = {}
-        pads = (0, 256, 768)
+        pads = tuple(int(x) for x in a.stride_pads.split(','))
         probes = {}
         try:
             for pad in pads:
                 ldp = B + pad
+                # exactly the headline's set-up: NBUF independent mask / reward / flag sets used round-robin
                 pm = [torch.empty((T, ldp), dtype=torch.int32, device=dev)[:, :B] for _ in range(NBUF)]
-                pr = torch.empty((T, ldp), dtype=torch.float32, device=dev)[:, :B]
-                pf = torch.empty((T, ldp), dtype=torch.uint8, device=dev)[:, :B]
+                pr = [torch.empty((T, ldp), dtype=torch.float32, device=dev)[:, :B] for _ in range(NBUF)]
+                pf = [torch.empty((T, ldp), dtype=torch.uint8, device=dev)[:, :B] for _ in range(NBUF)]
                 for k in range(NBUF):
                     env.seed(a.seed + k)
                     _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(pm[k].data_ptr()), ldp, stream))
                 sc = torch.zeros(2, dtype=torch.int64, device=dev)
                 probes[pad] = (pm, pr, pf, sc,
                                [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=pm[k].data_ptr(),
-                                                 d_reward_tb=pr.data_ptr(), d_flags_tb=pf.data_ptr(), ld_masks=ldp, ld_out=ldp,
+                                                 d_reward_tb=pr[k].data_ptr(), d_flags_tb=pf[k].data_ptr(), ld_masks=ldp, ld_out=ldp,
                                                  d_success_count=sc.data_ptr()) for k in range(NBUF)])
             env.seed(a.seed)
             best = {pad: [] for pad in pads}

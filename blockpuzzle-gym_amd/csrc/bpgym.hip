@@ -861,20 +861,8 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
                                                    int64_t e0, int64_t n, int lane)
 {
     constexpr bool PAIRS = TT % 2 == 0;          // rows are whole 16-byte pieces: 16-byte LDS and global accesses
-    if constexpr (TR == 0) {
-        // no tile: every lane writes its own row (400-byte stride between lanes: every store instruction touches
-        // 64 lines; the L2 has to merge the pieces) -- kept for the A/B in tools/tune_round3, not used by the library
-        if (e0 + lane < n) {
-            double2 *row = reinterpret_cast<double2 *>(G + (e0 + lane) * TT);
-            static_for<0, TT / 2>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                row[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
-            });
-        }
-        return;
-    }
 #pragma unroll
-    for (int c = 0; c < 64 / (TR ? TR : 64); c++) {
+    for (int c = 0; c < 64 / TR; c++) {
         if (c) wave_lds_sync();                                          // previous quarter streamed out
         if ((lane / TR) == c) {
             double *row = tile + (lane % TR) * TT;
@@ -1945,145 +1933,11 @@ k_success_count(const uint32_t *__restrict__ ever, int64_t n, CountArgs ca)
 // policy_gradient/rollout.py:255-258: G[t_] starts as r[t_] and adds gamma**(t-t_) * r[t] for
 // t = t_+1.. in increasing t (float64, products and sums rounded separately, so the result matches
 // the reference's NumPy bit for bit).  gamma**k (C pow, as Python computes it) comes in through
-// the kernel arguments.
-//
-// The loop nest is the reference's own -- OUTER over the step t that brings a new reward, INNER over
-// the returns t_ < t it is added to -- so the additions of one outer step are independent chains.
-// That matters because an f64 result is ~60 cycles away on gfx950 (tools/valu_rates.hip: eight
-// independent products followed by eight additions still run at 8.6 cycles per instruction for a
-// wave on its own, 3.4 with four waves per SIMD): round 1's nest (one accumulator, 2 * (T-1-t_)
-// dependent operations per return, 255 VGPRs, one wave per SIMD) spent 59 % of its wave cycles in
-// issue stalls.  What it takes is occupancy, so each env is split over TWO lanes:
-//   lane (e, q), q = lane / 32, owns the returns t_ = 2i + q and consumes the reward of step
-//   t = s + q at "virtual step" s.  Then acc[i] += pw[s - 2i] * r[t] has the SAME table index for
-//   both halves of the wave (t - t_ = s - 2i either way): one instruction stream, uniform (SGPR)
-//   constants, 25 instead of 50 accumulators per lane -> ~100 VGPRs, 3-4 waves per SIMD.
-// Products are issued DR_W at a time into their own registers before the DR_W additions.
-constexpr int DR_W = 16;
-
-// The waves of a block work on consecutive 32-env groups and never exchange anything: their LDS tiles
-// are private and synchronised at wave scope, the block only makes the four waves' 128-byte pieces of a
-// reward row arrive at the memory side together.
-constexpr int DR_WPB = 4;
-
-// STAGE: the rewards wait in LDS instead of registers.  Lane (e, q) fetches the rows t = 2i + q of env e
-// (NI requests instead of TT: each reward is requested once per wave, not once per half) into a
-// [TT][32] float tile that shares its LDS with the output tile, and virtual step s reads
-// stage[s + q][e]: 25 transient VGPRs instead of 50 live ones.  W = products issued ahead of their
-// additions.
-template <int TT, int WPB = DR_WPB, bool STAGE = true, int W = DR_W>
-__global__ void __launch_bounds__(64 * WPB)
-k_discounted_return_reg(const float *__restrict__ reward_tb, int64_t n, int64_t ld, PowTable pw,
-                        double *__restrict__ G)
-{
-    constexpr int NI = (TT + 1) / 2;          // accumulators per lane (half 1 leaves the last one unused when T is odd)
-    // Row stride of the 16 x T output tile.  Even T: dense rows -- lane (e, q) writes element 2i + q of
-    // row e, 100 e + 2 (2i + q) in bank units, which is conflict-free over the 16 x 2 active lanes --
-    // so that the tile is the output image itself and streams out with 16-byte accesses.  Odd T: rows
-    // padded to an odd length (T | 1), 8-byte accesses.
-    constexpr bool DENSE = TT % 2 == 0;
-    constexpr int R = DENSE ? TT : (TT | 1);
-    constexpr int TILE_BYTES = (16 * R * 8 > TT * 32 * 4) ? 16 * R * 8 : TT * 32 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TILE_BYTES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, e = lane & 31, q = lane >> 5;
-    double *tile = reinterpret_cast<double *>(lds_raw[wave]);
-    float *stage = reinterpret_cast<float *>(lds_raw[wave]);
-    const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 32;
-    if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
-    const int nvalid = (int)((n - base) < 32 ? (n - base) : 32);
-    const bool live = e < nvalid;
-    // Row bases are uniform (scalar unit), the per-lane part is ONE 32-bit byte offset (env within the
-    // row, plus one row for the upper half of the wave): no per-load address arithmetic on the vector
-    // unit.  ld = row stride of the (T, ld) reward stream; the host guarantees 8 * ld < 2^32.
-    const uint32_t voff = (uint32_t)((int64_t)q * ld + base + (live ? e : 0)) * 4u;
-    float rw[STAGE ? 1 : TT];                 // !STAGE: rw[s] = reward of step s + q
-    if constexpr (STAGE) {
-        float tmp[NI];
-        static_for<0, NI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)(2 * i) * ld);
-            tmp[i] = (2 * i + 1 < TT || q == 0) ? *reinterpret_cast<const float *>(row + voff) : 0.0f;
-        });
-        static_for<0, NI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (2 * i + 1 < TT || q == 0) stage[(2 * i + q) * 32 + e] = tmp[i];
-        });
-        wave_lds_sync();
-    } else {
-        static_for<0, TT>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            const char *row = reinterpret_cast<const char *>(reward_tb + (int64_t)s * ld);
-            rw[s] = (s + 1 < TT || q == 0) ? *reinterpret_cast<const float *>(row + voff) : 0.0f;
-        });
-    }
-    double acc[NI];
-    // STAGE: the reward of virtual step s + 1 is requested from LDS before the arithmetic of step s
-    // (the sched_barriers below keep the compiler from moving the read), so its latency is never exposed
-    float rcur = 0.0f, rnext = 0.0f;
-    if constexpr (STAGE) rcur = stage[q * 32 + e];
-    static_for<0, TT>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (STAGE && s + 1 < TT) {
-            if (s + 2 < TT || q == 0) rnext = stage[(s + 1 + q) * 32 + e];
-        }
-        // half 1 is one step ahead: its last virtual step would be t = T
-        if (s + 1 < TT || q == 0) {
-            double rt;
-            if constexpr (STAGE) rt = (double)rcur;
-            else rt = (double)rw[s];
-            if constexpr (s % 2 == 0) acc[s / 2] = rt;                     // t_ == t: G[t_] starts as r[t_]
-            constexpr int npair = (s + 1) / 2;                             // returns 2i (+q) < t
-            static_for<0, (npair + W - 1) / W>([&](auto gc) {
-                constexpr int i0 = decltype(gc)::value * W;
-                constexpr int cnt = (npair - i0) < W ? (npair - i0) : W;
-                double prod[W];
-                static_for<0, cnt>([&](auto jc) {
-                    constexpr int i = i0 + decltype(jc)::value;
-                    prod[decltype(jc)::value] = pw.v[s - 2 * i] * rt;
-                });
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, cnt>([&](auto jc) {
-                    constexpr int i = i0 + decltype(jc)::value;
-                    acc[i] = acc[i] + prod[decltype(jc)::value];
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        rcur = rnext;
-    });
-    if constexpr (STAGE) wave_lds_sync();     // every lane is done reading the staged rewards
-    // 16 envs x T at a time through LDS (6.5 KB per wave: the LDS does not cap the occupancy below
-    // what the registers allow), each pass streamed out as one contiguous 16 * T * 8-byte piece of G
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int e0 = pass * 16;
-        if (pass) wave_lds_sync();                       // first half streamed out
-        if (live && (e >> 4) == pass) {
-            static_for<0, NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                if (2 * i + q < TT) tile[(e - e0) * R + 2 * i + q] = acc[i];
-            });
-        }
-        wave_lds_sync();
-        const int rows = nvalid - e0 < 16 ? (nvalid - e0 < 0 ? 0 : nvalid - e0) : 16;
-        double *o = G + (base + e0) * (int64_t)TT;
-        const int total = rows * TT;
-        if constexpr (DENSE) {
-            // (base + e0) * T * 8 bytes is a multiple of 16 * T * 8: 16-byte aligned
-            const double2 *t2 = reinterpret_cast<const double2 *>(tile);
-            double2 *o2 = reinterpret_cast<double2 *>(o);
-            for (int f = lane; f < total / 2; f += 64) o2[f] = t2[f];
-        } else {
-            int ee = 0, rem = lane;
-            while (rem >= TT) { rem -= TT; ee++; }
-            for (int f = lane; f < total; f += 64) {
-                o[f] = tile[ee * R + rem];
-                rem += 64;
-                while (rem >= TT) { rem -= TT; ee++; }
-            }
-        }
-    }
-}
+// the kernel arguments.  The loop nest is the reference's own -- OUTER over the step t that brings a
+// new reward, INNER over the returns t_ < t it is added to -- so the additions of one outer step are
+// independent chains (an f64 result is ~60 cycles away on gfx950, profiles/r02_valu_rates.log).
+// T = 50 / 25 / 10 run in registers, one env per lane (k_discounted_return_lane below; rounds 1 and 2 had
+// one and two lanes per env with all 2 450 operations -- git history); every other horizon here:
 
 // any T up to DR_TMAX: returns accumulate in the LDS tile (row of the lane), four at a time so
 // that independent chains overlap; the gamma**k table travels in the kernel arguments as well
@@ -2156,7 +2010,7 @@ __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
                          double *__restrict__ G)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][(TR ? TR : 1) * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
     if (base >= n) return;                    // whole wave out of range (no block-wide barrier below)
@@ -2272,7 +2126,7 @@ __global__ void __launch_bounds__(64 * WPB)
 k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
                            int64_t n)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][(TR ? TR : 1) * TT * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // grid-stride over 64-env tiles (one tile per wave when the grid covers the batch)
     for (int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64; base < n; base += (int64_t)gridDim.x * WPB * 64) {
@@ -2956,9 +2810,11 @@ int bpg_synth_masks_ld(bpg_batch *b, int t0, int T, uint32_t *d_masks, int64_t l
 // Row stride for the time-major (T, ld) streams of an n-env batch.  A wave keeps 5-10 rows of the
 // same columns in flight, and rows a large power of two apart put all of them on the same HBM
 // channels: measured at 2^20 .. 2^23 envs, 53-68 % of peak with ld = n against 67-75 % with every row
-// shifted by 0.5-1.5 KB (profiles/r02_tune_row_stride.log; a 128-byte shift is worse than none, a
-// 16 KB shift as bad as none; the gain is largest on the boxes where ld = n is slowest).  Below 2^20
-// envs the shift does not pay (neutral up to 2^18, -2 % at 2^19 and 3 * 2^18).
+// shifted by an odd number of KB (profiles/r02_tune_row_stride.log; a 128-byte shift is worse than none, a
+// 16 KB shift as bad as none, 2 KB as bad as none on most boxes).  Among the odd shifts (1, 3, 5, 9 KB) there is
+// no winner: bench.py's row_stride_probe on a dozen box sessions (profiles/r03_row_stride_probes.log) has them
+// within +-5 % of each other in either direction -- as far apart as two allocations of the SAME layout in one
+// process.  Below 2^20 envs the shift does not pay (neutral up to 2^18, -2 % at 2^19 and 3 * 2^18).
 // ld = n below 2^20; otherwise n rounded up to 256 elements, plus 256 when that leaves an even multiple.
 int64_t bpg_row_stride(int64_t n)
 {

@@ -4,7 +4,8 @@
 //   B  the success count at small batches: none / one atomic per block on one word / sharded (the library's);
 //   C  the policy-gradient path at 1 M envs: rollout + reward stream + return kernel (round 2) against rollout +
 //      step-ok words + expansion kernel;
-//   D  the return kernels on their own: round 2's two-lanes-per-env form, the lane-per-env exact form, the scan.
+//   D  the return kernels on their own: the lane-per-env exact form (plain / general rewards), the scan, the expansion
+//      from step-ok words (round 2's two-lanes-per-env kernel was timed beside them until it was removed: profiles/r03_tune_return_kernels.log).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/tune_round3 tools/tune_round3.hip
 //   ./tools/tune_round3 A 131072 262144 | B 65536 | C 1048576 | D 1048576
 #include "../blockpuzzle-gym_amd/csrc/bpgym.hip"
@@ -143,11 +144,8 @@ static int run(char mode, int64_t B)
         const double gbytes = (double)B * (8 + 8 * T), rbytes = (double)B * T * 12;
         constexpr int WPB = DR_LANE_WPB;
         const dim3 lg((unsigned)((B + 64 * WPB - 1) / (64 * WPB))), lb(64 * WPB);
-        const dim3 og((unsigned)((B + 32 * DR_WPB - 1) / (32 * DR_WPB))), ob(64 * DR_WPB);
         for (int rep = 0; rep < 2; rep++) {
             ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024);                       // round 2: reward + flags streams ...
-            TIME("  + k_discounted_return_reg<50> (round 2)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_reg<50>), og, ob, 0, 0, (const float *)R, B, b.LD, pw, GG));
             TIME("  + k_discounted_return_lane<50, exact>", rbytes,
                  hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
             ROLL(2, 1024, 5, false, 2, 2, 1, 1, 1024);                       // flags + step-ok words ...
@@ -159,12 +157,9 @@ static int run(char mode, int64_t B)
         const double rbytes = (double)B * T * 12;
         constexpr int WPB = DR_LANE_WPB;
         const dim3 lg((unsigned)((B + 64 * WPB - 1) / (64 * WPB))), lb(64 * WPB);
-        const dim3 og((unsigned)((B + 32 * DR_WPB - 1) / (32 * DR_WPB))), ob(64 * DR_WPB);
         // rewards of a real rollout in every buffer set
         for (int k = 0; k < b.NB; k++) { rot = k; ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); }
         for (int rep = 0; rep < 3; rep++) {
-            TIME("k_discounted_return_reg<50> (round 2, two lanes per env)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_reg<50>), og, ob, 0, 0, (const float *)R, B, b.LD, pw, GG));
             TIME("k_discounted_return_lane<50, exact> (plain rewards)", rbytes,
                  hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
             TIME("k_discounted_return_lane<50, scan>", rbytes,
