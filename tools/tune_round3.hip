@@ -11,6 +11,7 @@
 #include "../blockpuzzle-gym_amd/csrc/bpgym.hip"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -209,9 +210,84 @@ static int run(char mode, int64_t B)
     return 0;
 }
 
+// E: where the three streams of a launch sit relative to each other.  Separate allocations of this size all start on a
+// 2 MB boundary, so row t of the masks and row t of the rewards (same row stride) alias modulo 2 MB.  One arena per
+// buffer set with the reward / flag streams skewed against the mask stream by skew_r / skew_f bytes; per-launch event
+// times grouped by buffer set (min / mean / max over the sets show the placement-to-placement variance).
+static int run_skew(int64_t B)
+{
+    const int T = 50, NSET = 6, REPSE = 8;
+    const int64_t LD = bpg_row_stride(B);
+    const size_t mbytes = (size_t)LD * T * 4, fbytes = (size_t)LD * T;
+    uint32_t *now, *ever; CK(hipMalloc(&now, B * 4)); CK(hipMalloc(&ever, B * 4));
+    hipLaunchKernelGGL(k_init, dim3(2048), dim3(256), 0, 0, now, ever, B, 6u);
+    uint32_t *d_counter; CK(hipMalloc(&d_counter, 8)); CK(hipMemset(d_counter, 0, 8));
+    unsigned long long *cnt, *shards; CK(hipMalloc(&cnt, 16)); CK(hipMemset(cnt, 0, 16));
+    CK(hipMalloc(&shards, COUNT_SHARDS * COUNT_SHARD_STRIDE * 8)); CK(hipMemset(shards, 0, COUNT_SHARDS * COUNT_SHARD_STRIDE * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const StepConst c = mk_c(); SynthConst s = mk_s();
+    ResetConst rc{}; rc.enabled = 1; rc.is_variation = 1; rc.base_nobj = 6; rc.seed0 = 1; rc.reset_counter = d_counter;
+    CountArgs ca{cnt, cnt + 1, shards};
+    const double bytes = (double)B * (T * 9 + 12);
+    printf("== mode E  B = %lld envs, T = %d, LD = %lld: stream placement inside one arena per buffer set (%d sets)\n", (long long)B, T, (long long)LD, NSET);
+    const size_t skews[][2] = {{0, 0}, {1024, 2048}, {3072, 5120}, {65536 + 1024, 131072 + 3072}, {4096, 8192}, {1 << 20, 1 << 19},
+                               {(1 << 20) + 1024, (1 << 19) + 3072}, {SIZE_MAX, SIZE_MAX}};
+    for (auto &sk : skews) {
+        const bool separate = sk[0] == SIZE_MAX;          // three allocations per set (what torch.empty gives)
+        std::vector<char *> arena(NSET, nullptr);
+        std::vector<uint32_t *> M_(NSET), R_(NSET); std::vector<uint8_t *> F_(NSET);
+        for (int k = 0; k < NSET; k++) {
+            if (separate) {
+                CK(hipMalloc(&M_[k], mbytes)); CK(hipMalloc(&R_[k], mbytes)); CK(hipMalloc(&F_[k], fbytes));
+            } else {
+                CK(hipMalloc(&arena[k], 2 * mbytes + fbytes + (8 << 20)));
+                M_[k] = (uint32_t *)arena[k];
+                R_[k] = (uint32_t *)(arena[k] + mbytes + sk[0]);
+                F_[k] = (uint8_t *)(arena[k] + 2 * mbytes + sk[0] + sk[1]);
+            }
+            s.seed0 = 1 + k;
+            for (int t = 0; t < T; t++)
+                hipLaunchKernelGGL(k_synth_masks, dim3(2048), dim3(256), 0, 0, ever, B, t, 1, M_[k] + (int64_t)t * LD, LD, s);
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<double> per_set(NSET, 0.0);
+        for (int r = 0; r < REPSE + 2; r++)
+            for (int k = 0; k < NSET; k++) {
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) per_set[k] += ms / REPSE;
+            }
+        // and the launch train over all sets (no event between launches)
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 10; r++)
+            for (int k = 0; k < NSET; k++)
+                hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float tot; CK(hipEventElapsedTime(&tot, e0, e1));
+        double mn = 1e9, mx = 0, mean = 0;
+        for (double v : per_set) { mn = std::min(mn, v); mx = std::max(mx, v); mean += v / NSET; }
+        if (separate) printf("separate allocations            ");
+        else printf("skew reward %8zu flags %8zu", sk[0], sk[1]);
+        printf("  per set (event pairs): min %6.2f mean %6.2f max %6.2f us   train %6.2f us (%4.1f%% of 8 TB/s)   sets:", mn * 1e3, mean * 1e3,
+               mx * 1e3, tot / (10 * NSET) * 1e3, bytes / (tot / (10 * NSET)) / 1e6 / 80.0);
+        for (double v : per_set) printf(" %.1f", v * 1e3);
+        printf("\n"); fflush(stdout);
+        for (int k = 0; k < NSET; k++) {
+            if (separate) { (void)hipFree(M_[k]); (void)hipFree(R_[k]); (void)hipFree(F_[k]); }
+            else (void)hipFree(arena[k]);
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 3) { printf("usage: tune_round3 A|B|C|D envs...\n"); return 1; }
+    if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E envs...\n"); return 1; }
+    if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
         if (run(argv[1][0], atoll(argv[i]))) return 1;
     return 0;
