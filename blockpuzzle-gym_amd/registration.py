@@ -67,8 +67,9 @@ def register_with_gym(prefix=''):
     """Optional: if the real `gym` package is installed, register the seven ids with it
     (same names, max_episode_steps=50, kwargs={'reward_type': 'sparse'} as
     gym_blocks/__init__.py:6-53), so `gym.make('BlocksTouch-v0')` returns the drop-in single
-    env.  gym is not a dependency and is absent from the build image, so this path is
-    untested there; returns the list of ids registered (empty if gym is missing)."""
+    env.  gym is not a dependency and is absent from the build image: the call is tested against
+    a recording stand-in for gym.envs.registration (tests/test_abi_cpu.py); returns the list of ids
+    registered (empty if gym is missing)."""
     try:
         from gym.envs.registration import register as gym_register
     except Exception:  # noqa: BLE001
