@@ -214,10 +214,29 @@ def launch_ranks(a, argv):
     return 0 if ok else 1
 
 
+_RESULT_FD = None
+
+
+def emit(line):
+    """The ONE JSON line of the run, on the process's original stdout."""
+    data = (json.dumps(line) + '\n').encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
+    global _RESULT_FD
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a, sys.argv[1:]))
+    # Libraries print to stdout behind our back (RCCL its version banner, gloo its connection report): while the
+    # bench runs, file descriptor 1 points at stderr, and only the result line goes to the real stdout.
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     try:
         run(a)
     except SystemExit:
@@ -226,7 +245,10 @@ def main():
         rank = int(os.environ.get('RANK', '0'))
         traceback.print_exc()
         line = error_line('%s: %s' % (type(e).__name__, str(e)[:500]), a, rank=rank)
-        print(json.dumps(line), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+        if rank == 0:
+            emit(line)
+        else:
+            print(json.dumps(line), file=sys.stderr, flush=True)
         sys.exit(2)
 
 
@@ -507,7 +529,7 @@ def run(a):
     if multi:
         dist.barrier()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if multi:
         dist.destroy_process_group()
 
