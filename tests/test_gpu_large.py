@@ -110,3 +110,36 @@ def test_episode_arrays_beyond_2_31_elements():
     slot = torch.empty_like(ag)
     big2.step(None, contact_masks=masks[0], ag_out=slot[:, 1])
     assert torch.equal(slot[:, 1], ag[:, 1])
+
+
+def test_return_from_step_ok_words_at_full_size_and_beyond_2_31_elements():
+    """bpg_rollout(d_G) at BASELINE's 1 048 576 envs and at 45 M envs (G holds 2.25e9 float64): the rows of the
+    rollout call == the rows bpg_discounted_return computes from the reward stream the same call wrote (that
+    kernel is pinned to the oracle at small sizes), bit for bit over the WHOLE batch; plus the size-independent
+    recurrence |G[t] - (r[t] + gamma G[t+1])| <= 1e-12 and G[:, T-1] == r[T-1] everywhere."""
+    L = bpg._lib.lib()
+    gamma = 1.0 - 1.0 / T
+    for B in (1 << 20, 45_000_002):
+        env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=8)
+        masks = torch.empty((T, B), dtype=torch.int32, device=DEV)
+        bpg._lib.check(L.bpg_synth_masks(env._h, 0, T, P(masks), None))
+        reward = torch.empty((T, B), dtype=torch.float32, device=DEV)
+        G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+        ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 5) % 3
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
+                                 d_reward_tb=reward.data_ptr(), d_G=G.data_ptr(), gamma=gamma)
+        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        # the last column is the last reward; the recurrence holds within rounding, chunk by chunk (memory)
+        step = 1 << 22
+        for lo in range(0, B, step):
+            g = G[lo:lo + step]
+            r = reward[:, lo:lo + step].t().double()
+            assert torch.equal(g[:, T - 1].view(torch.int64), r[:, T - 1].contiguous().view(torch.int64))
+            assert float((g[:, :-1] - (r[:, :-1] + gamma * g[:, 1:])).abs().max()) <= 1e-12
+            del g, r
+        G2 = torch.empty((B, T), dtype=torch.float64, device=DEV)
+        bpg._lib.check(L.bpg_discounted_return(P(reward), B, T, gamma, P(G2), 0, None))
+        for lo in range(0, B, step):
+            assert torch.equal(G[lo:lo + step].view(torch.int64), G2[lo:lo + step].view(torch.int64))
+        del G, G2, masks, reward, env
+        torch.cuda.empty_cache()
