@@ -8,6 +8,7 @@ achieved_goal, reward bits, the is_success latch, TimeLimit's done.  Bit-exact t
 The oracle side follows fetch_env.py:148-167 (_step_callback), :135-143 (compute_reward),
 :275-281 (_is_success), :247-255 / :646-679 (_reset_sim) and gym's TimeLimit."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -73,7 +74,8 @@ def check_step(ret, exp):
 @pytest.mark.parametrize('env_id', ENV_IDS)
 @pytest.mark.parametrize('B', [193, 1])
 def test_random_api_sequences_vs_oracle(env_id, B):
-    rng = np.random.RandomState(1000 * B + len(env_id))
+    # BPG_FUZZ_SEED shifts the sequence (soak runs: `for s in 1 2 3 ...; do BPG_FUZZ_SEED=$s pytest tests/test_gpu_fuzz.py`)
+    rng = np.random.RandomState(1000 * B + len(env_id) + 7919 * int(os.environ.get('BPG_FUZZ_SEED', '0')))
     L = bpg._lib.lib()
     env = bpg.make(env_id, num_envs=B, device=DEV, seed=3)
     mir = Mirror(env_id, B)

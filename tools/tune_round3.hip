@@ -133,6 +133,13 @@ static int run(char mode, int64_t B)
             ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); ROLL(2, 512, 5, false, 3, 2, 1, 0, 1024);
             ROLL(2, 256, 10, true, 3, 2, 1, 0, 256);
         }
+    } else if (mode == 'F') {                    // the bandwidth-bound sizes: capped (resident) vs uncapped grids, rows in flight
+        for (int rep = 0; rep < 3; rep++) {
+            ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); ROLL(2, 1024, 5, false, 3, 2, 0, 0, 1024);
+            ROLL(2, 1024, 10, false, 3, 2, 1, 0, 1024); ROLL(2, 1024, 10, false, 3, 2, 0, 0, 1024);
+            ROLL(2, 512, 5, false, 3, 2, 1, 0, 1024); ROLL(2, 512, 5, false, 3, 2, 0, 0, 1024);
+            ROLL(2, 256, 5, false, 3, 2, 1, 0, 256); ROLL(2, 256, 5, false, 3, 2, 0, 0, 256);
+        }
     } else if (mode == 'B') {
         TIME("empty kernel (launch floor)", 1.0, hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, b.d_counter));
         for (int rep = 0; rep < 2; rep++) {
@@ -286,7 +293,7 @@ static int run_skew(int64_t B)
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E envs...\n"); return 1; }
+    if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
         if (run(argv[1][0], atoll(argv[i]))) return 1;
