@@ -331,7 +331,7 @@ def run(a):
                              d_success_count=stats.data_ptr() + 16 * i) for i in range(n_it)]
     # ONE pair of HIP events on the launch stream around the K timed launches: the kernel's average
     # duration = elapsed / K.  (An event pair around every launch puts two marker packets between
-    # consecutive kernels: +2.4 us per launch on this stream, measured with tools/tune_geometry.)
+    # consecutive kernels: +2.4 us per launch on this stream, measured with round 2's tools/tune_geometry.)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     works = []

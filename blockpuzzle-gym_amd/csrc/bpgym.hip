@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t nobj_of(uint32_t ever) { return (ever >> NOB
 
 // Write-once reward / flag streams of the fused rollout use nontemporal stores:
 // they are never re-read by these kernels, and keeping them out of the L2 /
-// Infinity Cache leaves it to the inputs (tools/tune_rollout.hip: 86 vs 88 us
+// Infinity Cache leaves it to the inputs (round 1's tools/tune_rollout.hip, profiles/r01_tune_rollout_variants.log: 86 vs 88 us
 // with cold inputs, 75 vs 88 us when the masks are cache-resident).  The
 // write-only episode streams stay plain stores: a pure float4 fill runs 5.1 TB/s
 // plain vs 4.8 TB/s nontemporal on MI355X, and the episode writer follows it.
@@ -358,7 +358,7 @@ template <int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec pack(co
     else if constexpr (EPL == 2) return make_uint2(o[0], o[1]);
     else return o[0];
 }
-// mask stream: read exactly once per launch -> nontemporal loads (tools/tune_geometry.hip: NTL)
+// mask stream: read exactly once per launch -> nontemporal loads (profiles/r02_tune_geometry_nontemporal_loads.log)
 template <bool NTL, int EPL> __device__ __forceinline__ typename LaneVec<EPL>::vec ld_vec(const typename LaneVec<EPL>::vec *p)
 {
     if constexpr (!NTL) return *p;
@@ -2350,21 +2350,20 @@ int fat_grid(int64_t work_items)
     return (int)g;
 }
 
-// Launch shape of the fused rollout, chosen from the batch size (tools/tune_geometry.hip,
-// profiles/r02_tune_geometry.log; MI355X, T = 50, masks read cold from HBM).  The kernel is a pure
-// stream with T independent requests per lane, so what matters is (a) enough resident waves on
-// every CU to cover the HBM latency and (b), when there are not, that no wave waits for a store
-// round trip before it can consume a load (the pipelined loop).  Measured kernel time per launch:
-//     envs        plain 4/lane x 1024 (round 1)     chosen shape (contiguous rows)
-//     65 536      49 us                              10.1 us  1/lane, 256-lane blocks, pipelined
-//     131 072     45 us                              15.2 us  2/lane, 256, pipelined
-//     262 144     52 us                              24.8 us  2/lane, 256, pipelined
-//     524 288     58 us                              43-46 us 2/lane, 1024, plain
-//     1 048 576   89 us                              88-101 us 2/lane, 1024, plain   (80-86 us with shifted rows)
-//     4 194 304   372 us                             355 us   2/lane, 256, pipelined (317-322 us, 2/lane x 1024, shifted rows)
-// "Shifted rows": the row stride bpg_row_stride() recommends (profiles/r02_tune_row_stride.log).
+// Launch shape of the fused rollout, chosen from the batch size (tools/tune_round3.hip mode A,
+// profiles/r03_tune_mid_shapes.log; round 2: profiles/r02_tune_geometry.log; MI355X, T = 50, masks read cold
+// from HBM).  The kernel is a pure stream with T independent requests per lane, so what matters is (a) enough
+// resident waves on every CU to cover the HBM latency and (b), when there are not, that no wave waits for a
+// store round trip before it can consume a load (the pipelined loop).  rocprofv3 means per launch
+// (profiles/r03_pmc/kernel_means.json), round 1's plain 4/lane x 1024 shape in parentheses:
+//     65 536      9.9 us  (49)   1/lane, 256-lane blocks, pipelined, 10 rows in flight
+//     131 072    14.5 us  (45)   1/lane, 256, pipelined, 5 rows in flight
+//     262 144    23.5 us  (52)   2/lane, 256, plain loop
+//     524 288    43.8 us  (58)   2/lane, 1024, plain
+//     1 048 576  82-91 us (89)   2/lane, 1024, plain (shifted rows, bpg_row_stride; box-dependent)
+//     4 194 304  351 us   (372)  2/lane, 256, plain, when the rows are a power of two apart (1024 lanes: 468 us)
 // 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
-// 4-per-lane instantiation.  One success-count atomic per block (block_count_add).
+// 4-per-lane instantiation.  One returning atomic per block on a sharded counter (block_count_add).
 constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
 struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
