@@ -581,6 +581,12 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
             res['rollout_masks_%d_envs' % Bx] = rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line)
         except Exception as e:  # noqa: BLE001
             res['rollout_masks_%d_envs' % Bx] = {'error': repr(e)[:200]}
+    # ... and the evaluator's n_test_rollouts = 10 (config.py:43) rollouts of configs[1] in ONE launch
+    try:
+        res['rollout_masks_65536_envs_10_rollouts_per_launch'] = rollout_at(torch, bpg, _lib, 65536, T, dev, stream, timed,
+                                                                            line, rollouts=10)
+    except Exception as e:  # noqa: BLE001
+        res['rollout_masks_65536_envs_10_rollouts_per_launch'] = {'error': repr(e)[:200]}
 
     # (1) one env.step launch: 12 B in (now, ever, mask) + 13 B out (now, ever, reward, flags) = 25 B/env-step
     # (SURVEY 8d's per-step form).  One batch stepped over and over keeps its 26 MB in the Infinity Cache ...
@@ -786,33 +792,38 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     return res
 
 
-def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line):
+def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1):
     """The bench headline (one fused reset + T-step + success-count launch, masks from HBM) at
-    another batch size."""
+    another batch size; rollouts = K > 1: K consecutive rollouts (the evaluator's loop, train.py:63-64)
+    in ONE launch, every figure per rollout."""
     L = _lib.lib()
+    K = rollouts
     e = bpg.make(ENV_ID, num_envs=Bx, device=dev, seed=7)
-    ng = (torch.arange(Bx, device=dev, dtype=torch.int32) * 7) % 3
-    e.reset(num_grey=ng)
-    nset = int(2.5 * 256 * 2**20 // (Bx * T * 9)) + 1
+    ng = ((torch.arange(K * Bx, device=dev, dtype=torch.int32) * 7) % 3).reshape(K, Bx)
+    e.reset(num_grey=ng[0])
+    nset = int(2.5 * 256 * 2**20 // (K * Bx * T * 9)) + 1
     sets = []
     for k in range(nset):
         e.seed(7 + k)
-        m = bpg.time_major_empty(T, Bx, torch.int32, dev)        # rows bpg_row_stride(Bx) apart, as the headline
+        m = bpg.time_major_empty(K * T, Bx, torch.int32, dev)    # rows bpg_row_stride(Bx) apart, as the headline
         ld = int(m.stride(0))
-        _lib.check(L.bpg_synth_masks_ld(e._h, 0, T, C.c_void_p(m.data_ptr()), ld, stream))
-        sets.append((m, bpg.time_major_empty(T, Bx, torch.float32, dev), bpg.time_major_empty(T, Bx, torch.uint8, dev)))
-    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-    args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=ld, ld_out=ld,
-                             d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
+        _lib.check(L.bpg_synth_masks_ld(e._h, 0, K * T, C.c_void_p(m.data_ptr()), ld, stream))
+        sets.append((m, bpg.time_major_empty(K * T, Bx, torch.float32, dev), bpg.time_major_empty(K * T, Bx, torch.uint8, dev)))
+    cnt = torch.zeros(max(2, K), dtype=torch.int64, device=dev)
+    args = [_lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=ld,
+                             ld_out=ld, d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
             for m, r, f in sets]
     it = [0]
 
     def go():
         _lib.check(L.bpg_rollout(e._h, C.byref(args[it[0] % nset]), stream))
         it[0] += 1
-    out = line(timed(go, max(40, 2 * nset)), Bx * (T * 9 + 12), Bx * T)
+    out = line(timed(go, max(40, 2 * nset)) / K, Bx * (T * 9 + 12), Bx * T)
     out['buffer_sets'] = nset
     out['note'] = 'ms = events around a train of back-to-back launches (includes the launch gaps; see launch_floor_smallest_kernel)'
+    if K > 1:
+        out['rollouts_per_launch'] = K
+        out['note'] = 'per rollout: ' + out['note'] + ' / rollouts_per_launch'
     return out
 
 

@@ -35,7 +35,7 @@ class RolloutArgs(C.Structure):
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
         ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
-        ('d_G', C.c_void_p), ('gamma', C.c_double),
+        ('d_G', C.c_void_p), ('gamma', C.c_double), ('rollouts', C.c_int32), ('reserved_', C.c_int32),
     ]
 
 

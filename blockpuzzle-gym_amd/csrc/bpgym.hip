@@ -391,16 +391,17 @@ struct ResetConst {
     const int32_t *num_grey;   // explicit variates for np_random.randint(3) (:647) or NULL
 };
 
-__device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_t i, const ResetConst &rc)
+__device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_t i, const ResetConst &rc,
+                                           uint32_t stream_index_offset = 0u, int64_t variate_offset = 0)
 {
     if (rc.is_variation) {
         uint32_t g;
         if (rc.num_grey) {
-            const int32_t v = rc.num_grey[i];
+            const int32_t v = rc.num_grey[variate_offset + i];
             g = v < 0 ? 0u : (v > 2 ? 2u : (uint32_t)v);
         } else {
             // counter-based stand-in for np_random.randint(3)
-            g = hash32(env_key(rc.seed0, (uint32_t)i, 0xA511E9B3U) + *rc.reset_counter) % 3u;
+            g = hash32(env_key(rc.seed0, (uint32_t)i, 0xA511E9B3U) + *rc.reset_counter + stream_index_offset) % 3u;
         }
         now = 0u;
         ever = (4u + g) << NOBJ_SHIFT;
@@ -514,7 +515,7 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
 
 // Enqueued right after every launch that reset the batch: stream order makes all lanes of the
 // reset see the old value and the next reset the new one, also under hipGraph replay.
-__global__ void k_bump_counter(uint32_t *counter) { *counter += 1u; }
+__global__ void k_bump_counter(uint32_t *counter, uint32_t by) { *counter += by; }
 
 __global__ void __launch_bounds__(256)
 k_init(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, uint32_t nobj)
@@ -908,20 +909,31 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
 // after a wave's steps, was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs,
 // profiles/r03_tune_pg_path.log -- the memory-bound step phase and the VALU-bound return phase of the same
 // waves do not overlap -- and removed.)
-template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false>
+// MULTI: `rollouts` consecutive rollouts in this ONE launch (each: reset, T steps, success count into its own counter
+// word), rollout r on rows r*T .. r*T+T-1 of the streams -- exactly what `rollouts` launches in a row would do, without
+// their fixed cost (5-6 us per launch, which is all a 65 536-env rollout has left to lose).  Envs are independent and a
+// lane only ever touches its own, so nothing has to be synchronised between the rollouts of a launch; the counts go out
+// as plain atomics that drain behind the next rollout's steps.
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
+          bool MULTI = false>
 __global__ void __launch_bounds__(LB)
-k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
-          uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb, int64_t n, int T,
+k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks_all,
+          uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
-          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits)
+          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts)
 {
+    static_assert(!MULTI || (RESET && !OKB), "several rollouts per launch: each starts with its reset; no step-ok words");
     using Vec = typename LaneVec<EPL>::vec;
     using Fl = typename LaneVec<EPL>::fl;
     const int64_t nvec = n / EPL;               // the host guarantees n, ld_masks, ld_out % EPL == 0
     const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint32_t nsucc = 0;
     if (ca.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *ca.zero_next = 0ull;
+    for (int ro = 0; ro < (MULTI ? rollouts : 1); ro++) {
+    const uint32_t *__restrict__ masks = masks_all + (MULTI ? (int64_t)ro * T * ld_masks : 0);
+    uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
+    uint8_t *__restrict__ flags_tb = flags_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
+    uint32_t nsucc = 0;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
         // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
@@ -939,7 +951,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         uint64_t okb[EPL];                          // OKB: bit t = the success condition held at step t
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
-            if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc);
+            if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
             if (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
             cm[k] = an[k] & PAIR_BITS;
             el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
@@ -1070,7 +1082,15 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
         }
     }
-    if (ca.count) block_count_add(nsucc, ca);
+    if (ca.count) {
+        if (MULTI) {
+            block_count_add(nsucc, CountArgs{ca.count + ro, nullptr, nullptr});
+            __syncthreads();                       // the partial sums are written again by the next rollout
+        } else {
+            block_count_add(nsucc, ca);
+        }
+    }
+    }
 }
 
 // ------------------------------ float views ---------------------------------
@@ -2629,7 +2649,7 @@ int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_
                        b->now, b->ever, b->n, reset_const(b, 1, d_num_grey), d_env_mask,
                        static_obs(b, d_obs, ld, true, d_env_mask));
     if (b->info.is_variation && !d_num_grey)     // only generator-drawn resets consume a stream index
-        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter);
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter, 1u);
     return check_launch("k_reset");
 }
 
@@ -2967,7 +2987,7 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
     hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        b->n, pc, d_xy, d_status);
     if (!explicit_draws)
-        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter + 1);
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, (hipStream_t)stream, b->d_reset_counter + 1, 1u);
     return check_launch("k_randomize_objects");
 }
 
@@ -3125,18 +3145,25 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         else gmode = G_FROM_REWARD;
     }
     uint64_t *okbits = gmode == G_OKBITS ? b->d_okbits : nullptr;
+    // several rollouts in one launch (stream path only): rollout r = reset + T steps + count on rows r*T .. of the streams
+    const int rollouts = a->rollouts > 1 ? a->rollouts : 1;
+    if (a->rollouts < 0 || a->rollouts > 4096) return fail(BPG_ERR_ARG, "rollouts must be in 0..4096");
+    if (rollouts > 1 && (!a->reset_first || episode || a->d_G))
+        return fail(BPG_ERR_ARG, "rollouts > 1 needs reset_first and takes neither episode arrays nor d_G");
     int rcode = BPG_OK;
     if (!episode) {
         const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
         const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb);
         const dim3 grid(geo.grid), block(geo.block);
-#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB)                                           \
-        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB>), grid, block, 0, st,  \
-                           b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits)
+#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI)                                    \
+        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, MULTI>), grid, block, 0, st, \
+                           b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits,  \
+                           rollouts)
 #define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
         do {                                                                                                  \
-            if (a->reset_first) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, OKB);                 \
-            else BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, false, UNR, PIPE, LB, OKB);                               \
+            if (rollouts > 1) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, false, true);           \
+            else if (a->reset_first) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, OKB, false);     \
+            else BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, false, UNR, PIPE, LB, OKB, false);                        \
         } while (0)
 #define BPG_LAUNCH_ROLLOUT_1(SRC, EPL, OUT, UNR, PIPE, LB)                                                     \
         do {                                                                                                  \
@@ -3212,7 +3239,7 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     if (rcode == BPG_OK && gmode == G_FROM_REWARD)
         rcode = bpg_discounted_return_ld(a->d_reward_tb, b->n, ldo, a->T, a->gamma, a->d_G, b->device, stream);
     if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey) {
-        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, st, b->d_reset_counter);
+        hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, st, b->d_reset_counter, (uint32_t)rollouts);
         rcode = check_launch("k_bump_counter");
     }
     return rcode;

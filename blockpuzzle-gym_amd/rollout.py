@@ -376,6 +376,51 @@ class RolloutStudent:
             out['G'] = G if self.output == 'torch' else G.cpu().numpy()
         return out
 
+    def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
+                                flags_tb=None):
+        """The evaluator's test loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)`
+        (train.py:63-64, play.py:59) -- with the contacts of all K rollouts read from one stream, in ONE
+        launch: rollout r is reset + T steps on rows r*T .. r*T+T-1 of `masks` ((K*T, B) int32 device
+        tensor, rows may be padded) and appends its success rate to success_history exactly as K calls of
+        generate_rollouts_fused would (rollout.py:163-170); no episode dict is kept, as the test loop
+        drops it.  num_grey: (K, B) explicit draws for BlocksTouchVariation, or None for the env's
+        generator (its next K draws).  reward_tb / flags_tb: optional (K*T, B) float32 / uint8 streams
+        the launch fills (step reward; bit 0 is_success, bit 1 done).  Returns the K success rates."""
+        env, B, T = self.env, self.rollout_batch_size, self.T
+        assert masks.dim() == 2 and masks.shape[1] == B and masks.shape[0] % T == 0 and masks.element_size() == 4 \
+            and masks.stride(1) == 1 and masks.is_cuda
+        K = masks.shape[0] // T
+        if n_rollouts is not None and int(n_rollouts) != K:
+            raise ValueError('masks hold %d rollouts of T = %d rows, n_rollouts = %d' % (K, T, n_rollouts))
+        ld = int(masks.stride(0)) if masks.shape[0] > 1 else B
+        ld_out = 0
+        for s, dt in ((reward_tb, torch.float32), (flags_tb, torch.uint8)):
+            if s is not None:
+                assert s.shape == masks.shape and s.dtype == dt and s.stride(1) == 1 and s.is_cuda
+                lo = int(s.stride(0)) if s.shape[0] > 1 else B
+                if ld_out not in (0, lo):
+                    raise ValueError('reward_tb and flags_tb must share one row stride')
+                ld_out = lo
+        ng = None
+        if num_grey is not None:
+            ng = torch.as_tensor(num_grey).to(self.device, torch.int32).contiguous()
+            assert ng.shape == (K, B)
+        if test and not env.info.set_test_supported:
+            raise NotImplementedError()             # fetch_env.py:100-101, as each of the K calls would
+        # (set_test only re-places the cubes, rollout.py:53-55: with the contacts read from the stream the
+        # placement has no reader, so nothing is placed here)
+        counts = torch.zeros(K, dtype=torch.int64, device=self.device)
+        args = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld_out,
+                                d_num_grey=None if ng is None else ng.data_ptr(),
+                                d_reward_tb=None if reward_tb is None else reward_tb.data_ptr(),
+                                d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
+                                d_success_count=counts.data_ptr())
+        _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
+        rates = [float(c) / B for c in counts.tolist()]
+        self.success_history.extend(rates)
+        self.n_episodes += K * B
+        return rates
+
     # -- rollout.py:174-210 -----------------------------------------------
     def clear_history(self):
         self.success_history.clear()

@@ -315,6 +315,13 @@ typedef struct {
                                   64 < T <= 319: computed from d_reward_tb, which is then required.  8-byte aligned
                                   (16 for the fast T = 50 / 10 forms).  NULL = not produced */
     double gamma;              /* discount of d_G (config.py:83: 1 - 1/T) */
+    int32_t rollouts;          /* 0 / 1: one rollout.  K > 1 (stream path, reset_first = 1, no d_ep_*, no d_G): K consecutive
+                                  rollouts in this ONE launch -- generate_rollouts called K times in a row with nothing
+                                  between the calls (rollout.py:75-172) -- rollout r = reset + T steps on rows r*T .. r*T+T-1
+                                  of d_masks / d_reward_tb / d_flags_tb (K*T rows each), its success count added to
+                                  d_success_count[r] (K words), explicit d_num_grey (K, n_envs) or the generator's next K
+                                  draws.  Same results as K calls; the fixed cost of a launch is paid once. */
+    int32_t reserved_;
 } bpg_rollout_args;
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 

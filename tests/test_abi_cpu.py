@@ -133,7 +133,7 @@ def test_row_stride_helper_is_a_pure_host_function():
         assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
-    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16 + 16
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16 + 16 + 8
 
 
 def test_every_kernel_stub_has_a_device_kernel_of_the_same_name():

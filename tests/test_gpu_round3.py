@@ -384,3 +384,118 @@ def test_rollout_with_return_is_capturable_in_a_hip_graph():
     f = fl.cpu().numpy()
     r = np.where((f >> 2) & 1, np.float32(-0.0), np.float32(-1.0)).astype(np.float32)
     same_bits(want.cpu().numpy()[:200], oracle_G(r[:, :200], gamma))
+
+
+# ------------------------------------------------------------------ several rollouts in one launch
+def _multi_streams(K, T, B, outs):
+    ld = int(L.bpg_row_stride(B))
+    r = torch.full((K * T, ld), float('nan'), dtype=torch.float32, device=DEV)[:, :B] if 'reward' in outs else None
+    f = torch.full((K * T, ld), 0xEE, dtype=torch.uint8, device=DEV)[:, :B] if 'flags' in outs else None
+    return r, f, ld
+
+
+@pytest.mark.parametrize('env_id,explicit', [('BlocksTouchVariation-v0', True), ('BlocksTouchVariation-v0', False),
+                                             ('ToppleTower-v0', False)])
+@pytest.mark.parametrize('B', [300, 65536, 100003, 262144, 1 << 20])
+def test_k_rollouts_in_one_launch_equal_k_launches(env_id, explicit, B):
+    """rollouts = K (the evaluator's loop, train.py:63-64: generate_rollouts K times with nothing between the
+    calls): one launch must leave exactly what K launches leave -- reward and flag rows of every rollout, the K
+    success counts, the final state, and the generator position (the next draw after the K resets) -- at every
+    launch shape, with explicit draws and with the generator's, with all / some / none of the output streams."""
+    K, T = 3, 50 if B <= 262144 else 20
+    gen = torch.Generator(device=DEV).manual_seed(B + K)
+    masks = bpg.time_major_empty(K * T, B, torch.int32, DEV)
+    src = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=B)
+    bpg._lib.check(L.bpg_synth_masks_ld(src._h, 0, K * T, P(masks), int(masks.stride(0)), None))
+    noise = torch.randint(0, 1 << 21, (K * T, B), device=DEV, generator=gen, dtype=torch.int32)
+    for _ in range(6):                                   # ~1 % of the bits, legal or not: raw contact words
+        noise &= torch.randint(0, 1 << 21, (K * T, B), device=DEV, generator=gen, dtype=torch.int32)
+    masks ^= noise
+    ldm = int(masks.stride(0))
+    ng = torch.randint(0, 3, (K, B), device=DEV, generator=gen, dtype=torch.int32) if explicit else None
+    for outs in (('reward', 'flags'), ('flags',), ()):
+        one = bpg.make(env_id, num_envs=B, device=DEV, seed=11)
+        many = bpg.make(env_id, num_envs=B, device=DEV, seed=11)
+        r1, f1, ldo = _multi_streams(K, T, B, outs)
+        rk, fk, _ = _multi_streams(K, T, B, outs)
+        c1 = torch.zeros(K, dtype=torch.int64, device=DEV)
+        ck = torch.zeros(K, dtype=torch.int64, device=DEV)
+        for k in range(K):
+            a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks[k * T:].data_ptr(), ld_masks=ldm, ld_out=ldo if outs else 0,
+                                     d_num_grey=None if ng is None else ng[k].data_ptr(),
+                                     d_reward_tb=None if r1 is None else r1[k * T:].data_ptr(),
+                                     d_flags_tb=None if f1 is None else f1[k * T:].data_ptr(),
+                                     d_success_count=c1[k:].data_ptr())
+            bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ldm, ld_out=ldo if outs else 0,
+                                 d_num_grey=None if ng is None else ng.data_ptr(),
+                                 d_reward_tb=None if rk is None else rk.data_ptr(),
+                                 d_flags_tb=None if fk is None else fk.data_ptr(), d_success_count=ck.data_ptr())
+        bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+        torch.cuda.synchronize()
+        assert torch.equal(c1, ck), (outs, c1.tolist(), ck.tolist())
+        if r1 is not None:
+            assert torch.equal(r1.view(torch.int32), rk.view(torch.int32)) and not torch.isnan(rk).any()
+        if f1 is not None:
+            assert torch.equal(f1, fk)
+            assert [int((fk[k * T + T - 1] & 1).sum().item()) for k in range(K)] == ck.tolist()
+        s1, sk = one.state_dict(), many.state_dict()
+        for key in s1:
+            assert torch.equal(s1[key], sk[key]), key
+        assert len(set(ck.tolist())) > 1 or B < 1000, ck.tolist()    # the rollouts really differ
+        # and the next reset draws the same thing on both
+        one.reset(), many.reset()
+        assert torch.equal(one.num_objs_per_env(), many.num_objs_per_env())
+
+
+def test_k_rollouts_from_the_synthetic_source_and_the_argument_checks():
+    B, K, T = 70001, 4, 50
+    one = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=5)
+    many = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=5)
+    f1, fk = torch.empty((K * T, B), dtype=torch.uint8, device=DEV), torch.empty((K * T, B), dtype=torch.uint8, device=DEV)
+    c1, ck = torch.zeros(K, dtype=torch.int64, device=DEV), torch.zeros(K, dtype=torch.int64, device=DEV)
+    for k in range(K):
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=f1[k * T:].data_ptr(), ld_out=B, d_success_count=c1[k:].data_ptr())
+        bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_flags_tb=fk.data_ptr(), ld_out=B, d_success_count=ck.data_ptr())
+    bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+    torch.cuda.synchronize()
+    assert torch.equal(f1, fk) and torch.equal(c1, ck)
+    # (the synthetic source times its goal contacts by the env key alone, so the K flag blocks are equal by
+    # construction; the draws show in the final state below)
+    for key, v in one.state_dict().items():
+        assert torch.equal(v, many.state_dict()[key]), key
+    # K > 1 without the reset, with episode arrays, with d_G, or negative: refused before any launch
+    before = many.state_dict()
+    G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+    ag = torch.empty((B, T + 1, many.dimg), dtype=torch.float32, device=DEV)
+    for bad in (dict(reset_first=0, rollouts=2), dict(reset_first=1, rollouts=2, d_G=G.data_ptr(), gamma=0.98),
+                dict(reset_first=1, rollouts=2, d_ep_ag=ag.data_ptr()), dict(reset_first=1, rollouts=-1),
+                dict(reset_first=1, rollouts=5000)):
+        with pytest.raises(bpg._lib.BpgError) as e:
+            bpg._lib.check(L.bpg_rollout(many._h, C.byref(bpg._lib.RolloutArgs(T=T, **bad)), None))
+        assert e.value.code == bpg._lib.ERR_ARG
+    torch.cuda.synchronize()
+    for key, v in many.state_dict().items():
+        assert torch.equal(v, before[key])
+
+
+@pytest.mark.parametrize('env_id', ['BlocksTouchVariation-v0', 'BlocksTouch-v0'])
+def test_evaluator_loop_in_one_launch_keeps_the_success_history_of_k_calls(env_id):
+    """train.py:62-64: evaluator.clear_history(); for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)."""
+    B, K, T = 4096, 10, 50
+    mk = lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=3)   # noqa: E731
+    w1 = bpg.RolloutStudent(mk, None, dims_of(env_id), None, T, rollout_batch_size=B, output='torch')
+    wk = bpg.RolloutStudent(mk, None, dims_of(env_id), None, T, rollout_batch_size=B, output='torch')
+    masks = bpg.time_major_empty(K * T, B, torch.int32, DEV)
+    bpg._lib.check(L.bpg_synth_masks_ld(w1.env._h, 0, K * T, P(masks), int(masks.stride(0)), None))
+    w1.clear_history(), wk.clear_history()
+    for k in range(K):
+        w1.generate_rollouts_fused(masks=masks[k * T:(k + 1) * T])
+    fl = bpg.time_major_empty(K * T, B, torch.uint8, DEV)
+    rates = wk.evaluate_rollouts_fused(masks, n_rollouts=K, flags_tb=fl)
+    assert list(w1.success_history) == list(wk.success_history) == rates and len(rates) == K
+    assert w1.n_episodes == wk.n_episodes
+    assert w1.logs('test') == wk.logs('test')
+    with pytest.raises(ValueError):
+        wk.evaluate_rollouts_fused(masks, n_rollouts=K + 1)

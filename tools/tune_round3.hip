@@ -116,7 +116,7 @@ static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k+
         const double bytes = (double)B * (T * (4 + ((OUT & 1) ? 4 : 0) + ((OUT & 2) ? 1 : 0)) + 12 + (OKB ? 8 : 0)); \
         TIME(nm, bytes, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, OUT, true, UNR, PIPE, true, LBV, (OKB != 0)>), dim3((unsigned)grid), \
                                     dim3(BLOCK), 0, 0, b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca,  \
-                                    OKB ? b.okbits : nullptr));                                                \
+                                    OKB ? b.okbits : nullptr, 1));                                                \
     } while (0)
 
 static int run(char mode, int64_t B)
@@ -141,7 +141,7 @@ static int run(char mode, int64_t B)
             ROLL(2, 256, 5, false, 3, 2, 1, 0, 256); ROLL(2, 256, 5, false, 3, 2, 0, 0, 256);
         }
     } else if (mode == 'B') {
-        TIME("empty kernel (launch floor)", 1.0, hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, b.d_counter));
+        TIME("empty kernel (launch floor)", 1.0, hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, b.d_counter, 1u));
         for (int rep = 0; rep < 2; rep++) {
             ROLL(1, 256, 10, true, 3, 0, 1, 0, 256); ROLL(1, 256, 10, true, 3, 1, 1, 0, 256); ROLL(1, 256, 10, true, 3, 2, 1, 0, 256);
             ROLL(1, 128, 10, true, 3, 0, 1, 0, 256); ROLL(1, 128, 10, true, 3, 1, 1, 0, 256); ROLL(1, 128, 10, true, 3, 2, 1, 0, 256);
@@ -262,7 +262,7 @@ static int run_skew(int64_t B)
             for (int k = 0; k < NSET; k++) {
                 CK(hipEventRecord(e0, 0));
                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
-                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr);
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (r >= 2) per_set[k] += ms / REPSE;
@@ -272,7 +272,7 @@ static int run_skew(int64_t B)
         for (int r = 0; r < 10; r++)
             for (int k = 0; k < NSET; k++)
                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
-                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr);
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float tot; CK(hipEventElapsedTime(&tot, e0, e1));
         double mn = 1e9, mx = 0, mean = 0;
