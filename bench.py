@@ -704,7 +704,28 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     res['compute_reward_f32_rows'] = line(timed(cr, 20), nrow * (8 * env.dimg + 4), nrow)
     del cr_ag, cr_g, cr_out
 
-    # (3e) policy-gradient discounted return: (T,B) f32 in, (B,T) f64 out
+    # (3d') the expert's inputs of one step (policy_gradient/rollout.py:105-171, :198): 87 -> 40 (float64) observation
+    # columns, 36 -> 16 goal entries twice; 636 B read + 448 B written per env
+    try:
+        tr_o = torch.zeros((B, 87), dtype=torch.float32, device=dev)
+        tr_o[:, 11 + 15 + 2] = 1.0                      # slot 0 green
+        tr_o[:, 11 + 19 + 15 + 3] = 1.0                 # slot 1 blue
+        tr_g = torch.randint(-1, 2, (B, 36), device=dev).to(torch.float32)
+        tr_ag = torch.randint(-1, 2, (B, 36), device=dev).to(torch.float32)
+        tr_out = (torch.empty((B, 40), dtype=torch.float64, device=dev), torch.empty((B, 16), dtype=torch.float32, device=dev),
+                  torch.empty((B, 16), dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+
+        def tr():
+            _lib.check(L.bpg_trim_expert_inputs(C.c_void_p(tr_o.data_ptr()), C.c_void_p(tr_g.data_ptr()), C.c_void_p(tr_ag.data_ptr()),
+                                                B, 87, 36, 40, 16, 4, 1, C.c_void_p(tr_out[0].data_ptr()),
+                                                C.c_void_p(tr_out[1].data_ptr()), C.c_void_p(tr_out[2].data_ptr()),
+                                                C.c_void_p(tr_out[3].data_ptr()), dev.index, stream))
+        res['trim_expert_inputs_variation'] = line(timed(tr, 20), B * (87 * 4 + 2 * 36 * 4 + 40 * 8 + 2 * 16 * 4), B)
+        assert int(tr_out[3].item()) == 0
+        del tr_o, tr_g, tr_ag, tr_out
+    except Exception as e:  # noqa: BLE001
+        res['trim_expert_inputs_variation'] = {'error': repr(e)[:200]}
+
     # three (reward, G) pairs round-robin: neither the 210 MB read nor the 419 MB written find the
     # previous launch's lines in the 256 MiB Infinity Cache
     NDR = 3

@@ -107,6 +107,8 @@ SIGNATURES = {
     'bpg_discounted_return_scan': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                              C.c_int, C.c_void_p]),
     'bpg_nan_flag_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    'bpg_trim_expert_inputs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 
 

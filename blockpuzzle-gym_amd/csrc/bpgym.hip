@@ -1771,6 +1771,126 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     }
 }
 
+// ------------------------------ expert input trimming ------------------------
+// RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171, batched branch): what an
+// expert trained on a smaller puzzle is handed when it is in charge of a step (:196-200).
+//   g_, ag_: the entries (i, j) with i, j < num_objs of the max_num_objs x max_num_objs goal matrices (:141-151), float32;
+//   o_ (Variation, :152-168): o[1 : 1 + ENV_FEATURES] followed by the BLOCK_BASE_FEATURES of every block slot whose
+//       colour one-hot has its (first) maximum at GREEN or BLUE, in slot order, as float64 (the reference concatenates
+//       into a float64 array); a row with another number of such slots than num_objs - 2 is the reference's
+//       ValueError (`block_features[i] = temp`, :166): reported through bad_flag, the row's missing picks read slot 0;
+//   o_ (every other env, :169-170): o[:, :dimo], float32.
+// One block = 64 envs: the rows are staged in LDS with coalesced loads (row strides odd), lane = env picks the
+// coloured slots, then all lanes stream the contiguous output regions.
+constexpr int TRIM_ENV_FEATURES = 10, TRIM_BLOCK_BASE = 15, TRIM_COLORS = 4, TRIM_BLOCK = TRIM_BLOCK_BASE + TRIM_COLORS;
+constexpr int TRIM_GREEN = 2, TRIM_BLUE = 3, TRIM_MAX_SLOTS = 8, TRIM_ENVS = 64;
+struct TrimConst {
+    int dimo_in, dimg_in, dimo_out, dimg_out;
+    int num_blocks, max_blocks;     // Variation: slots kept / slots present in o
+    int ldo, ldg;                   // LDS row strides (odd)
+    uint8_t sel[64];                // source column of g_ / ag_ column k
+};
+
+template <bool VAR>
+__global__ void __launch_bounds__(256)
+k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__restrict__ ag, int64_t n, TrimConst tc,
+       void *__restrict__ o_out, float *__restrict__ g_out, float *__restrict__ ag_out, uint32_t *__restrict__ bad_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *t_g = reinterpret_cast<float *>(smem);                    // [64][ldg]
+    float *t_ag = t_g + TRIM_ENVS * tc.ldg;
+    float *t_o = t_ag + TRIM_ENVS * tc.ldg;                          // [64][ldo], Variation only
+    __shared__ uint8_t pick[TRIM_ENVS][TRIM_MAX_SLOTS];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * TRIM_ENVS;
+    const int nvalid = (int)((n - base) < TRIM_ENVS ? (n - base) : TRIM_ENVS);
+    {
+        const float *pg = g + base * tc.dimg_in, *pa = ag + base * tc.dimg_in;
+        const int total = nvalid * tc.dimg_in;
+        int e = tid / tc.dimg_in, k = tid - e * tc.dimg_in;
+        const int e_inc = 256 / tc.dimg_in, k_inc = 256 - e_inc * tc.dimg_in;
+        for (int f = tid; f < total; f += 256) {
+            t_g[e * tc.ldg + k] = pg[f];
+            t_ag[e * tc.ldg + k] = pa[f];
+            e += e_inc; k += k_inc;
+            if (k >= tc.dimg_in) { k -= tc.dimg_in; e++; }
+        }
+    }
+    if (VAR) {
+        const float *po = o + base * tc.dimo_in;
+        const int total = nvalid * tc.dimo_in;
+        int e = tid / tc.dimo_in, k = tid - e * tc.dimo_in;
+        const int e_inc = 256 / tc.dimo_in, k_inc = 256 - e_inc * tc.dimo_in;
+        for (int f = tid; f < total; f += 256) {
+            t_o[e * tc.ldo + k] = po[f];
+            e += e_inc; k += k_inc;
+            if (k >= tc.dimo_in) { k -= tc.dimo_in; e++; }
+        }
+        __syncthreads();
+        if (tid < TRIM_ENVS) {
+            int cnt = 0;
+            if (tid < nvalid) {
+                for (int j = 0; j < tc.max_blocks; j++) {
+                    const float *c = t_o + tid * tc.ldo + 1 + TRIM_ENV_FEATURES + j * TRIM_BLOCK + TRIM_BLOCK_BASE;
+                    // np.argmax (get_color, :24-26): first index of the maximum, a NaN counts as the maximum
+                    int am = 0;
+                    float best = c[0];
+#pragma unroll
+                    for (int q = 1; q < TRIM_COLORS; q++)
+                        if (best == best && (c[q] > best || c[q] != c[q])) { best = c[q]; am = q; }
+                    if (am == TRIM_GREEN || am == TRIM_BLUE) {
+                        if (cnt < tc.num_blocks) pick[tid][cnt] = (uint8_t)j;
+                        cnt++;
+                    }
+                }
+                if (cnt != tc.num_blocks) atomicOr(bad_flag, 1u);
+            }
+            for (int q = cnt; q < tc.num_blocks; q++) pick[tid][q] = 0;
+        }
+    }
+    __syncthreads();
+    if (VAR) {
+        double *oo = reinterpret_cast<double *>(o_out) + base * tc.dimo_out;
+        const int total = nvalid * tc.dimo_out;
+        int e = tid / tc.dimo_out, k = tid - e * tc.dimo_out;
+        const int e_inc = 256 / tc.dimo_out, k_inc = 256 - e_inc * tc.dimo_out;
+        for (int f = tid; f < total; f += 256) {
+            int src = 1 + k;
+            if (k >= TRIM_ENV_FEATURES) {
+                const int b = (k - TRIM_ENV_FEATURES) / TRIM_BLOCK_BASE, cidx = (k - TRIM_ENV_FEATURES) - b * TRIM_BLOCK_BASE;
+                src = 1 + TRIM_ENV_FEATURES + TRIM_BLOCK * pick[e][b] + cidx;
+            }
+            oo[f] = (double)t_o[e * tc.ldo + src];
+            e += e_inc; k += k_inc;
+            if (k >= tc.dimo_out) { k -= tc.dimo_out; e++; }
+        }
+    } else {
+        float *oo = reinterpret_cast<float *>(o_out) + base * tc.dimo_out;
+        const float *po = o + base * tc.dimo_in;
+        const int total = nvalid * tc.dimo_out;
+        int e = tid / tc.dimo_out, k = tid - e * tc.dimo_out;
+        const int e_inc = 256 / tc.dimo_out, k_inc = 256 - e_inc * tc.dimo_out;
+        for (int f = tid; f < total; f += 256) {
+            oo[f] = po[e * tc.dimo_in + k];
+            e += e_inc; k += k_inc;
+            if (k >= tc.dimo_out) { k -= tc.dimo_out; e++; }
+        }
+    }
+    {
+        float *og = g_out + base * tc.dimg_out, *oa = ag_out + base * tc.dimg_out;
+        const int total = nvalid * tc.dimg_out;
+        int e = tid / tc.dimg_out, k = tid - e * tc.dimg_out;
+        const int e_inc = 256 / tc.dimg_out, k_inc = 256 - e_inc * tc.dimg_out;
+        for (int f = tid; f < total; f += 256) {
+            const int src = e * tc.ldg + tc.sel[k];
+            og[f] = t_g[src];
+            oa[f] = t_ag[src];
+            e += e_inc; k += k_inc;
+            if (k >= tc.dimg_out) { k -= tc.dimg_out; e++; }
+        }
+    }
+}
+
 // ------------------------------ compute_reward ------------------------------
 // fetch_env.py:141-143 on float rows, one row per lane; the block's rows are
 // staged through LDS with coalesced loads (row stride padded odd).
@@ -3317,6 +3437,56 @@ int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, 
     hipLaunchKernelGGL(k_discounted_return_scan, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, (hipStream_t)stream,
                        d_reward_tb, n, ld, T, R, gamma, d_G);
     return check_launch("k_discounted_return_scan");
+}
+
+int bpg_trim_expert_inputs(const float *d_o, const float *d_g, const float *d_ag, int64_t n, int dimo_in, int dimg_in,
+                           int dimo_out, int dimg_out, int num_objs, int is_variation, void *d_o_out, float *d_g_out,
+                           float *d_ag_out, uint32_t *d_bad_flag, int device_id, void *stream)
+{
+    if (!d_o || !d_g || !d_ag || !d_o_out || !d_g_out || !d_ag_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(BPG_ERR_ARG, "n < 0");
+    if (dimo_in < 1 || dimg_in < 1 || dimo_out < 1 || dimg_out < 1 || num_objs < 1) return fail(BPG_ERR_ARG, "bad dimensions");
+    if (dimg_in > 64 || dimo_in > 1024) return fail(BPG_ERR_UNSUPPORTED, "trim supports dimg <= 64 and dimo <= 1024");
+    int max_objs = (int)std::sqrt((double)dimg_in);                 // (int)(g.shape[1] ** 0.5), rollout.py:139
+    while ((max_objs + 1) * (max_objs + 1) <= dimg_in) max_objs++;
+    while (max_objs * max_objs > dimg_in) max_objs--;
+    TrimConst tc{};
+    tc.dimo_in = dimo_in; tc.dimg_in = dimg_in; tc.dimo_out = dimo_out; tc.dimg_out = dimg_out;
+    int kept = 0;
+    for (int i = 0; i < dimg_in; i++)
+        if (i / max_objs < num_objs && i % max_objs < num_objs) {
+            if (kept < 64) tc.sel[kept] = (uint8_t)i;
+            kept++;
+        }
+    if (kept != dimg_out) return fail(BPG_ERR_ARG, "trim: the kept goal entries are not dimg (assert, rollout.py:146)");
+    if (is_variation) {
+        tc.num_blocks = num_objs - 2;
+        tc.max_blocks = max_objs - 2;
+        if (tc.num_blocks < 0 || tc.max_blocks < 0 || tc.max_blocks > TRIM_MAX_SLOTS || tc.num_blocks > TRIM_MAX_SLOTS)
+            return fail(BPG_ERR_ARG, "trim: bad number of block slots");
+        if (dimo_in < 1 + TRIM_ENV_FEATURES + TRIM_BLOCK * tc.max_blocks)
+            return fail(BPG_ERR_ARG, "trim: the observation row is shorter than its block slots");
+        if (dimo_out != TRIM_ENV_FEATURES + TRIM_BLOCK_BASE * tc.num_blocks)
+            return fail(BPG_ERR_ARG, "trim: o_ is not dimo wide (assert, rollout.py:171)");
+        if (!d_bad_flag) return fail(BPG_ERR_ARG, "trim of a Variation observation needs d_bad_flag");
+    } else if (dimo_out > dimo_in) {
+        return fail(BPG_ERR_ARG, "trim: o_ is not dimo wide (assert, rollout.py:171)");
+    }
+    if (n == 0) return BPG_OK;
+    DeviceGuard guard(device_id);
+    tc.ldo = dimo_in | 1; tc.ldg = dimg_in | 1;
+    const size_t lds = (size_t)TRIM_ENVS * sizeof(float) * (2 * tc.ldg + (is_variation ? tc.ldo : 0));
+    const dim3 grid((unsigned)((n + TRIM_ENVS - 1) / TRIM_ENVS)), block(256);
+    const void *fn = is_variation ? reinterpret_cast<const void *>(k_trim<true>) : reinterpret_cast<const void *>(k_trim<false>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    if (is_variation)
+        hipLaunchKernelGGL(k_trim<true>, grid, block, lds, (hipStream_t)stream, d_o, d_g, d_ag, n, tc, d_o_out, d_g_out, d_ag_out, d_bad_flag);
+    else
+        hipLaunchKernelGGL(k_trim<false>, grid, block, lds, (hipStream_t)stream, d_o, d_g, d_ag, n, tc, d_o_out, d_g_out, d_ag_out, d_bad_flag);
+    return check_launch("k_trim");
 }
 
 int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint32_t *d_flag, int device_id,

@@ -466,12 +466,51 @@ class PGRolloutStudent(RolloutStudent):
                          render=render, **kwargs)
         self.gamma, self.time = gamma, 0.0
         self.beta_final, self.annealing_coeff, self.expert = beta_final, annealing_coeff, expert
+        if hasattr(policy, 'kwargs'):
+            self.kwargs = policy.kwargs             # policy_gradient/rollout.py:53: trim reads ['info']['env_name'] from it
+        self._trim_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def beta(self):
         return (1.0 - self.beta_final) * np.exp(-self.time / self.annealing_coeff) + self.beta_final
 
     def anneal(self):
         self.time += 1.0
+
+    def _env_name(self):
+        info = (self.kwargs or {}).get('info') if isinstance(self.kwargs, dict) else None
+        if info and 'env_name' in info:             # what the reference reads (policy_gradient/rollout.py:117, :152)
+            return info['env_name']
+        return self.env.spec.id                     # workers built without the policy's kwargs: the env's own id
+
+    def trim(self, o, g, ag, dimo, dimg, num_objs=4):
+        """policy_gradient/rollout.py:105-171: the inputs of an expert trained on a smaller puzzle -- the corner of
+        the goal matrices that belongs to the first `num_objs` objects, and of the observation either its first
+        `dimo` entries or (Variation) the env features plus the base features of the GREEN and BLUE blocks.
+        One HIP launch on device tensors (numpy inputs are moved to the worker's device and the results come
+        back as numpy).  Dtypes as the reference's: g_, ag_ float32; o_ float32, Variation float64.  A
+        Variation row without exactly num_objs - 2 coloured blocks raises ValueError as NumPy does at :166."""
+        if o.shape[-1] == dimo:                     # "No need to trim": the same objects back (:107-108)
+            return o, g, ag
+        assert len(o.shape) != 1                    # the reference's 1-D branch is `assert(False)` (:114-115)
+        as_numpy = not torch.is_tensor(o)
+        dev = lambda x: torch.as_tensor(x).to(self.device, torch.float32).contiguous()   # noqa: E731
+        o, g, ag = dev(o), dev(g), dev(ag)
+        n, variation = o.shape[0], 'Variation' in self._env_name()
+        assert int(min(num_objs, int(g.shape[1] ** 0.5))) ** 2 == dimg       # assert(len(g_[0]) == dimg), :146
+        assert (dimo == 10 + 15 * (num_objs - 2)) if variation else (dimo <= o.shape[1])     # assert(o_.shape[1] == dimo), :171
+        o_ = torch.empty((n, dimo), dtype=torch.float64 if variation else torch.float32, device=self.device)
+        g_ = torch.empty((n, dimg), dtype=torch.float32, device=self.device)
+        ag_ = torch.empty((n, dimg), dtype=torch.float32, device=self.device)
+        self._trim_bad.zero_()
+        _lib.check(_lib.lib().bpg_trim_expert_inputs(_ptr(o), _ptr(g), _ptr(ag), n, o.shape[1], g.shape[1], dimo, dimg,
+                                                     int(num_objs), int(variation), _ptr(o_), _ptr(g_), _ptr(ag_),
+                                                     _ptr(self._trim_bad), self.device.index, _stream(self.device)))
+        if variation and int(self._trim_bad.item()):
+            raise ValueError('trim: an observation row does not hold exactly %d GREEN / BLUE blocks '
+                             '(policy_gradient/rollout.py:166)' % (num_objs - 2))
+        if as_numpy:
+            return o_.cpu().numpy(), g_.cpu().numpy(), ag_.cpu().numpy()
+        return o_, g_, ag_
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None, want_reward=False,
                                 materialize_constants=False, gamma=None):
@@ -498,14 +537,15 @@ class PGRolloutStudent(RolloutStudent):
         beta = self.beta() if self.expert is not None else 0
         ep = self._alloc_episode(time_major=True, g=False, o=False)
         ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])
-        ep['sigma'] = torch.zeros((T, B, self.dims['u']), dtype=torch.float32, device=self.device)
+        # "We can't report sigma accurately when we are using the expert": np.zeros((B, dimu)), float64 (:207-209)
+        ep['sigma'] = torch.zeros((T, B, self.dims['u']), device=self.device,
+                                  dtype=torch.float64 if self.expert is not None else torch.float32)
         reward = time_major_empty(T, B, torch.float32, self.device)
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]
-            if np.random.rand() < beta:
-                if o.shape[-1] != self.expert.dimo:
-                    raise NotImplementedError('expert observation trimming (policy_gradient/rollout.py:105-171)')
-                u, raw = self.expert.get_actions(*self._policy_in(o, ag, self.g), compute_raw=True)
+            if np.random.rand() < beta:            # the expert is in charge (:196-200)
+                o_, g_, ag_ = self.trim(o, self.g, ag, self.expert.dimo, self.expert.dimg)
+                u, raw = self.expert.get_actions(*self._policy_in(o_, ag_, g_), compute_raw=True)
                 sigma = None
             else:
                 u, raw, sigma = self.policy.get_actions(*self._policy_in(o, ag, self.g), exploit=exploit)

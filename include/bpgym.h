@@ -289,6 +289,22 @@ int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,
                               uint32_t want_touch, uint32_t want_never, int64_t n,
                               float *d_out, int device_id, void *stream);
 
+/* RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171, batched branch): the inputs
+ * of an expert trained on a smaller puzzle (`self.expert.get_actions(o_, ag_, g_, compute_raw=True)`, :196-200).
+ *   d_o (n, dimo_in), d_g / d_ag (n, dimg_in) float32 rows, contiguous.
+ *   d_g_out / d_ag_out (n, dimg_out) float32: entries (i, j), i, j < num_objs, of the sqrt(dimg_in)-sided matrices (:139-151);
+ *     dimg_out must be their number (the reference's assert, :146).
+ *   is_variation != 0 (:152-168): d_o_out (n, dimo_out) FLOAT64 = o[1:11] followed by the 15 base features of every
+ *     block slot whose colour one-hot peaks (np.argmax) at GREEN or BLUE, slot order; dimo_out must be 10 + 15 *
+ *     (num_objs - 2) (:171).  A row with another number of such slots makes NumPy raise in the reference (:166): bit 0 of
+ *     *d_bad_flag is set (the caller clears it; read it where the rollout is synchronised anyway) and the row's
+ *     missing picks repeat slot 0.
+ *   is_variation == 0 (:169-170): d_o_out (n, dimo_out) FLOAT32 = o[:, :dimo_out]; d_bad_flag may be NULL.
+ * Callers skip the call when dimo_in == dimo_out (the reference returns its inputs, :107-108).  dimg_in <= 64. */
+int bpg_trim_expert_inputs(const float *d_o, const float *d_g, const float *d_ag, int64_t n, int dimo_in, int dimg_in,
+                           int dimo_out, int dimg_out, int num_objs, int is_variation, void *d_o_out, float *d_g_out,
+                           float *d_ag_out, uint32_t *d_bad_flag, int device_id, void *stream);
+
 /* RolloutStudent.generate_rollouts inner loop (rollout.py:100-153) for T steps
  * in ONE launch: state stays in registers, every array below is optional
  * (NULL = not produced).  With reset_first the launch also performs the

@@ -233,6 +233,46 @@ def synth_masks(seed, env_ids, T, num_objs):
     return out
 
 
+# policy_gradient/rollout.py:8-26 constants of the observation layout
+ENV_FEATURES, BLOCK_BASE_FEATURES, COLOR_FEATURES = 10, 15, 4
+BLOCK_FEATURES = BLOCK_BASE_FEATURES + COLOR_FEATURES
+GREEN, BLUE = 2, 3
+
+
+def trim(o, g, ag, dimo, dimg, is_variation, num_objs=4):
+    """RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171), batched branch,
+    restated with array indexing: returns (o_, g_, ag_) with the reference's dtypes.  Pinned by
+    tests/golden/trim.npz (outputs of the reference's own trim)."""
+    o, g, ag = np.asarray(o), np.asarray(g), np.asarray(ag)
+    if o.shape[-1] == dimo:                                   # :107-108
+        return o, g, ag
+    assert o.ndim == 2                                        # the 1-D branch is `assert(False)`, :114-115
+    max_num_objs = int(g.shape[1] ** 0.5)                     # :139
+    keep = [i for i in range(g.shape[1])
+            if i // max_num_objs < num_objs and i % max_num_objs < num_objs]          # :140-145
+    assert len(keep) == dimg                                  # :146
+    g_, ag_ = g[:, keep].copy(), ag[:, keep].copy()           # np.asarray of the gathered scalars keeps the dtype
+    if is_variation:                                          # :149-168
+        B = o.shape[0]
+        num_blocks, max_num_blocks = num_objs - 2, max_num_objs - 2
+        feats = np.empty((B, BLOCK_BASE_FEATURES * num_blocks))                       # float64, :157
+        for i in range(B):
+            rows = []
+            for j in range(max_num_blocks):
+                start = ENV_FEATURES + 1 + j * BLOCK_FEATURES
+                color = int(np.argmax(o[i, start + BLOCK_BASE_FEATURES:start + BLOCK_FEATURES]))   # get_color, :24-26
+                if color in (GREEN, BLUE):
+                    rows.append(o[i, start:start + BLOCK_BASE_FEATURES])
+            if len(rows) != num_blocks:
+                raise ValueError('row %d has %d coloured blocks, the expert takes %d' % (i, len(rows), num_blocks))   # :166
+            feats[i] = np.concatenate(rows) if rows else np.zeros(0)
+        o_ = np.concatenate([o[:, 1:ENV_FEATURES + 1], feats], axis=1)                # float64, :167
+    else:
+        o_ = o[:, :dimo]                                      # :169-170
+    assert o_.shape[1] == dimo                                # :171
+    return o_, g_, ag_
+
+
 def discounted_return(r, gamma):
     r = np.ascontiguousarray(r, np.float64)
     G = np.zeros_like(r)

@@ -465,6 +465,129 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
     return out
 
 
+def _worker_inputs(env_id, B, seed, steps_of):
+    """(o, g, ag) as the pg worker holds them (policy_gradient/rollout.py:64-66, :188-191: float32 arrays filled
+    from the env's float64 observation dicts), env b advanced steps_of(b) scripted steps after its reset."""
+    o = g = ag = None
+    for b in range(B):
+        env = H.make(env_id)
+        attach_scripts(env, seed + 1000 * b, [], p_pair=0.1)
+        env.seed(seed + 1000 * b)
+        obs = env.reset()
+        rng = np.random.RandomState(seed + b)
+        for _ in range(steps_of(b)):
+            obs = env.step(rng.uniform(-1, 1, 4).astype(np.float32))[0]
+        if o is None:
+            o = np.empty((B, obs['observation'].shape[0]), np.float32)
+            g = np.empty((B, obs['desired_goal'].shape[0]), np.float32)
+            ag = np.empty_like(g)
+        o[b], g[b], ag[b] = obs['observation'], obs['desired_goal'], obs['achieved_goal']
+    return o, g, ag
+
+
+def trim_cases():
+    """RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171, batched branch): what
+    the expert of a smaller puzzle is handed.  Inputs are observations of the reference envs; expected outputs are
+    the reference's, dtype included (the Variation branch concatenates a float64 array and returns float64)."""
+    import types
+    H.install()
+    from gym_blocks.policy_gradient.rollout import RolloutStudent
+    out = {}
+    cases = [('variation', 'BlocksTouchVariation-v0', 40, 16, 4, 12),   # 4 slots, 2 coloured -> BlocksTouch's dims
+             ('choose', 'BlocksTouchChoose-v0', 40, 16, 4, 6),          # plain prefix of o, 4 x 4 corner of the 5 x 5 goal
+             ('tower', 'ToppleTower-v0', 25, 9, 3, 5),                  # another num_objs
+             ('same', 'BlocksTouch-v0', 40, 16, 4, 3)]                  # nothing to trim: the arrays themselves
+    for name, env_id, dimo, dimg, num_objs, B in cases:
+        o, g, ag = _worker_inputs(env_id, B, 4100 + len(out), lambda b: b % 4)
+        fake = types.SimpleNamespace(kwargs={'info': {'env_name': env_id}})
+        o_, g_, ag_ = RolloutStudent.trim(fake, o, g, ag, dimo, dimg, num_objs=num_objs)
+        out.update({name + '_o': o, name + '_g': g, name + '_ag': ag, name + '_dims': np.asarray([dimo, dimg, num_objs], np.int32),
+                    name + '_o_out': np.asarray(o_), name + '_g_out': np.asarray(g_), name + '_ag_out': np.asarray(ag_),
+                    name + '_same_objects': np.asarray([o_ is o, g_ is g, ag_ is ag])})
+    return out
+
+
+class RecordingExpert:
+    """The expert of policy_gradient/rollout.py:198-200: sees the TRIMMED inputs, returns (u, raw)."""
+
+    def __init__(self, seed, dimo, dimg, log):
+        self.rng, self.dimo, self.dimg, self.log = np.random.RandomState(seed), dimo, dimg, log
+
+    def get_actions(self, o, ag, g, compute_raw=False):
+        assert compute_raw
+        u = self.rng.uniform(-1, 1, size=(o.shape[0], 4)).astype(np.float32)
+        self.log.append(dict(o=np.array(o), ag=np.array(ag), g=np.array(g), u=u))
+        return u, (u * np.float32(0.5))
+
+
+def expert_rollout_trace(env_id, seed, B, dimo, dimg, n_rollouts=2):
+    """policy_gradient generate_rollouts with an expert in charge on some steps (np.random.rand() < beta,
+    :196-206).  The coin flips come from the GLOBAL NumPy stream, which the reference's placement loops also
+    consume (quirk Q7), so the fixture records which steps the expert took."""
+    H.install()
+    from gym_blocks.policy_gradient.rollout import RolloutStudent
+    logs = []
+
+    def make_env():
+        env = H.make(env_id)
+        log = []
+        attach_scripts(env, seed + 1000 * len(logs), log, p_pair=0.012)
+        env.seed(seed + 1000 * len(logs))
+        logs.append(log)
+        return env
+
+    np.random.seed(seed)
+    probe = H.make(env_id)
+    o = probe.reset()
+    dims = dict(o=o['observation'].shape[0], u=4, g=o['desired_goal'].shape[0], info_is_success=1)
+    T = probe._max_episode_steps
+    ulog, xlog = [], []
+    policy = RandomPolicy(seed, ulog)
+    policy.kwargs = {'info': {'env_name': env_id}}
+    worker = RolloutStudent(make_env=make_env, policy=policy, expert=RecordingExpert(seed + 1, dimo, dimg, xlog), dims=dims,
+                            logger=NullLogger(), T=T, rollout_batch_size=B, gamma=1. - 1. / T, beta_final=0.35,
+                            annealing_coeff=2.0)
+    worker.seed(seed)
+    out = dict(T=np.int32(T), B=np.int32(B), n_rollouts=np.int32(n_rollouts), expert_dims=np.asarray([dimo, dimg], np.int32))
+    for r in range(n_rollouts):
+        for log in logs:
+            del log[:]
+        del ulog[:], xlog[:]
+        out['r%d_beta' % r] = np.float64(worker.beta())
+        ep = worker.generate_rollouts()
+        worker.anneal()
+        for k, v in ep.items():
+            out['r%d_%s' % (r, k)] = v
+        # which steps the expert took: its raw actions are u / 2, the policy's are u
+        con = -np.ones((B, T, MAXCON, 2), np.int16)
+        ncon = np.zeros((B, T), np.int32)
+        for b, log in enumerate(logs):
+            for t, pairs in enumerate(log):
+                con[b, t] = pad_contacts(pairs)
+                ncon[b, t] = len(pairs)
+        out['r%d_contacts' % r], out['r%d_ncon' % r] = con, ncon
+        out['r%d_num_objs' % r] = np.asarray([e.unwrapped.num_objs for e in worker.envs], np.int32)
+        in_charge = np.zeros(T, np.uint8)
+        xi = pi = 0
+        for t in range(T):
+            raw_t = ep['u'][:, t]
+            if xi < len(xlog) and np.array_equal(raw_t, xlog[xi]['u'] * np.float32(0.5)):
+                in_charge[t] = 1
+                xi += 1
+            else:
+                assert np.array_equal(raw_t, ulog[pi])
+                pi += 1
+        assert xi == len(xlog) and pi == len(ulog)
+        out['r%d_expert_in_charge' % r] = in_charge
+        out['r%d_policy_u' % r] = np.asarray(ulog, np.float32).reshape(len(ulog), B, 4)
+        out['r%d_expert_u' % r] = np.asarray([x['u'] for x in xlog], np.float32).reshape(len(xlog), B, 4)
+        for key in ('o', 'ag', 'g'):
+            arr = np.asarray([x[key] for x in xlog])
+            out['r%d_expert_saw_%s' % (r, key)] = arr.reshape((len(xlog), B, -1))
+        out['r%d_success_rate' % r] = np.float64(worker.success_history[-1])
+    return out
+
+
 def main(HERE=HERE):
     H.install()
     from gym_blocks.envs import fetch_env
@@ -523,6 +646,11 @@ def main(HERE=HERE):
                              'BlocksTouchChoose-v0']):
         ro = rollout_trace(eid, seed=700 + k, B=4, modes=[0, 0], pg=True)
         np.savez_compressed(os.path.join(HERE, 'pg_rollout_%s.npz' % eid.split('-')[0]), **ro)
+    np.savez_compressed(os.path.join(HERE, 'trim.npz'), **trim_cases())
+    np.savez_compressed(os.path.join(HERE, 'pg_expert_rollout_BlocksTouchVariation.npz'),
+                        **expert_rollout_trace('BlocksTouchVariation-v0', seed=810, B=4, dimo=40, dimg=16))
+    np.savez_compressed(os.path.join(HERE, 'pg_expert_rollout_BlocksTouchChoose.npz'),
+                        **expert_rollout_trace('BlocksTouchChoose-v0', seed=811, B=3, dimo=40, dimg=16))
     print('golden fixtures written to', HERE)
 
 

@@ -499,3 +499,176 @@ def test_evaluator_loop_in_one_launch_keeps_the_success_history_of_k_calls(env_i
     assert w1.logs('test') == wk.logs('test')
     with pytest.raises(ValueError):
         wk.evaluate_rollouts_fused(masks, n_rollouts=K + 1)
+
+
+# ------------------------------------------------------------------ expert input trimming (pg worker)
+class _NamedPolicy:
+    def __init__(self, env_id):
+        self.kwargs = {'info': {'env_name': env_id}}           # policy_gradient/rollout.py:53, :117
+
+
+def _pg_worker(env_id, B=2, output='numpy', expert=None, policy=None, **kw):
+    return bpg.PGRolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=1), policy or _NamedPolicy(env_id),
+                                expert, dims_of(env_id), None, 50, rollout_batch_size=B, gamma=0.98, output=output, **kw)
+
+
+TRIM_ENVS = dict(variation='BlocksTouchVariation-v0', choose='BlocksTouchChoose-v0', tower='ToppleTower-v0', same='BlocksTouch-v0')
+
+
+@pytest.mark.parametrize('name', sorted(TRIM_ENVS))
+def test_trim_equals_the_references_trim_on_its_own_observations(name):
+    """policy_gradient/rollout.py:105-171: golden inputs (observations of the reference envs) and outputs of the
+    reference's trim, values and dtypes; numpy in -> numpy out, device tensors in -> device tensors out."""
+    d = np.load(os.path.join(GOLDEN, 'trim.npz'))
+    dimo, dimg, num_objs = (int(x) for x in d[name + '_dims'])
+    w = _pg_worker(TRIM_ENVS[name])
+    o, g, ag = d[name + '_o'], d[name + '_g'], d[name + '_ag']
+    for as_torch in (False, True):
+        args = [torch.as_tensor(x, device=DEV) for x in (o, g, ag)] if as_torch else [o, g, ag]
+        out = w.trim(*args, dimo, dimg, num_objs=num_objs)
+        if name == 'same':
+            assert all(a is b for a, b in zip(out, args))
+            continue
+        for got, key in zip(out, ('o_out', 'g_out', 'ag_out')):
+            assert torch.is_tensor(got) == as_torch
+            got = got.cpu().numpy() if as_torch else got
+            want = d['%s_%s' % (name, key)]
+            assert got.dtype == want.dtype and got.shape == want.shape
+            np.testing.assert_array_equal(got, want, err_msg=key)
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 70001])
+def test_trim_kernel_equals_the_oracle_on_random_rows(n):
+    """Every block size edge, colours in any slots (the two coloured blocks are taken in SLOT order whatever their
+    colours), one-hots that are not one-hot (np.argmax: first maximum, NaN wins), other goal sizes."""
+    rng = np.random.RandomState(n)
+    # Variation: 87 -> 40, 36 -> 16
+    o = rng.standard_normal((n, 87)).astype(np.float32)
+    o[:, 0] = rng.randint(2, 5, n)
+    for i in range(n):
+        slots = rng.permutation(4)
+        for k, j in enumerate(slots):
+            c = np.zeros(4, np.float32)
+            if k < 2:
+                c[rng.randint(2, 4)] = 1.0                    # GREEN or BLUE, both may be the same colour
+            elif rng.rand() < 0.5:
+                c[rng.randint(0, 2)] = 1.0                    # GREY / RED; else all zeros (absent block): argmax 0 = GREY
+            o[i, 11 + 19 * j + 15:11 + 19 * j + 19] = c
+    if n >= 64:                                               # soft "one-hots": ties and NaNs
+        o[5, 11 + 15:11 + 19] = [0.5, 0.5, 0.5, 0.5]          # first maximum -> GREY
+        o[5, 11 + 19 + 15:11 + 19 + 19] = [0.1, 0.2, 0.7, 0.7]    # -> GREEN
+        o[5, 11 + 38 + 15:11 + 38 + 19] = [0.1, 0.2, np.nan, 9.0]  # NaN counts as the maximum -> GREEN
+        o[5, 11 + 57 + 15:11 + 57 + 19] = [np.nan, 0.2, 3.0, 9.0]  # -> GREY
+    g = rng.randint(-1, 2, (n, 36)).astype(np.float32)
+    ag = rng.randint(-1, 2, (n, 36)).astype(np.float32)
+    w = _pg_worker('BlocksTouchVariation-v0')
+    got = w.trim(o, g, ag, 40, 16)
+    want = O.trim(o, g, ag, 40, 16, True)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype
+        np.testing.assert_array_equal(a, b)
+    # one coloured block too many / too few anywhere in the batch: NumPy's ValueError (:166)
+    for row, paint in ((n - 1, [0, 0, 1, 0]), (0, [1, 0, 0, 0])):
+        bad = o.copy()
+        slot = [j for j in range(4) if (np.argmax(bad[row, 11 + 19 * j + 15:11 + 19 * j + 19]) >= 2) == (paint[0] == 0)]
+        slot = [j for j in range(4) if j not in slot][0]
+        bad[row, 11 + 19 * slot + 15:11 + 19 * slot + 19] = paint
+        with pytest.raises(ValueError):
+            O.trim(bad, g, ag, 40, 16, True)
+        with pytest.raises(ValueError):
+            w.trim(bad, g, ag, 40, 16)
+    # prefix trimming with other geometries: 6 x 6 -> 3 x 3, 5 x 5 -> 4 x 4, 5 x 5 -> 2 x 2
+    for env_id, dimo_in, side, dimo, num_objs in (('ToppleTower-v0', 70, 6, 25, 3), ('BlocksTouchChoose-v0', 55, 5, 40, 4),
+                                                 ('BlocksTouchChoose-v0', 55, 5, 13, 2)):
+        o2 = rng.standard_normal((n, dimo_in)).astype(np.float32)
+        g2 = rng.standard_normal((n, side * side)).astype(np.float32)
+        ag2 = rng.standard_normal((n, side * side)).astype(np.float32)
+        got = _pg_worker(env_id).trim(o2, g2, ag2, dimo, num_objs * num_objs, num_objs=num_objs)
+        want = O.trim(o2, g2, ag2, dimo, num_objs * num_objs, False, num_objs=num_objs)
+        for a, b in zip(got, want):
+            assert a.dtype == b.dtype
+            np.testing.assert_array_equal(a, b)
+
+
+def test_trim_refuses_what_the_reference_asserts_on():
+    w = _pg_worker('BlocksTouchVariation-v0')
+    o, g, ag = np.zeros((4, 87), np.float32), np.zeros((4, 36), np.float32), np.zeros((4, 36), np.float32)
+    with pytest.raises(AssertionError):                       # 9 kept goal entries, not 16 (:146)
+        w.trim(o, g, ag, 40, 16, num_objs=3)
+    with pytest.raises(AssertionError):                       # o_ would be 40 wide, not 41 (:171)
+        w.trim(o, g, ag, 41, 16)
+    with pytest.raises(AssertionError):                       # the unbatched branch is `assert(False)` (:114-115)
+        w.trim(o[0], g[0], ag[0], 40, 16)
+    L_ = bpg._lib
+    t = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=DEV)   # noqa: E731
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for bad in (dict(dimg_out=9), dict(dimo_out=41), dict(dimo_in=80), dict(flag=None), dict(n=-1)):
+        a = dict(n=4, dimo_in=87, dimg_in=36, dimo_out=40, dimg_out=16, flag=flag)
+        a.update(bad)
+        rc = L.bpg_trim_expert_inputs(P(t(4, 87)), P(t(4, 36)), P(t(4, 36)), a['n'], a['dimo_in'], a['dimg_in'], a['dimo_out'],
+                                      a['dimg_out'], 4, 1, P(t(4, 40, dt=torch.float64)), P(t(4, 16)), P(t(4, 16)),
+                                      None if a['flag'] is None else P(a['flag']), 0, None)
+        assert rc == L_.ERR_ARG, bad
+
+
+@pytest.mark.parametrize('name,is_variation', [('BlocksTouchVariation', True), ('BlocksTouchChoose', False)])
+def test_golden_pg_rollout_with_an_expert_in_charge(name, is_variation, monkeypatch):
+    """policy_gradient/rollout.py:174-290 with an expert (:196-209): which of expert / policy acts is the reference's
+    coin flip (replayed from the fixture: the reference's placement loops consume the same global stream, quirk Q7),
+    the expert is handed trim(o, g, ag), its RAW action is stored, sigma is float64 zeros, G is the reference's."""
+    env_id = name + '-v0'
+    d = np.load(os.path.join(GOLDEN, 'pg_expert_rollout_%s.npz' % name))
+    B, T = int(d['B']), int(d['T'])
+    dimo, dimg = (int(x) for x in d['expert_dims'])
+    state = {}
+
+    class Policy(_NamedPolicy):
+        def get_actions(self, o, ag, g, exploit=False):
+            u = state['policy_u'].pop(0)
+            return u, u.copy(), np.ones_like(u)               # sigma is dropped when there is an expert (:207-209)
+
+    class Expert:
+        def __init__(self):
+            self.dimo, self.dimg = dimo, dimg
+
+        def get_actions(self, o, ag, g, compute_raw=False):
+            assert compute_raw
+            k = state['seen']
+            state['seen'] += 1
+            assert o.shape == (B, dimo) and o.dtype == state['saw_o'].dtype
+            np.testing.assert_array_equal(ag, state['saw_ag'][k])
+            np.testing.assert_array_equal(g, state['saw_g'][k])
+            assert ag.dtype == np.float32 and g.dtype == np.float32
+            state['o_seen'].append(o)
+            u = state['expert_u'][k]
+            return u, u * np.float32(0.5)
+
+    src = bpg.ScriptedContacts()
+    w = bpg.PGRolloutStudent(lambda: bpg.make(env_id, device=DEV), Policy(env_id), Expert(), dims_of(env_id), None, T,
+                             rollout_batch_size=B, gamma=1. - 1. / T, beta_final=0.35, annealing_coeff=2.0)
+    w.env.contact_source = src
+    for r in range(int(d['n_rollouts'])):
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        src.pairs = np.ascontiguousarray(con.transpose(1, 0, 2, 3))
+        src.ncon = np.ascontiguousarray(d['r%d_ncon' % r].T)
+        src.t = 0
+        flips = [0.0 if c else 1.0 for c in d['r%d_expert_in_charge' % r]]
+        monkeypatch.setattr(np.random, 'rand', lambda: flips.pop(0))
+        state.update(policy_u=list(d['r%d_policy_u' % r]), expert_u=d['r%d_expert_u' % r], seen=0, o_seen=[],
+                     saw_o=d['r%d_expert_saw_o' % r], saw_ag=d['r%d_expert_saw_ag' % r], saw_g=d['r%d_expert_saw_g' % r])
+        assert w.beta() == float(d['r%d_beta' % r])
+        ep = w.generate_rollouts(num_grey=d['r%d_num_objs' % r] - 4)
+        w.anneal()
+        assert not flips and not state['policy_u'] and state['seen'] == len(state['expert_u'])
+        np.testing.assert_array_equal(ep['u'], d['r%d_u' % r])
+        np.testing.assert_array_equal(ep['G'].view(np.uint64), d['r%d_G' % r].view(np.uint64))
+        np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
+        np.testing.assert_array_equal(ep['info_is_success'], d['r%d_info_is_success' % r])
+        assert ep['sigma'].dtype == d['r%d_sigma' % r].dtype and not ep['sigma'].any() and ep['sigma'].shape == d['r%d_sigma' % r].shape
+        assert w.success_history[-1] == pytest.approx(float(d['r%d_success_rate' % r]), abs=1e-7)
+        # what the expert saw of the observation: the restatement applied to this episode's own o (no physics
+        # backend behind the contacts-in boundary, so the feature values are the env's, not the fixture's)
+        for k, t in enumerate(np.flatnonzero(d['r%d_expert_in_charge' % r])):
+            want = O.trim(ep['o'][:, t], ep['g'][:, t], ep['ag'][:, t], dimo, dimg, is_variation)[0]
+            np.testing.assert_array_equal(state['o_seen'][k], want)

@@ -275,3 +275,51 @@ def test_env_key_mirrors_the_reference_seed_arithmetic():
         assert L.orc_synth_mask(s, i, 7, 6) == L.orc_synth_mask((s + 1000 * i) % 2 ** 64, 0, 7, 6)
         assert L.orc_num_grey_draw(s, i, 2) == L.orc_num_grey_draw((s + 1000 * i) % 2 ** 64, 0, 2)
     assert L.orc_env_key(5, 3, 0) != L.orc_env_key(5, 3, 1) and L.orc_env_key(5, 3, 0) != L.orc_env_key(6, 3, 0)
+
+
+# ------------------------------------------------------------------ expert input trimming (pg worker)
+TRIM_CASES = [('variation', True), ('choose', False), ('tower', False), ('same', False)]
+
+
+@pytest.mark.parametrize('name,is_variation', TRIM_CASES)
+def test_trim_restatement_equals_the_references_trim(name, is_variation):
+    """policy_gradient/rollout.py:105-171 (batched branch): values AND dtypes (Variation returns float64)."""
+    d = np.load(os.path.join(G, 'trim.npz'))
+    dimo, dimg, num_objs = (int(x) for x in d[name + '_dims'])
+    o, g, ag = d[name + '_o'], d[name + '_g'], d[name + '_ag']
+    o_, g_, ag_ = O.trim(o, g, ag, dimo, dimg, is_variation, num_objs=num_objs)
+    for got, key in ((o_, 'o_out'), (g_, 'g_out'), (ag_, 'ag_out')):
+        want = d['%s_%s' % (name, key)]
+        assert got.dtype == want.dtype and got.shape == want.shape, key
+        np.testing.assert_array_equal(got, want, err_msg=key)
+    if name == 'same':                               # "No need to trim": the very same objects
+        assert d['same_same_objects'].all() and o_ is o and g_ is g and ag_ is ag
+    else:
+        assert not d[name + '_same_objects'].any()
+
+
+def test_trim_restatement_on_the_inputs_the_reference_expert_saw():
+    """The expert of the reference's pg rollouts was handed trim(o_t, g, ag_t): the recorded inputs equal the
+    restatement applied to the episode arrays of the same fixture, at every step the expert was in charge."""
+    for name, is_variation in (('BlocksTouchVariation', True), ('BlocksTouchChoose', False)):
+        d = np.load(os.path.join(G, 'pg_expert_rollout_%s.npz' % name))
+        dimo, dimg = (int(x) for x in d['expert_dims'])
+        for r in range(int(d['n_rollouts'])):
+            steps = np.flatnonzero(d['r%d_expert_in_charge' % r])
+            assert len(steps) == d['r%d_expert_saw_o' % r].shape[0] and len(steps) > 0
+            for k, t in enumerate(steps):
+                o_, g_, ag_ = O.trim(d['r%d_o' % r][:, t], d['r%d_g' % r][:, t], d['r%d_ag' % r][:, t], dimo, dimg, is_variation)
+                for got, key in ((o_, 'o'), (g_, 'g'), (ag_, 'ag')):
+                    want = d['r%d_expert_saw_%s' % (r, key)][k]
+                    assert got.dtype == want.dtype
+                    np.testing.assert_array_equal(got, want)
+
+
+def test_trim_raises_as_numpy_does_when_a_row_has_the_wrong_number_of_coloured_blocks():
+    d = np.load(os.path.join(G, 'trim.npz'))
+    o = d['variation_o'].copy()
+    o[3, 11 + 15:11 + 19] = [1, 0, 0, 0]             # slot 0 of row 3 painted grey: one coloured block left
+    with pytest.raises(ValueError):
+        O.trim(o, d['variation_g'], d['variation_ag'], 40, 16, True)
+    with pytest.raises(AssertionError):              # 3 objects of a 6 x 6 goal are 9 entries, not 16
+        O.trim(d['variation_o'], d['variation_g'], d['variation_ag'], 40, 16, True, num_objs=3)
