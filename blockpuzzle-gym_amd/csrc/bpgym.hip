@@ -1780,58 +1780,86 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 //       into a float64 array); a row with another number of such slots than num_objs - 2 is the reference's
 //       ValueError (`block_features[i] = temp`, :166): reported through bad_flag, the row's missing picks read slot 0;
 //   o_ (every other env, :169-170): o[:, :dimo], float32.
-// One block = 64 envs: the rows are staged in LDS with coalesced loads (row strides odd), lane = env picks the
-// coloured slots, then all lanes stream the contiguous output regions.
+// One block = 64 envs: the rows are staged in LDS with batched 16-byte loads, lane = env picks the coloured slots,
+// then all lanes stream the contiguous output regions.
 constexpr int TRIM_ENV_FEATURES = 10, TRIM_BLOCK_BASE = 15, TRIM_COLORS = 4, TRIM_BLOCK = TRIM_BLOCK_BASE + TRIM_COLORS;
 constexpr int TRIM_GREEN = 2, TRIM_BLUE = 3, TRIM_MAX_SLOTS = 8, TRIM_ENVS = 64;
 struct TrimConst {
     int dimo_in, dimg_in, dimo_out, dimg_out;
     int num_blocks, max_blocks;     // Variation: slots kept / slots present in o
-    int ldo, ldg;                   // LDS row strides (odd)
+    bool vec_o;                     // o starts on a 16-byte boundary (every block's 64 rows then do)
     uint8_t sel[64];                // source column of g_ / ag_ column k
 };
+
+// Stages `total` consecutive floats (16-byte aligned start) from global memory into LDS, unchanged layout: every lane
+// requests TRIM_U float4 before the first one is consumed (one memory round trip per TRIM_U * 4 KB of the block).
+constexpr int TRIM_U = 6;
+__device__ __forceinline__ void trim_stage(float *__restrict__ dst, const float *__restrict__ src, int total, int tid, bool vec)
+{
+    const int nq = vec ? total >> 2 : 0;            // vec: src is 16-byte aligned
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int q0 = tid; q0 < nq; q0 += 256 * TRIM_U) {
+        float4 v[TRIM_U];
+#pragma unroll
+        for (int u = 0; u < TRIM_U; u++) {
+            const int q = q0 + u * 256;
+            v[u] = s4[q < nq ? q : nq - 1];           // clamped: no lane-dependent definedness of v
+        }
+#pragma unroll
+        for (int u = 0; u < TRIM_U; u++)
+            if (q0 + u * 256 < nq) d4[q0 + u * 256] = v[u];
+    }
+    for (int f = 4 * nq + tid; f < total; f += 256) dst[f] = src[f];
+}
 
 template <bool VAR>
 __global__ void __launch_bounds__(256)
 k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__restrict__ ag, int64_t n, TrimConst tc,
        void *__restrict__ o_out, float *__restrict__ g_out, float *__restrict__ ag_out, uint32_t *__restrict__ bad_flag)
 {
+    // LDS (Variation only): the block's o rows exactly as they lie in global memory (64 rows are a multiple of 16
+    // bytes whatever the row length), then the source column of every o_ column.  The goal entries are gathered
+    // straight from global memory (a wave reads 16 of the 36 floats of 4 consecutive rows: the same few lines):
+    // requested first, stored last, so their latency hides behind the observation part.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *t_g = reinterpret_cast<float *>(smem);                    // [64][ldg]
-    float *t_ag = t_g + TRIM_ENVS * tc.ldg;
-    float *t_o = t_ag + TRIM_ENVS * tc.ldg;                          // [64][ldo], Variation only
+    float *t_o = reinterpret_cast<float *>(smem);                    // [64][dimo_in]
     __shared__ uint8_t pick[TRIM_ENVS][TRIM_MAX_SLOTS];
+    __shared__ uint8_t col_slot[TRIM_ENV_FEATURES + TRIM_BLOCK_BASE * TRIM_MAX_SLOTS];     // 255: env feature
+    __shared__ uint16_t col_off[TRIM_ENV_FEATURES + TRIM_BLOCK_BASE * TRIM_MAX_SLOTS];
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * TRIM_ENVS;
     const int nvalid = (int)((n - base) < TRIM_ENVS ? (n - base) : TRIM_ENVS);
-    {
-        const float *pg = g + base * tc.dimg_in, *pa = ag + base * tc.dimg_in;
-        const int total = nvalid * tc.dimg_in;
-        int e = tid / tc.dimg_in, k = tid - e * tc.dimg_in;
-        const int e_inc = 256 / tc.dimg_in, k_inc = 256 - e_inc * tc.dimg_in;
-        for (int f = tid; f < total; f += 256) {
-            t_g[e * tc.ldg + k] = pg[f];
-            t_ag[e * tc.ldg + k] = pa[f];
-            e += e_inc; k += k_inc;
-            if (k >= tc.dimg_in) { k -= tc.dimg_in; e++; }
-        }
+    constexpr int TRIM_GU = 4;                   // 64 x 16 goal entries = 4 per lane
+    const int gtotal = nvalid * tc.dimg_out;
+    const float *pg = g + base * tc.dimg_in, *pa = ag + base * tc.dimg_in;
+    float vg[TRIM_GU], va[TRIM_GU];
+#pragma unroll
+    for (int u = 0; u < TRIM_GU; u++) {
+        int f = tid + u * 256;
+        f = f < gtotal ? f : gtotal - 1;
+        const int e = f / tc.dimg_out, k = f - e * tc.dimg_out;
+        const int src = e * tc.dimg_in + tc.sel[k];
+        vg[u] = pg[src];
+        va[u] = pa[src];
     }
     if (VAR) {
-        const float *po = o + base * tc.dimo_in;
-        const int total = nvalid * tc.dimo_in;
-        int e = tid / tc.dimo_in, k = tid - e * tc.dimo_in;
-        const int e_inc = 256 / tc.dimo_in, k_inc = 256 - e_inc * tc.dimo_in;
-        for (int f = tid; f < total; f += 256) {
-            t_o[e * tc.ldo + k] = po[f];
-            e += e_inc; k += k_inc;
-            if (k >= tc.dimo_in) { k -= tc.dimo_in; e++; }
+        trim_stage(t_o, o + base * tc.dimo_in, nvalid * tc.dimo_in, tid, tc.vec_o);
+        if (tid < tc.dimo_out) {
+            const int k = tid;
+            if (k < TRIM_ENV_FEATURES) { col_slot[k] = 255; col_off[k] = (uint16_t)(1 + k); }
+            else {
+                const int b = (k - TRIM_ENV_FEATURES) / TRIM_BLOCK_BASE;
+                col_slot[k] = (uint8_t)b;
+                col_off[k] = (uint16_t)(1 + TRIM_ENV_FEATURES + (k - TRIM_ENV_FEATURES) - b * TRIM_BLOCK_BASE);
+            }
         }
         __syncthreads();
         if (tid < TRIM_ENVS) {
             int cnt = 0;
             if (tid < nvalid) {
                 for (int j = 0; j < tc.max_blocks; j++) {
-                    const float *c = t_o + tid * tc.ldo + 1 + TRIM_ENV_FEATURES + j * TRIM_BLOCK + TRIM_BLOCK_BASE;
+                    const float *c = t_o + tid * tc.dimo_in + 1 + TRIM_ENV_FEATURES + j * TRIM_BLOCK + TRIM_BLOCK_BASE;
                     // np.argmax (get_color, :24-26): first index of the maximum, a NaN counts as the maximum
                     int am = 0;
                     float best = c[0];
@@ -1854,13 +1882,11 @@ k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__
         const int total = nvalid * tc.dimo_out;
         int e = tid / tc.dimo_out, k = tid - e * tc.dimo_out;
         const int e_inc = 256 / tc.dimo_out, k_inc = 256 - e_inc * tc.dimo_out;
+#pragma unroll 4
         for (int f = tid; f < total; f += 256) {
-            int src = 1 + k;
-            if (k >= TRIM_ENV_FEATURES) {
-                const int b = (k - TRIM_ENV_FEATURES) / TRIM_BLOCK_BASE, cidx = (k - TRIM_ENV_FEATURES) - b * TRIM_BLOCK_BASE;
-                src = 1 + TRIM_ENV_FEATURES + TRIM_BLOCK * pick[e][b] + cidx;
-            }
-            oo[f] = (double)t_o[e * tc.ldo + src];
+            const int sl = col_slot[k];
+            const int src = col_off[k] + (sl == 255 ? 0 : TRIM_BLOCK * pick[e][sl]);
+            oo[f] = (double)t_o[e * tc.dimo_in + src];
             e += e_inc; k += k_inc;
             if (k >= tc.dimo_out) { k -= tc.dimo_out; e++; }
         }
@@ -1870,6 +1896,7 @@ k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__
         const int total = nvalid * tc.dimo_out;
         int e = tid / tc.dimo_out, k = tid - e * tc.dimo_out;
         const int e_inc = 256 / tc.dimo_out, k_inc = 256 - e_inc * tc.dimo_out;
+#pragma unroll 4
         for (int f = tid; f < total; f += 256) {
             oo[f] = po[e * tc.dimo_in + k];
             e += e_inc; k += k_inc;
@@ -1878,15 +1905,16 @@ k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__
     }
     {
         float *og = g_out + base * tc.dimg_out, *oa = ag_out + base * tc.dimg_out;
-        const int total = nvalid * tc.dimg_out;
-        int e = tid / tc.dimg_out, k = tid - e * tc.dimg_out;
-        const int e_inc = 256 / tc.dimg_out, k_inc = 256 - e_inc * tc.dimg_out;
-        for (int f = tid; f < total; f += 256) {
-            const int src = e * tc.ldg + tc.sel[k];
-            og[f] = t_g[src];
-            oa[f] = t_ag[src];
-            e += e_inc; k += k_inc;
-            if (k >= tc.dimg_out) { k -= tc.dimg_out; e++; }
+#pragma unroll
+        for (int u = 0; u < TRIM_GU; u++) {
+            const int f = tid + u * 256;
+            if (f < gtotal) { og[f] = vg[u]; oa[f] = va[u]; }
+        }
+        for (int f = tid + TRIM_GU * 256; f < gtotal; f += 256) {     // larger goal matrices than 4 x 4
+            const int e = f / tc.dimg_out, k = f - e * tc.dimg_out;
+            const int src = e * tc.dimg_in + tc.sel[k];
+            og[f] = pg[src];
+            oa[f] = pa[src];
         }
     }
 }
@@ -3474,8 +3502,8 @@ int bpg_trim_expert_inputs(const float *d_o, const float *d_g, const float *d_ag
     }
     if (n == 0) return BPG_OK;
     DeviceGuard guard(device_id);
-    tc.ldo = dimo_in | 1; tc.ldg = dimg_in | 1;
-    const size_t lds = (size_t)TRIM_ENVS * sizeof(float) * (2 * tc.ldg + (is_variation ? tc.ldo : 0));
+    tc.vec_o = aligned16(d_o);
+    const size_t lds = is_variation ? (size_t)TRIM_ENVS * sizeof(float) * dimo_in : 0;
     const dim3 grid((unsigned)((n + TRIM_ENVS - 1) / TRIM_ENVS)), block(256);
     const void *fn = is_variation ? reinterpret_cast<const void *>(k_trim<true>) : reinterpret_cast<const void *>(k_trim<false>);
     if (lds > 64 * 1024) {
