@@ -587,6 +587,12 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
                                                                             line, rollouts=10)
     except Exception as e:  # noqa: BLE001
         res['rollout_masks_65536_envs_10_rollouts_per_launch'] = {'error': repr(e)[:200]}
+    # ... and of the headline batch: what the kernel streams at once the fixed cost of a launch is spread over 10 rollouts
+    try:
+        res['rollout_masks_%d_envs_10_rollouts_per_launch' % B] = rollout_at(torch, bpg, _lib, B, T, dev, stream, timed, line,
+                                                                            rollouts=10)
+    except Exception as e:  # noqa: BLE001
+        res['rollout_masks_%d_envs_10_rollouts_per_launch' % B] = {'error': repr(e)[:200]}
 
     # (1) one env.step launch: 12 B in (now, ever, mask) + 13 B out (now, ever, reward, flags) = 25 B/env-step
     # (SURVEY 8d's per-step form).  One batch stepped over and over keeps its 26 MB in the Infinity Cache ...
