@@ -470,11 +470,16 @@ class PGRolloutStudent(RolloutStudent):
             self.kwargs = policy.kwargs             # policy_gradient/rollout.py:53: trim reads ['info']['env_name'] from it
         self._trim_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
 
+    def save_policy_weights(self, path):
+        self.policy.save_weights(path)              # policy_gradient/rollout.py:313-314 (train.py:112)
+
     def beta(self):
         return (1.0 - self.beta_final) * np.exp(-self.time / self.annealing_coeff) + self.beta_final
 
     def anneal(self):
         self.time += 1.0
+        if self.expert is not None:                  # policy_gradient/rollout.py:292-293
+            self._log('info', 'Beta = {}'.format(self.beta()))
 
     def _env_name(self):
         info = (self.kwargs or {}).get('info') if isinstance(self.kwargs, dict) else None

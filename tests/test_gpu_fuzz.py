@@ -84,8 +84,8 @@ def test_random_api_sequences_vs_oracle(env_id, B):
     mir.reset(ng, np.ones(B, bool))
     np.testing.assert_array_equal(obs['achieved_goal'].cpu().numpy(), mir.ag().astype(np.float32))
     saved = None
-    ops = rng.choice(['mask', 'list', 'csr', 'fused', 'reset', 'partial', 'save', 'restore'], size=140,
-                     p=[0.36, 0.14, 0.08, 0.12, 0.04, 0.14, 0.06, 0.06])
+    ops = rng.choice(['mask', 'list', 'csr', 'fused', 'reset', 'partial', 'save', 'restore', 'multi'], size=140,
+                     p=[0.33, 0.13, 0.08, 0.11, 0.04, 0.13, 0.06, 0.06, 0.06])
     for op in ops:
         ngeom = np.array([len(mir.v['models'][m]['id2obj']) for m in mir.model])
         if op == 'mask':
@@ -128,6 +128,33 @@ def test_random_api_sequences_vs_oracle(env_id, B):
                 np.testing.assert_array_equal(bits(rew[t]), exp[1])
                 np.testing.assert_array_equal(flg[t].cpu().numpy() & 3, exp[3].astype(np.uint8) | (exp[2].astype(np.uint8) << 1))
             np.testing.assert_array_equal(env.achieved_goal_f64().cpu().numpy(), mir.ag())
+        elif op == 'multi':                         # K x (reset + T' steps) in ONE launch (the evaluator's loop)
+            K, Tp = int(rng.randint(2, 5)), int(rng.randint(1, 7))
+            ngk = rng.randint(3, size=(K, B)).astype(np.int32)
+            nob = 4 + ngk if mir.variation else np.broadcast_to(mir.nobj(), (K, B))
+            masks = np.concatenate([legal_masks(rng, Tp, B, nob[k], density=2) for k in range(K)])
+            if rng.rand() < 0.3:
+                masks = (rng.randint(0, 1 << 21, size=(K * Tp, B)) & rng.randint(0, 1 << 21, size=(K * Tp, B))).astype(np.uint32)
+            dm = torch.as_tensor(masks.view(np.int32), device=DEV)
+            rew = torch.empty((K * Tp, B), dtype=torch.float32, device=DEV)
+            flg = torch.empty((K * Tp, B), dtype=torch.uint8, device=DEV)
+            cnt = torch.zeros(K, dtype=torch.int64, device=DEV)
+            dng = torch.as_tensor(ngk, device=DEV)
+            a = bpg._lib.RolloutArgs(T=Tp, reset_first=1, rollouts=K, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(),
+                                     d_flags_tb=flg.data_ptr(), d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr())
+            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            torch.cuda.synchronize()
+            for k in range(K):
+                mir.reset(ngk[k], np.ones(B, bool))
+                for t in range(Tp):
+                    exp = mir.step_masks(masks[k * Tp + t])
+                    np.testing.assert_array_equal(bits(rew[k * Tp + t]), exp[1])
+                    np.testing.assert_array_equal(flg[k * Tp + t].cpu().numpy() & 3,
+                                                  exp[3].astype(np.uint8) | (exp[2].astype(np.uint8) << 1))
+                assert int(cnt[k].item()) == sum(int(e.e.has_succeeded) for e in mir.envs)
+            np.testing.assert_array_equal(env.achieved_goal_f64().cpu().numpy(), mir.ag())
+            if mir.variation:
+                np.testing.assert_array_equal(env.num_objs_per_env().cpu().numpy(), mir.nobj())
         elif op in ('reset', 'partial'):
             sel = np.ones(B, bool) if op == 'reset' else rng.rand(B) < 0.3
             ng = rng.randint(3, size=B).astype(np.int32)
