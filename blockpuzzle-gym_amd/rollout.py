@@ -416,6 +416,8 @@ class RolloutStudent:
                                 d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
                                 d_success_count=counts.data_ptr())
         _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
+        if env.info.is_variation:       # the K in-launch resets drew new block counts: the env's observation rows follow
+            env._fill_static_observation()
         rates = [float(c) / B for c in counts.tolist()]
         self.success_history.extend(rates)
         self.n_episodes += K * B

@@ -155,6 +155,7 @@ def test_random_api_sequences_vs_oracle(env_id, B):
             np.testing.assert_array_equal(env.achieved_goal_f64().cpu().numpy(), mir.ag())
             if mir.variation:
                 np.testing.assert_array_equal(env.num_objs_per_env().cpu().numpy(), mir.nobj())
+                env._fill_static_observation()      # raw C-ABI call under a Python env: its observation rows follow the new draws
         elif op in ('reset', 'partial'):
             sel = np.ones(B, bool) if op == 'reset' else rng.rand(B) < 0.3
             ng = rng.randint(3, size=B).astype(np.int32)

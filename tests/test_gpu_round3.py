@@ -497,6 +497,9 @@ def test_evaluator_loop_in_one_launch_keeps_the_success_history_of_k_calls(env_i
     assert list(w1.success_history) == list(wk.success_history) == rates and len(rates) == K
     assert w1.n_episodes == wk.n_episodes
     assert w1.logs('test') == wk.logs('test')
+    assert torch.equal(w1.env.observation, wk.env.observation)          # Variation: block counts / colours of the last draw
+    for key, v in w1.env.state_dict().items():
+        assert torch.equal(v, wk.env.state_dict()[key]), key
     with pytest.raises(ValueError):
         wk.evaluate_rollouts_fused(masks, n_rollouts=K + 1)
 
