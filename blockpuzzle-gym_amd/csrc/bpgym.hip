@@ -914,6 +914,14 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
 // their fixed cost (5-6 us per launch, which is all a 65 536-env rollout has left to lose).  Envs are independent and a
 // lane only ever touches its own, so nothing has to be synchronised between the rollouts of a launch; the counts go out
 // as plain atomics that drain behind the next rollout's steps.
+// Diagnostics for tools/tune_round3.hip (mode T) only: with BPG_TIMELINE defined, lane 0 of every block records the
+// constant-rate clock at a few points of the launch into a buffer the tool sets.  Never defined in the library build.
+#ifdef BPG_TIMELINE
+__device__ unsigned long long *bpg_timeline = nullptr;
+#define BPG_TL(slot) do { if (threadIdx.x == 0 && bpg_timeline) bpg_timeline[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define BPG_TL(slot) do { } while (0)
+#endif
 template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
           bool MULTI = false>
 __global__ void __launch_bounds__(LB)
@@ -929,6 +937,9 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (ca.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *ca.zero_next = 0ull;
+    BPG_TL(0);
+    int tl_pass = 0;
+    (void)tl_pass;
     for (int ro = 0; ro < (MULTI ? rollouts : 1); ro++) {
     const uint32_t *__restrict__ masks = masks_all + (MULTI ? (int64_t)ro * T * ld_masks : 0);
     uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
@@ -1061,8 +1072,10 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                     one_step(b * UNROLL + u, mt, 1u << u);
                 }
                 flush_ok(b * UNROLL);
+                if (b == 0 && tl_pass < 2) BPG_TL(1 + 4 * tl_pass);
             }
         }
+        if (tl_pass < 2) BPG_TL(2 + 4 * tl_pass);
         for (int t = nb * UNROLL; t < T; t++) {          // T % UNROLL leftover steps
             uint32_t mt[EPL] = {};
             if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * ldm], mt);
@@ -1081,7 +1094,10 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
 #pragma unroll
             for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
         }
+        if (tl_pass < 2) BPG_TL(3 + 4 * tl_pass);
+        tl_pass++;
     }
+    BPG_TL(11);
     if (ca.count) {
         if (MULTI) {
             block_count_add(nsucc, CountArgs{ca.count + ro, nullptr, nullptr});
@@ -1090,7 +1106,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             block_count_add(nsucc, ca);
         }
     }
+    BPG_TL(12);
     }
+#ifdef BPG_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);                 // the tool wants to see the stores drain
+    BPG_TL(13);
+#endif
 }
 
 // ------------------------------ float views ---------------------------------

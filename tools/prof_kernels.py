@@ -53,6 +53,46 @@ def rollout(B, reps, synth=False, contiguous=False, pg=False):
     torch.cuda.synchronize()
 
 
+def multi(B, K, reps):
+    """K consecutive rollouts per launch (bpg_rollout_args.rollouts), explicit draws, streams of K * T rows."""
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+    ng = ((torch.arange(K * B, device=DEV, dtype=torch.int32) * 7) % 3).reshape(K, B)
+    env.reset(num_grey=ng[0])
+    nset = max(2, min(int(2.5 * 256 * 2**20 // (K * B * T * 9)) + 1, 8))
+    sets = []
+    for k in range(nset):
+        env.seed(k)
+        m = bpg.time_major_empty(K * T, B, torch.int32, DEV)
+        _lib.check(L.bpg_synth_masks_ld(env._h, 0, K * T, P(m), m.stride(0), None))
+        sets.append((m, bpg.time_major_empty(K * T, B, torch.float32, DEV), bpg.time_major_empty(K * T, B, torch.uint8, DEV)))
+    cnt = torch.zeros(K, dtype=torch.int64, device=DEV)
+    for i in range(reps):
+        m, r, f = sets[i % nset]
+        a = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_num_grey=ng.data_ptr(), ld_masks=m.stride(0), ld_out=f.stride(0),
+                             d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
+        _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    torch.cuda.synchronize()
+
+
+def trim(B, reps):
+    o = torch.randn((3, B, 87), device=DEV)
+    o[:, :, 11 + 15:11 + 19] = torch.tensor([0., 0., 1., 0.], device=DEV)              # slot 0 green
+    o[:, :, 11 + 19 + 15:11 + 19 + 19] = torch.tensor([0., 0., 0., 1.], device=DEV)    # slot 1 blue
+    for j in (2, 3):
+        o[:, :, 11 + 19 * j + 15:11 + 19 * j + 19] = torch.tensor([1., 0., 0., 0.], device=DEV)
+    g = torch.randint(-1, 2, (3, B, 36), device=DEV).to(torch.float32)
+    ag = torch.randint(-1, 2, (3, B, 36), device=DEV).to(torch.float32)
+    out = [(torch.empty((B, 40), dtype=torch.float64, device=DEV), torch.empty((B, 16), dtype=torch.float32, device=DEV),
+            torch.empty((B, 16), dtype=torch.float32, device=DEV)) for _ in range(3)]
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for i in range(reps):
+        k = i % 3
+        _lib.check(L.bpg_trim_expert_inputs(P(o[k]), P(g[k]), P(ag[k]), B, 87, 36, 40, 16, 4, 1, P(out[k][0]), P(out[k][1]),
+                                            P(out[k][2]), P(flag), 0, None))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+
+
 def main():
     which = sys.argv[1:] or ['rollout']
     B = 1 << 20
@@ -69,6 +109,12 @@ def main():
             rollout(524288, 20)
         elif w == 'rollout4m':
             rollout(4194304, 8, contiguous=True)
+        elif w == 'multi64k':
+            multi(65536, 10, 30)
+        elif w == 'multi1m':
+            multi(B, 10, 6)
+        elif w == 'trim':
+            trim(B, 15)
         elif w == 'pg':
             rollout(B, 20, pg=True)
         elif w == 'synth':

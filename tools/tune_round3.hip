@@ -8,6 +8,7 @@
 //      from step-ok words (round 2's two-lanes-per-env kernel was timed beside them until it was removed: profiles/r03_tune_return_kernels.log).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/tune_round3 tools/tune_round3.hip
 //   ./tools/tune_round3 A 131072 262144 | B 65536 | C 1048576 | D 1048576
+#define BPG_TIMELINE 1       // lane 0 of every block timestamps a few points of k_rollout (mode T)
 #include "../blockpuzzle-gym_amd/csrc/bpgym.hip"
 
 #include <algorithm>
@@ -291,9 +292,56 @@ static int run_skew(int64_t B)
     return 0;
 }
 
+// mode T: where a single 1 M-env launch spends its time -- per-block timestamps (constant-rate clock, 10 ns) of: entry,
+// first batch consumed, last step done, state stored (passes 0 and 1), before / after the count, stores drained.
+static int run_timeline(int64_t B)
+{
+    Bufs b;
+    const int T = 50;
+    if (setup(b, B, T, false)) return 1;
+    const StepConst c = mk_c();
+    const SynthConst s = mk_s();
+    const ResetConst rc = mk_rc(b);
+    CountArgs ca{b.cnt, nullptr, b.shards};
+    const int grid = 256;
+    unsigned long long *tl;
+    CK(hipMalloc(&tl, (size_t)grid * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bpgk::bpg_timeline), &tl, sizeof(tl)));
+    std::vector<unsigned long long> h((size_t)grid * 16);
+    printf("== mode T  B = %lld envs, grid %d x 1024, epl2 plain unr5: per-block times in us relative to the earliest entry\n", (long long)B, grid);
+    for (int rep = 0; rep < 8; rep++) {
+        const bool count = rep < 5;
+        ca.count = count ? b.cnt : nullptr;
+        CK(hipMemset(tl, 0, (size_t)grid * 16 * 8));
+        rot++;
+        CK(hipEventRecord(b.e0, 0));
+        hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false, false>), dim3(grid), dim3(1024), 0, 0,
+                           b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
+        CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));
+        float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));
+        CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+        if (rep < 3) continue;
+        unsigned long long t0 = ~0ull;
+        for (int g = 0; g < grid; g++) t0 = std::min(t0, h[(size_t)g * 16]);
+        const char *names[14] = {"entry", "pass0 first batch", "pass0 last step", "pass0 state stored", "", "pass1 first batch",
+                                 "pass1 last step", "pass1 state stored", "", "", "", "before count", "after count", "stores drained"};
+        printf("launch %d (%s): %.2f us by events\n", rep, count ? "with the success count" : "no count", ms * 1e3);
+        for (int slot : {0, 1, 2, 3, 5, 6, 7, 11, 12, 13}) {
+            std::vector<double> v;
+            for (int g = 0; g < grid; g++) v.push_back((double)(h[(size_t)g * 16 + slot] - t0) / 100.0);   // 100 MHz
+            std::sort(v.begin(), v.end());
+            printf("  %-20s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f\n", names[slot], v.front(), v[grid / 10], v[grid / 2],
+                   v[grid * 9 / 10], v.back());
+        }
+    }
+    teardown(b);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F envs...\n"); return 1; }
+    if (argc >= 3 && argv[1][0] == 'T') return run_timeline(atoll(argv[2]));
+    if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F|T envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
         if (run(argv[1][0], atoll(argv[i]))) return 1;
