@@ -120,6 +120,26 @@ static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k+
                                     OKB ? b.okbits : nullptr, 1));                                                \
     } while (0)
 
+// The return kernels' traffic without their transposition: every lane widens float4 -> 4 doubles at the same linear
+// index (4 B in, 8 B out per element), one block per tile of 256 lanes x U float4.
+template <int U>
+__global__ void __launch_bounds__(256) k_widen_linear(const float4 *__restrict__ in, double *__restrict__ out, int64_t nq)
+{
+    const int64_t q0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x;
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int64_t q = q0 + u * 256; v[u] = in[q < nq ? q : nq - 1]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t q = q0 + u * 256;
+        if (q < nq) {
+            double2 *o = reinterpret_cast<double2 *>(out + 4 * q);
+            o[0] = make_double2((double)v[u].x, (double)v[u].y);
+            o[1] = make_double2((double)v[u].z, (double)v[u].w);
+        }
+    }
+}
+
 static int run(char mode, int64_t B)
 {
     const int T = 50;
@@ -177,6 +197,13 @@ static int run(char mode, int64_t B)
                  hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG));
             TIME("k_returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),
                  hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), lg, lb, 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
+            {   // the same bytes with no transposition (rows of the padded reward stream are read as one linear array)
+                const int64_t nq = B * T / 4;
+                TIME("ceiling: linear f32 -> f64 widening copy, 4 float4 per lane", rbytes,
+                     hipLaunchKernelGGL(k_widen_linear<4>, dim3((unsigned)((nq + 1023) / 1024)), dim3(256), 0, 0, (const float4 *)R, GG, nq));
+                TIME("ceiling: linear f32 -> f64 widening copy, 1 float4 per lane", rbytes,
+                     hipLaunchKernelGGL(k_widen_linear<1>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, (const float4 *)R, GG, nq));
+            }
 #define WPBV(W)                                                                                                                    \
             do {                                                                                                                   \
                 const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
