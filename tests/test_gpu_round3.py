@@ -675,3 +675,32 @@ def test_golden_pg_rollout_with_an_expert_in_charge(name, is_variation, monkeypa
         for k, t in enumerate(np.flatnonzero(d['r%d_expert_in_charge' % r])):
             want = O.trim(ep['o'][:, t], ep['g'][:, t], ep['ag'][:, t], dimo, dimg, is_variation)[0]
             np.testing.assert_array_equal(state['o_seen'][k], want)
+
+
+def test_k_rollouts_in_one_launch_at_4m_envs_with_rows_a_power_of_two_apart():
+    """The launch shape of 4 M envs with contiguous rows (2 envs per lane x 256 lanes, uncapped grid) and the
+    generator's draws: one launch of K = 2 rollouts == two launches, final state and counts included."""
+    B, K, T = 1 << 22, 2, 10
+    src = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=9)
+    masks = torch.empty((K * T, B), dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_synth_masks_ld(src._h, 0, K * T, P(masks), B, None))
+    del src
+    one = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=2)
+    many = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=2)
+    f1 = torch.empty((K * T, B), dtype=torch.uint8, device=DEV)
+    fk = torch.empty((K * T, B), dtype=torch.uint8, device=DEV)
+    r1 = torch.empty((K * T, B), dtype=torch.float32, device=DEV)
+    rk = torch.empty((K * T, B), dtype=torch.float32, device=DEV)
+    c1, ck = torch.zeros(K, dtype=torch.int64, device=DEV), torch.zeros(K, dtype=torch.int64, device=DEV)
+    for k in range(K):
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks[k * T:].data_ptr(), ld_masks=B, ld_out=B,
+                                 d_reward_tb=r1[k * T:].data_ptr(), d_flags_tb=f1[k * T:].data_ptr(), d_success_count=c1[k:].data_ptr())
+        bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=B, ld_out=B,
+                             d_reward_tb=rk.data_ptr(), d_flags_tb=fk.data_ptr(), d_success_count=ck.data_ptr())
+    bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+    torch.cuda.synchronize()
+    assert torch.equal(c1, ck) and torch.equal(f1, fk) and torch.equal(r1.view(torch.int32), rk.view(torch.int32))
+    assert [int((fk[k * T + T - 1] & 1).sum().item()) for k in range(K)] == ck.tolist()
+    for key, v in one.state_dict().items():
+        assert torch.equal(v, many.state_dict()[key]), key
