@@ -140,6 +140,37 @@ int main()
         bad3 += std::memcmp(ref.data(), &G[(size_t)b * T], (size_t)T * 8) != 0;
     }
     std::printf("policy-gradient return from the rollout call: %d of %lld rows differ from the reference loop\n", bad3, (long long)B);
+
+    // The evaluator's test loop (train.py:62-64: n_test_rollouts consecutive generate_rollouts calls, only the success
+    // rates kept) as ONE launch: rollouts = K, masks of all K rollouts in one (K*T, n) stream, one counter word each.
+    // Two fresh handles (BlocksTouch keeps its matrix across resets, quirk Q1: both must start from the same state):
+    // one runs the K rollouts in one launch, the other as K launches -- the counts must agree.
+    const int K = 4;
+    bpg_batch *h2 = nullptr, *h3 = nullptr;
+    CHECK(bpg_create(&h2, variant, B, 0, info.max_episode_steps, 1234, 0));
+    CHECK(bpg_create(&h3, variant, B, 0, info.max_episode_steps, 1234, 0));
+    uint32_t *d_mk; uint8_t *d_fk;
+    unsigned long long *d_ck;
+    HIP(hipMalloc(&d_mk, (size_t)K * T * B * 4)); HIP(hipMalloc(&d_fk, (size_t)K * T * B));
+    HIP(hipMalloc(&d_ck, 2 * K * 8)); HIP(hipMemset(d_ck, 0, 2 * K * 8));
+    CHECK(bpg_synth_masks(h2, 0, K * T, d_mk, nullptr));
+    std::memset(&ra, 0, sizeof(ra));
+    ra.T = T; ra.reset_first = 1; ra.rollouts = K; ra.d_masks = d_mk; ra.d_flags_tb = d_fk; ra.d_success_count = d_ck;
+    CHECK(bpg_rollout(h2, &ra, nullptr));
+    for (int k = 0; k < K; k++) {
+        std::memset(&ra, 0, sizeof(ra));
+        ra.T = T; ra.reset_first = 1; ra.d_masks = d_mk + (size_t)k * T * B; ra.d_success_count = d_ck + K + k;
+        CHECK(bpg_rollout(h3, &ra, nullptr));
+    }
+    HIP(hipDeviceSynchronize());
+    unsigned long long ck[2 * K];
+    HIP(hipMemcpy(ck, d_ck, sizeof(ck), hipMemcpyDeviceToHost));
+    int bad4 = 0;
+    for (int k = 0; k < K; k++) bad4 += ck[k] != ck[K + k];
+    std::printf("%d rollouts in one launch: successes %llu %llu %llu %llu; %d differ from %d separate launches\n", K, ck[0], ck[1], ck[2],
+                ck[3], bad4, K);
+    CHECK(bpg_destroy(h2));
+    CHECK(bpg_destroy(h3));
     CHECK(bpg_destroy(h));
-    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0 && bad3 == 0) ? 0 : 2;
+    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0 && bad3 == 0 && bad4 == 0) ? 0 : 2;
 }

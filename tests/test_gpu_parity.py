@@ -937,6 +937,7 @@ def test_c_abi_from_plain_cpp_host(tmp_path):
     assert 'reward bits 0x80000000' in out.stdout and 'success count 1000 of 1000, mismatches 0' in out.stdout
     assert 'vs contiguous: 0 mismatches' in out.stdout and 'bpg_row_stride(2^20) = 1048832' in out.stdout
     assert 'return from the rollout call: 0 of 1000 rows differ' in out.stdout
+    assert '4 rollouts in one launch' in out.stdout and '; 0 differ from 4 separate launches' in out.stdout
 
 
 def test_contact_list_input_is_sanitised():
