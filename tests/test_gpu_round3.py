@@ -646,8 +646,14 @@ def test_golden_pg_rollout_with_an_expert_in_charge(name, is_variation, monkeypa
             u = state['expert_u'][k]
             return u, u * np.float32(0.5)
 
+    class Log:
+        lines = []
+
+        def info(self, msg):
+            self.lines.append(msg)
+
     src = bpg.ScriptedContacts()
-    w = bpg.PGRolloutStudent(lambda: bpg.make(env_id, device=DEV), Policy(env_id), Expert(), dims_of(env_id), None, T,
+    w = bpg.PGRolloutStudent(lambda: bpg.make(env_id, device=DEV), Policy(env_id), Expert(), dims_of(env_id), Log(), T,
                              rollout_batch_size=B, gamma=1. - 1. / T, beta_final=0.35, annealing_coeff=2.0)
     w.env.contact_source = src
     for r in range(int(d['n_rollouts'])):
@@ -663,6 +669,7 @@ def test_golden_pg_rollout_with_an_expert_in_charge(name, is_variation, monkeypa
         assert w.beta() == float(d['r%d_beta' % r])
         ep = w.generate_rollouts(num_grey=d['r%d_num_objs' % r] - 4)
         w.anneal()
+        assert Log.lines[-1] == 'Beta = {}'.format(w.beta())          # policy_gradient/rollout.py:292-293
         assert not flips and not state['policy_u'] and state['seen'] == len(state['expert_u'])
         np.testing.assert_array_equal(ep['u'], d['r%d_u' % r])
         np.testing.assert_array_equal(ep['G'].view(np.uint64), d['r%d_G' % r].view(np.uint64))
