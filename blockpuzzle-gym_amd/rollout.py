@@ -292,7 +292,11 @@ class RolloutStudent:
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         return ep, Qs
 
-    def generate_rollouts_graphed(self, test=False, num_grey=None):
+    def _graph_body(self, test, num_grey):
+        """What a replay runs: the rollout body, returning (episode dict, Qs)."""
+        return self._rollout_body(test, num_grey)
+
+    def generate_rollouts_graphed(self, test=False, num_grey=None, _key=()):
         """generate_rollouts for DEVICE-RESIDENT policies with the whole T-step loop (reset,
         policy, step kernels, episode writes) captured once into a hipGraph and replayed: below
         ~64 K envs the per-step path is bound by host launches (~50 us per step), a replay is
@@ -307,7 +311,7 @@ class RolloutStudent:
         B = self.rollout_batch_size
         explicit = num_grey is not None
         if (getattr(self, '_graph', None) is None or self._graph_test != bool(test)
-                or self._graph_explicit != explicit):
+                or self._graph_explicit != explicit or self._graph_key != _key):
             self._static_ng = torch.zeros(B, dtype=torch.int32, device=self.device)
             if explicit:
                 self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
@@ -316,14 +320,14 @@ class RolloutStudent:
             side.wait_stream(torch.cuda.current_stream(self.device))
             snapshot = self.env.state_dict()                   # the warm-up pass must not count
             with torch.cuda.stream(side):                      # warm-up outside the capture
-                self._rollout_body(test, ng)
+                self._graph_body(test, ng)
                 self.env.load_state_dict(snapshot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._graph_ep, self._graph_Qs = self._rollout_body(test, ng)
-            self._graph, self._graph_test, self._graph_explicit = graph, bool(test), explicit
+                self._graph_ep, self._graph_Qs = self._graph_body(test, ng)
+            self._graph, self._graph_test, self._graph_explicit, self._graph_key = graph, bool(test), explicit, _key
         if explicit:
             self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
         self._graph.replay()
@@ -538,6 +542,18 @@ class PGRolloutStudent(RolloutStudent):
                 continue
             return self._finish(ep)
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
+
+    def _graph_body(self, test, num_grey):
+        return self._pg_body(test, self._graph_exploit, num_grey), ()
+
+    def generate_rollouts_graphed(self, test=False, exploit=False, num_grey=None):
+        """The policy-gradient rollout (reset, T x (policy, step, reward row), the return kernel) replayed from one
+        hipGraph -- see RolloutStudent.generate_rollouts_graphed for the requirements.  Without an expert only: with
+        one, every step flips a host-side coin (policy_gradient/rollout.py:196) and calls host code."""
+        if self.expert is not None:
+            raise NotImplementedError('a rollout with an expert decides per step on the host: use generate_rollouts')
+        self._graph_exploit = bool(exploit)
+        return super().generate_rollouts_graphed(test=test, num_grey=num_grey, _key=('pg', bool(exploit)))
 
     def _pg_body(self, test, exploit, num_grey):
         env, B, T = self.env, self.rollout_batch_size, self.T

@@ -711,3 +711,44 @@ def test_k_rollouts_in_one_launch_at_4m_envs_with_rows_a_power_of_two_apart():
     assert [int((fk[k * T + T - 1] & 1).sum().item()) for k in range(K)] == ck.tolist()
     for key, v in one.state_dict().items():
         assert torch.equal(v, many.state_dict()[key]), key
+
+
+def test_graphed_pg_rollout_equals_eager():
+    """PGRolloutStudent.generate_rollouts_graphed: reset, T x (policy, step + reward row), the return kernel in one
+    hipGraph == the eager loop, replay after replay (fresh explicit draws per replay), G bit for bit."""
+    env_id, B, T = 'BlocksTouchVariation-v0', 2048, 50
+    rng = np.random.RandomState(6)
+    masks = i32(legal_masks(rng, T, B, 4, density=3))
+
+    class Policy:
+        device_tensors = True
+        kwargs = {'info': {'env_name': env_id}}
+
+        def get_actions(self, o, ag, g, exploit=False):
+            u = torch.tanh(ag[:, :4] * 0.5 + o[:, :4]) * (0.5 if exploit else 1.0)
+            return u, u * 2.0, torch.abs(u) + 1.0
+
+    def worker():
+        src = bpg.ScriptedContacts(masks=masks)
+        w = bpg.PGRolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, contact_source=src), Policy(), None,
+                                 dims_of(env_id), None, T, rollout_batch_size=B, gamma=1. - 1. / T, output='torch')
+        return w, src
+    wg, _ = worker()
+    we, src_e = worker()
+    for r, exploit in enumerate((False, False, True, True)):          # a change of `exploit` re-captures
+        ng = rng.randint(3, size=B).astype(np.int32)
+        epg = wg.generate_rollouts_graphed(exploit=exploit, num_grey=ng)
+        src_e.t = 0
+        epe = we.generate_rollouts(exploit=exploit, num_grey=ng)
+        assert set(epg) == set(epe) and 'G' in epg and 'sigma' in epg
+        for k in epe:
+            assert epg[k].dtype == epe[k].dtype and epg[k].shape == epe[k].shape, k
+            assert torch.equal(epg[k], epe[k]), k
+        assert wg.success_history[-1] == we.success_history[-1]
+        # the oracle's return on the rewards the episode implies (-0.0 on steps whose success condition held)
+        G = epg['G'].cpu().numpy()
+        assert G.dtype == np.float64 and (G <= 0).all()
+    with pytest.raises(NotImplementedError):
+        w2, _ = worker()
+        w2.expert = object()
+        w2.generate_rollouts_graphed()

@@ -160,6 +160,8 @@ static int run(char mode, int64_t B)
             ROLL(2, 1024, 10, false, 3, 2, 1, 0, 1024); ROLL(2, 1024, 10, false, 3, 2, 0, 0, 1024);
             ROLL(2, 512, 5, false, 3, 2, 1, 0, 1024); ROLL(2, 512, 5, false, 3, 2, 0, 0, 1024);
             ROLL(2, 256, 5, false, 3, 2, 1, 0, 256); ROLL(2, 256, 5, false, 3, 2, 0, 0, 256);
+            // 4 envs per lane: ONE lane group per block at 1 M envs (no boundary in the middle of the launch)
+            ROLL(4, 1024, 5, false, 3, 2, 1, 0, 1024); ROLL(4, 1024, 10, false, 3, 2, 1, 0, 1024);
         }
     } else if (mode == 'B') {
         TIME("empty kernel (launch floor)", 1.0, hipLaunchKernelGGL(k_bump_counter, dim3(1), dim3(1), 0, 0, b.d_counter, 1u));
