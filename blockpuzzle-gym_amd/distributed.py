@@ -76,6 +76,27 @@ def global_success_rate(local_success_count, local_num_envs):
     return float(t[0].item() / t[1].item())
 
 
+def mpi_average(value, device=None):
+    """train.py:21-26 (`mpi_average`, used for every logged statistic, :67-73): the mean over ALL ranks' values --
+    a scalar or a list per rank (an empty list counts as [0.]), weighted by how many values a rank holds, as
+    baselines' mpi_moments computes it -- with one all-reduce of (sum, count) over RCCL / gloo instead of MPI.
+    `device`: where the two-element tensor lives (the rank's GPU for the nccl backend; default: the current CUDA
+    device when the backend is nccl, else the CPU)."""
+    import numpy as np
+    if isinstance(value, (list, tuple)) and len(value) == 0:
+        value = [0.]
+    if not isinstance(value, (list, tuple)):
+        value = [value]
+    x = np.asarray([float(v) for v in value], np.float64)
+    if device is None:
+        device = (torch.device('cuda', torch.cuda.current_device())
+                  if dist.is_initialized() and dist.get_backend() == 'nccl' else torch.device('cpu'))
+    t = torch.tensor([x.sum(), float(x.size)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0].item() / t[1].item())
+
+
 def all_gather_per_env(local_values, shard_sizes=None):
     """All-gather of a per-env statistic (final is_success / episode return) into
     global env order: one collective per rollout (4 B/env; 2 MB per GPU at

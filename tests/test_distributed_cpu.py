@@ -30,7 +30,9 @@ def _worker(rank, world, port, total, q):
     succ = (torch.arange(start, stop) % 3 == 0)
     gathered = D.all_gather_per_env(local)
     rate = D.global_success_rate(succ.sum(), stop - start)
-    q.put((r, gathered.tolist(), rate))
+    # train.py:21-26 / :67-73: every logged statistic is averaged over the ranks (weighted by the number of values)
+    avg = [D.mpi_average(0.25 + r), D.mpi_average([1.0, 2.0, 3.0] if r == 0 else [10.0]), D.mpi_average([] if r == 0 else [4.0])]
+    q.put((r, gathered.tolist(), rate, avg))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -49,6 +51,13 @@ def test_two_rank_gather_and_success_rate(total):
         assert p.exitcode == 0
     expect = [0.5 * i for i in range(total)]
     expect_rate = sum(1 for i in range(total) if i % 3 == 0) / total
-    for _, gathered, rate in results:
+    for _, gathered, rate, avg in results:
         assert gathered == expect
         assert abs(rate - expect_rate) < 1e-12
+        assert avg == [0.75, 4.0, 2.0]          # (0.25 + 1.25) / 2; (1 + 2 + 3 + 10) / 4; ([0.] + [4.]) / 2
+
+
+def test_mpi_average_without_a_process_group():
+    sys.path.insert(0, ROOT)
+    from blockpuzzle_gym_amd import distributed as D
+    assert D.mpi_average(3.0) == 3.0 and D.mpi_average([1.0, 2.0]) == 1.5 and D.mpi_average([]) == 0.0
