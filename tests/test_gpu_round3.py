@@ -752,3 +752,27 @@ def test_graphed_pg_rollout_equals_eager():
         w2, _ = worker()
         w2.expert = object()
         w2.generate_rollouts_graphed()
+
+
+def test_trim_with_rows_that_start_off_a_16_byte_boundary():
+    """The staged observation rows use 16-byte loads only when the array starts on a 16-byte boundary."""
+    n = 333
+    rng = np.random.RandomState(3)
+    o = rng.standard_normal((n, 87)).astype(np.float32)
+    for j in range(4):
+        o[:, 11 + 19 * j + 15:11 + 19 * j + 19] = [0, 0, 1, 0] if j in (1, 3) else [1, 0, 0, 0]
+    g = rng.standard_normal((n, 36)).astype(np.float32)
+    ag = rng.standard_normal((n, 36)).astype(np.float32)
+    want = O.trim(o, g, ag, 40, 16, True)
+    for off in (1, 2, 3):
+        dev = lambda a: torch.cat([torch.zeros(off, device=DEV), torch.as_tensor(a, device=DEV).reshape(-1)])[off:].view(a.shape)   # noqa: E731
+        do, dg, dag = dev(o), dev(g), dev(ag)
+        assert do.data_ptr() % 16 != 0
+        o_ = torch.empty((n, 40), dtype=torch.float64, device=DEV)
+        g_, ag_ = torch.empty((n, 16), device=DEV), torch.empty((n, 16), device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        bpg._lib.check(L.bpg_trim_expert_inputs(P(do), P(dg), P(dag), n, 87, 36, 40, 16, 4, 1, P(o_), P(g_), P(ag_), P(flag), 0, None))
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        for got, exp in zip((o_, g_, ag_), want):
+            np.testing.assert_array_equal(got.cpu().numpy(), exp)
