@@ -367,8 +367,85 @@ static int run_timeline(int64_t B)
     return 0;
 }
 
+// mode P: the policy-gradient call (rollout with flags + step-ok words, then the expansion of the words into G rows) as
+// two launches one after the other, against the same work split into env halves on two streams: rollout A, then
+// rollout B and the expansion of A side by side (a read-heavy and a write-only kernel share the chip), then the
+// expansion of B.
+static int run_pg_split(int64_t B)
+{
+    Bufs b;
+    const int T = 50;
+    if (setup(b, B, T, true)) return 1;
+    const StepConst c = mk_c();
+    const SynthConst s = mk_s();
+    ResetConst rc = mk_rc(b);
+    const PowTable pw = mk_pw(T);
+    CountArgs ca{};
+    hipStream_t s0, s1;
+    hipEvent_t eA, eJ, t0, t1;
+    CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&eA, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&eJ, hipEventDisableTiming));
+    CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    constexpr int WPB = DR_LANE_WPB;
+    printf("== mode P  B = %lld envs, T = %d\n", (long long)B, T);
+    auto roll = [&](hipStream_t st, int64_t off, int64_t n) {
+        const RolloutGeometry geo = rollout_geometry(n, b.LD, b.LD, M + off, nullptr, F + off);
+        if (geo.epl == 2 && geo.block == 1024)
+            hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 2, true, 5, false, true, 1024, true, false>), dim3(geo.grid), dim3(geo.block), 0, st,
+                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1);
+        else
+            hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 2, true, 5, false, true, 256, true, false>), dim3(geo.grid), dim3(geo.block), 0, st,
+                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1);
+    };
+    auto expand = [&](hipStream_t st, int64_t off, int64_t n) {
+        hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), dim3((unsigned)((n + 64 * WPB - 1) / (64 * WPB))), dim3(64 * WPB), 0, st, pw,
+                           (const uint64_t *)(b.okbits + off), GG + off * T, n);
+    };
+    for (int rep = 0; rep < 4; rep++) {
+        for (int variant = 0; variant < 4; variant++) {
+            const int nparts = variant == 0 ? 1 : (variant == 1 ? 2 : (variant == 2 ? 4 : 2));
+            const bool serial_halves = variant == 3;          // the halves one after the other on ONE stream (what the split alone costs)
+            const int REP = 20;
+            float best = 1e9f;
+            for (int outer = 0; outer < 3; outer++) {
+                CK(hipEventRecord(t0, s0));
+                for (int r = 0; r < REP; r++) {
+                    rot++;
+                    if (nparts == 1) { roll(s0, 0, B); expand(s0, 0, B); continue; }
+                    const int64_t part = B / nparts;
+                    if (serial_halves) {
+                        for (int p = 0; p < nparts; p++) roll(s0, p * part, part);
+                        for (int p = 0; p < nparts; p++) expand(s0, p * part, part);
+                        continue;
+                    }
+                    CK(hipEventRecord(eJ, s0)); CK(hipStreamWaitEvent(s1, eJ, 0));     // fork
+                    for (int p = 0; p < nparts; p++) {
+                        roll(s0, p * part, part);
+                        if (p + 1 < nparts) {
+                            CK(hipEventRecord(eA, s0)); CK(hipStreamWaitEvent(s1, eA, 0));
+                            expand(s1, p * part, part);
+                        } else {
+                            expand(s0, p * part, part);
+                        }
+                    }
+                    CK(hipEventRecord(eJ, s1)); CK(hipStreamWaitEvent(s0, eJ, 0));     // join
+                }
+                CK(hipEventRecord(t1, s0)); CK(hipEventSynchronize(t1));
+                float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+                best = std::min(best, ms / REP);
+            }
+            const char *nm[4] = {"one rollout launch + one expansion launch (the library)", "2 env halves, expansion of A beside rollout B (2 streams)",
+                                 "4 env quarters, expansions beside the next rollouts (2 streams)", "2 env halves one after the other on one stream"};
+            printf("%-66s %8.2f us per pg rollout (%5.1f GB/s)\n", nm[variant], best * 1e3, (double)B * (T * 5 + 28 + 8 + 8 * T) / best / 1e6);
+        }
+    }
+    teardown(b);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && argv[1][0] == 'P') return run_pg_split(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'T') return run_timeline(atoll(argv[2]));
     if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F|T envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
