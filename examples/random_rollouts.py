@@ -45,3 +45,11 @@ episode = worker.generate_rollouts()                   # policy in the loop, one
 print('episode:', {k: tuple(v.shape) for k, v in episode.items()}, worker.logs('train'))
 episode = worker.generate_rollouts_fused()             # whole rollout in one launch
 print('fused success rate %.4f' % worker.current_success_rate())
+
+# 4. the evaluator's test loop (train.py:62-64) as ONE launch: 10 rollouts on recorded contacts ----------------
+K, T = 10, 50
+masks = bpg.time_major_empty(K * T, B, torch.int32, worker.device)           # (K*T, B) contact words, rows padded
+bpg._lib.check(bpg._lib.lib().bpg_synth_masks_ld(worker.env._h, 0, K * T, masks.data_ptr(), int(masks.stride(0)), None))
+worker.clear_history()
+rates = worker.evaluate_rollouts_fused(masks, n_rollouts=K)
+print('evaluator: %d rollouts in one launch, success rates %s -> %s' % (K, ['%.4f' % r for r in rates[:3]], worker.logs('test')))

@@ -776,3 +776,12 @@ def test_trim_with_rows_that_start_off_a_16_byte_boundary():
         assert int(flag.item()) == 0
         for got, exp in zip((o_, g_, ag_), want):
             np.testing.assert_array_equal(got.cpu().numpy(), exp)
+
+
+def test_random_rollouts_example_runs():
+    """examples/random_rollouts.py: the gym-style single env, the batched env, both rollout workers' call forms and
+    the evaluator loop in one launch -- as a user would run it."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'random_rollouts.py'), '4096'], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'evaluator: 10 rollouts in one launch' in out.stdout and 'fused success rate' in out.stdout
