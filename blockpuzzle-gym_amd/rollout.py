@@ -493,7 +493,7 @@ class PGRolloutStudent(RolloutStudent):
             return info['env_name']
         return self.env.spec.id                     # workers built without the policy's kwargs: the env's own id
 
-    def trim(self, o, g, ag, dimo, dimg, num_objs=4):
+    def trim(self, o, g, ag, dimo, dimg, num_objs=4, _defer_check=False):
         """policy_gradient/rollout.py:105-171: the inputs of an expert trained on a smaller puzzle -- the corner of
         the goal matrices that belongs to the first `num_objs` objects, and of the observation either its first
         `dimo` entries or (Variation) the env features plus the base features of the GREEN and BLUE blocks.
@@ -512,11 +512,12 @@ class PGRolloutStudent(RolloutStudent):
         o_ = torch.empty((n, dimo), dtype=torch.float64 if variation else torch.float32, device=self.device)
         g_ = torch.empty((n, dimg), dtype=torch.float32, device=self.device)
         ag_ = torch.empty((n, dimg), dtype=torch.float32, device=self.device)
-        self._trim_bad.zero_()
+        if not _defer_check:
+            self._trim_bad.zero_()
         _lib.check(_lib.lib().bpg_trim_expert_inputs(_ptr(o), _ptr(g), _ptr(ag), n, o.shape[1], g.shape[1], dimo, dimg,
                                                      int(num_objs), int(variation), _ptr(o_), _ptr(g_), _ptr(ag_),
                                                      _ptr(self._trim_bad), self.device.index, _stream(self.device)))
-        if variation and int(self._trim_bad.item()):
+        if variation and not _defer_check and int(self._trim_bad.item()):     # _defer_check: the rollout reads the flag once, at its end
             raise ValueError('trim: an observation row does not hold exactly %d GREEN / BLUE blocks '
                              '(policy_gradient/rollout.py:166)' % (num_objs - 2))
         if as_numpy:
@@ -564,10 +565,14 @@ class PGRolloutStudent(RolloutStudent):
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), device=self.device,
                                   dtype=torch.float64 if self.expert is not None else torch.float32)
         reward = time_major_empty(T, B, torch.float32, self.device)
+        defer = self.expert is not None and self.output == 'torch'
+        if defer:
+            self._trim_bad.zero_()
         for t in range(T):
             o, ag = ep['o'][t], ep['ag'][t]
             if np.random.rand() < beta:            # the expert is in charge (:196-200)
-                o_, g_, ag_ = self.trim(o, self.g, ag, self.expert.dimo, self.expert.dimg)
+                # device-resident experts: no host read of the bad-row flag per step, one at the end of the rollout
+                o_, g_, ag_ = self.trim(o, self.g, ag, self.expert.dimo, self.expert.dimg, _defer_check=defer)
                 u, raw = self.expert.get_actions(*self._policy_in(o_, ag_, g_), compute_raw=True)
                 sigma = None
             else:
@@ -579,6 +584,9 @@ class PGRolloutStudent(RolloutStudent):
             if sigma is not None:
                 ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
             self._step_into(u, ep, t, reward_out=reward[t])
+        if defer and int(self._trim_bad.item()):
+            raise ValueError('trim: an observation row did not hold exactly 2 GREEN / BLUE blocks at some step of the '
+                             'rollout (policy_gradient/rollout.py:166)')
         if self._watch_o:
             self.initial_o = ep['o'][T]
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}

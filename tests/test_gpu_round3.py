@@ -785,3 +785,46 @@ def test_random_rollouts_example_runs():
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'evaluator: 10 rollouts in one launch' in out.stdout and 'fused success rate' in out.stdout
+
+
+def test_device_resident_expert_gets_trimmed_device_tensors_without_a_sync_per_step():
+    """output='torch': the expert is handed device tensors (o_ float64 for Variation), the bad-row flag of trim is read
+    once at the end of the rollout -- and a row that breaks the expert's assumption still raises ValueError."""
+    env_id, B, T = 'BlocksTouchVariation-v0', 300, 50
+    seen = []
+
+    class Policy(_NamedPolicy):
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, exploit=False):
+            u = torch.zeros((o.shape[0], 4), device=o.device)
+            return u, u, u
+
+    class Expert:
+        dimo, dimg = 40, 16
+
+        def get_actions(self, o, ag, g, compute_raw=False):
+            assert o.is_cuda and o.dtype == torch.float64 and o.shape == (B, 40)
+            assert ag.is_cuda and ag.dtype == torch.float32 and ag.shape == (B, 16) and g.shape == (B, 16)
+            seen.append(o)
+            u = torch.zeros((B, 4), device=o.device)
+            return u, u
+
+    w = bpg.PGRolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=1), Policy(env_id), Expert(),
+                             dims_of(env_id), None, T, rollout_batch_size=B, gamma=0.98, beta_final=1.0, annealing_coeff=1.0,
+                             output='torch')
+    ep = w.generate_rollouts()
+    assert len(seen) == T and ep['G'].shape == (B, T) and ep['sigma'].dtype == torch.float64
+    # the expert saw the trimmed form of the episode's own observations
+    want = O.trim(ep['o'][:, 3].cpu().numpy(), ep['g'][:, 3].cpu().numpy(), ep['ag'][:, 3].cpu().numpy(), 40, 16, True)[0]
+    np.testing.assert_array_equal(seen[3].cpu().numpy(), want)
+    # a third coloured block in some row: the deferred form raises nothing at the call, the flag stays set for the read
+    # at the end of the rollout; the immediate form raises NumPy's ValueError
+    o = ep['o'][:, 0].clone()
+    o[7, 11 + 19 * 2 + 15:11 + 19 * 2 + 19] = torch.tensor([0., 0., 0., 1.], device=DEV)
+    w._trim_bad.zero_()
+    w.trim(o, ep['g'][:, 0], ep['ag'][:, 0], 40, 16, _defer_check=True)
+    w.trim(ep['o'][:, 0], ep['g'][:, 0], ep['ag'][:, 0], 40, 16, _defer_check=True)      # a good call does not clear it
+    assert int(w._trim_bad.item()) == 1
+    with pytest.raises(ValueError):
+        w.trim(o, ep['g'][:, 0], ep['ag'][:, 0], 40, 16)
