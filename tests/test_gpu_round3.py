@@ -828,3 +828,34 @@ def test_device_resident_expert_gets_trimmed_device_tensors_without_a_sync_per_s
     assert int(w._trim_bad.item()) == 1
     with pytest.raises(ValueError):
         w.trim(o, ep['g'][:, 0], ep['ag'][:, 0], 40, 16)
+
+
+@pytest.mark.parametrize('B,K,T', [(1, 4096, 1), (3, 2, 1023), (65, 7, 64), (2, 3, 65)])
+def test_k_rollouts_at_the_edges_of_the_argument_ranges_against_the_oracle(B, K, T):
+    """One env, the largest K, the longest horizon (the elapsed counter saturates at 1023), odd tiny batches: every
+    rollout of the launch against one oracle env per slot (reset with the r-th draw, T steps on the r-th rows)."""
+    env_id = 'BlocksTouchVariation-v0'
+    rng = np.random.RandomState(B * 7 + K)
+    ng = rng.randint(3, size=(K, B)).astype(np.int32)
+    masks = np.concatenate([legal_masks(rng, T, B, 4 + ng[k], density=2) for k in range(K)])
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=1, max_episode_steps=50)
+    dm, dng = i32(masks), torch.as_tensor(ng, device=DEV)
+    rew = torch.empty((K * T, B), dtype=torch.float32, device=DEV)
+    flg = torch.empty((K * T, B), dtype=torch.uint8, device=DEV)
+    cnt = torch.zeros(K, dtype=torch.int64, device=DEV)
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
+                             d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr())
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    torch.cuda.synchronize()
+    rew, flg = rew.cpu().numpy().view(np.uint32), flg.cpu().numpy()
+    oenvs = [O.OracleEnv(env_id) for _ in range(B)]
+    for k in (range(K) if K <= 8 else (0, 1, K // 2, K - 1)):
+        succ = 0
+        for b, e in enumerate(oenvs):
+            e.reset(num_grey=int(ng[k, b]))
+            for t in range(T):
+                ag, r, done, ok = e.step_mask(int(masks[k * T + t, b]))
+                assert rew[k * T + t, b] == np.float32(r).view(np.uint32)
+                assert (flg[k * T + t, b] & 3) == (int(ok) | (int(done) << 1)), (k, t, b)
+            succ += int(e.e.has_succeeded)
+        assert int(cnt[k].item()) == succ
