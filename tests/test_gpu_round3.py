@@ -859,3 +859,27 @@ def test_k_rollouts_at_the_edges_of_the_argument_ranges_against_the_oracle(B, K,
                 assert (flg[k * T + t, b] & 3) == (int(ok) | (int(done) << 1)), (k, t, b)
             succ += int(e.e.has_succeeded)
         assert int(cnt[k].item()) == succ
+
+
+def test_step_with_in_kernel_contacts_equals_the_same_contacts_read_from_memory():
+    """bpg_step_synth (contacts drawn inside the step launch, keyed by seed, env and the env's elapsed step) ==
+    bpg_synth_masks for the same steps fed through bpg_step_masks: state, reward bits and flags, over a reset;
+    bpg_num_envs reports the handle's batch size."""
+    env_id, B, T = 'BlocksTouchVariation-v0', 70001, 12
+    a = bpg.make(env_id, num_envs=B, device=DEV, seed=21)
+    b = bpg.make(env_id, num_envs=B, device=DEV, seed=21)
+    assert int(L.bpg_num_envs(a._h)) == B
+    ng = torch.as_tensor(np.random.RandomState(0).randint(3, size=B).astype(np.int32), device=DEV)
+    for episode in range(2):
+        a.reset(num_grey=ng), b.reset(num_grey=ng)
+        m = torch.empty((T, B), dtype=torch.int32, device=DEV)
+        bpg._lib.check(L.bpg_synth_masks(b._h, 0, T, P(m), None))
+        for t in range(T):
+            ra, fa = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.uint8, device=DEV)
+            rb, fb = torch.empty(B, device=DEV), torch.empty(B, dtype=torch.uint8, device=DEV)
+            bpg._lib.check(L.bpg_step_synth(a._h, P(ra), P(fa), None))
+            bpg._lib.check(L.bpg_step_masks(b._h, P(m[t]), P(rb), P(fb), None))
+            assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(fa, fb), (episode, t)
+        for key, v in a.state_dict().items():
+            assert torch.equal(v, b.state_dict()[key]), key
+    assert int(a.success_count().item()) == int((fa & 1).sum().item()) > 0
