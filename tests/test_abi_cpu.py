@@ -219,3 +219,17 @@ def test_header_is_plain_c_and_its_structs_have_the_layout_ctypes_assumes(tmp_pa
         assert int(out[cname + '.size']) == C.sizeof(ct), cname
         for f in ct._fields_:
             assert int(out['%s.%s' % (cname, f[0])]) == getattr(ct, f[0]).offset, (cname, f[0])
+
+
+def test_every_entry_point_is_exercised_somewhere():
+    """No entry point of the header may exist only as a declaration: each one is either called by the host package
+    (whose paths the GPU tests drive) or named by a test directly."""
+    import glob
+    header = open(os.path.join(ROOT, 'include', 'bpgym.h')).read()
+    declared = sorted(set(re.findall(r'\b(bpg_[a-z0-9_]+)\s*\(', header)))
+    tests = ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'tests', '*.py')) if not f.endswith('test_abi_cpu.py'))
+    pkg = ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'blockpuzzle-gym_amd', '*.py')))
+    idle = [n for n in declared
+            if not re.search(r'\b%s\b' % n, tests) and len(re.findall(r'\b%s\b' % n, pkg)) < 2]      # 1 = the signature table only
+    assert idle == ['bpg_version'], idle            # bpg_version: below
+    assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 103
