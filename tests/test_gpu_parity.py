@@ -880,6 +880,27 @@ def test_rollout_worker_small_surface(tmp_path):
     assert isinstance(pickle.load(open(path, 'rb')), P)
     w.clear_history()
     assert len(w.success_history) == 0
+    # compute_Q: the policy returns (u, Q); mean_Q is logged and averaged over the history (rollout.py:99-107, :176-178)
+    class QPolicy:
+        def get_actions(self, o, ag, g, compute_Q=False, **kw):
+            assert compute_Q
+            return np.zeros((o.shape[0], 4), np.float32), np.full((o.shape[0], 1), 0.25, np.float32)
+    wq = bpg.RolloutStudent(lambda: bpg.make(env_id, device=DEV), QPolicy(), dims_of(env_id), None, 50,
+                            rollout_batch_size=2, compute_Q=True)
+    wq.generate_rollouts()
+    assert wq.current_mean_Q() == pytest.approx(0.25) and ('worker/mean_Q', pytest.approx(0.25)) in [(k, pytest.approx(v)) for k, v in wq.logs()]
+    # the policy-gradient worker hands save_policy_weights to the policy (policy_gradient/rollout.py:313-314)
+    saved = []
+
+    class WPolicy(P):
+        kwargs = {}
+
+        def save_weights(self, path):
+            saved.append(path)
+    wp = bpg.PGRolloutStudent(lambda: bpg.make(env_id, device=DEV), WPolicy(), None, dims_of(env_id), None, 50,
+                              rollout_batch_size=2, gamma=0.98)
+    wp.save_policy_weights(str(tmp_path))
+    assert saved == [str(tmp_path)]
 
 
 def test_callable_contact_source_with_observation():
