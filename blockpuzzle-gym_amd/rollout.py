@@ -177,8 +177,9 @@ class RolloutStudent:
         success_rate = float(self.env.success_count().item()) / self.rollout_batch_size
         self.success_history.append(success_rate)
         if self.compute_Q and len(Qs):
-            self.Q_history.append(float(np.mean([float(np.mean(q.detach().cpu().numpy() if torch.is_tensor(q) else q))
-                                                  for q in Qs])))
+            # rollout.py:168-169 `self.Q_history.append(np.mean(Qs))`: NumPy's mean over the stacked per-step arrays, in
+            # their own dtype -- the same expression on the same values (device tensors are brought to the host once)
+            self.Q_history.append(np.mean([q.detach().cpu().numpy() if torch.is_tensor(q) else q for q in Qs]))
         self.n_episodes += self.rollout_batch_size
         if 'is_success' not in self.info_keys:       # only keys named in dims (rollout.py:35,160-161)
             episode = {k: v for k, v in episode.items() if k != 'info_is_success'}

@@ -388,12 +388,17 @@ class RandomPolicy:
         self.rng = np.random.RandomState(seed)
         self.log = log
         self.kwargs = {}
+        self.qlog = []
 
     def get_actions(self, o, ag, g, **kw):
         u = self.rng.uniform(-1, 1, size=(o.shape[0], 4)).astype(np.float32)
         self.log.append(u)
         if 'exploit' in kw:      # policy_gradient/rollout.py:202-204
             return u, u.copy(), np.zeros_like(u)
+        if kw.get('compute_Q'):  # rollout.py:99-103: (u, Q)
+            Q = self.rng.standard_normal((o.shape[0], 1)).astype(np.float32)
+            self.qlog.append(Q)
+            return u, Q
         return u
 
 
@@ -403,7 +408,7 @@ class NullLogger:
     info = warning
 
 
-def rollout_trace(env_id, seed, B, modes, pg=False):
+def rollout_trace(env_id, seed, B, modes, pg=False, compute_Q=False):
     """Reference RolloutStudent.generate_rollouts (rollout.py:75-172 or the
     policy_gradient variant) over B scripted envs."""
     H.install()
@@ -427,6 +432,7 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
 
     np.random.seed(seed)
     probe = H.make(env_id)
+    probe.seed(seed + 999)        # see expert_rollout_trace: an unseeded probe can move the global stream
     o = probe.reset()
     dims = dict(o=o['observation'].shape[0], u=4, g=o['desired_goal'].shape[0],
                 info_is_success=1)
@@ -437,6 +443,8 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
               rollout_batch_size=B)
     if pg:
         kw.update(expert=None, gamma=1. - 1. / T)
+    if compute_Q:
+        kw.update(compute_Q=True)
     worker = RolloutStudent(**kw)
     worker.seed(seed)
     out = dict(T=np.int32(T), B=np.int32(B), modes=np.asarray(modes, np.uint8))
@@ -444,9 +452,14 @@ def rollout_trace(env_id, seed, B, modes, pg=False):
         for log in logs:
             del log[:]
         del ulog[:]
+        del policy.qlog[:]
         ep = worker.generate_rollouts(test=bool(test))
         for k, v in ep.items():
             out['r%d_%s' % (r, k)] = v
+        if compute_Q:            # rollout.py:168-169, :182-184, :197-198
+            out['r%d_Q' % r] = np.asarray(policy.qlog)                       # (T, B, 1) float32, as the policy returned them
+            out['r%d_Q_history_last' % r] = np.asarray(worker.Q_history[-1])  # np.mean(Qs): a float32 scalar
+            out['r%d_current_mean_Q' % r] = np.asarray(worker.current_mean_Q())
         con = -np.ones((B, T, MAXCON, 2), np.int16)
         ncon = np.zeros((B, T), np.int32)
         for b, log in enumerate(logs):
@@ -538,6 +551,7 @@ def expert_rollout_trace(env_id, seed, B, dimo, dimg, n_rollouts=2):
 
     np.random.seed(seed)
     probe = H.make(env_id)
+    probe.seed(seed + 999)        # an unseeded probe draws from OS entropy and, through its placement loops, moves the GLOBAL stream (Q7)
     o = probe.reset()
     dims = dict(o=o['observation'].shape[0], u=4, g=o['desired_goal'].shape[0], info_is_success=1)
     T = probe._max_episode_steps
@@ -651,6 +665,8 @@ def main(HERE=HERE):
                         **expert_rollout_trace('BlocksTouchVariation-v0', seed=810, B=4, dimo=40, dimg=16))
     np.savez_compressed(os.path.join(HERE, 'pg_expert_rollout_BlocksTouchChoose.npz'),
                         **expert_rollout_trace('BlocksTouchChoose-v0', seed=811, B=3, dimo=40, dimg=16))
+    np.savez_compressed(os.path.join(HERE, 'rollout_Q_BlocksTouch.npz'),
+                        **rollout_trace('BlocksTouch-v0', seed=860, B=5, modes=[0, 0, 0], compute_Q=True))
     print('golden fixtures written to', HERE)
 
 

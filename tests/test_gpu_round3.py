@@ -883,3 +883,37 @@ def test_step_with_in_kernel_contacts_equals_the_same_contacts_read_from_memory(
         for key, v in a.state_dict().items():
             assert torch.equal(v, b.state_dict()[key]), key
     assert int(a.success_count().item()) == int((fa & 1).sum().item()) > 0
+
+
+def test_golden_rollout_with_compute_q_keeps_the_references_mean_q():
+    """rollout.py:99-107, :168-169, :182-184: with compute_Q the policy returns (u, Q), the worker appends np.mean(Qs)
+    to Q_history -- float32, NumPy's mean over the stacked arrays -- and current_mean_Q / logs average the history."""
+    env_id = 'BlocksTouch-v0'
+    d = np.load(os.path.join(GOLDEN, 'rollout_Q_BlocksTouch.npz'))
+    B, T = int(d['B']), int(d['T'])
+
+    class Replay:
+        def get_actions(self, o, ag, g, compute_Q=False, **kw):
+            assert compute_Q is True
+            u, q = self.u[:, self.t], self.q[self.t]
+            self.t += 1
+            return u, q
+
+    policy, src = Replay(), bpg.ScriptedContacts()
+    w = bpg.RolloutStudent(lambda: bpg.make(env_id, device=DEV, contact_source=src), policy, dims_of(env_id), None, T,
+                           rollout_batch_size=B, compute_Q=True)
+    w.env.contact_source = src
+    for r in range(len(d['modes'])):
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        src.pairs = np.ascontiguousarray(con.transpose(1, 0, 2, 3))
+        src.ncon = np.ascontiguousarray(d['r%d_ncon' % r].T)
+        src.masks, src.t = None, 0
+        policy.u, policy.q, policy.t = d['r%d_u' % r], d['r%d_Q' % r], 0
+        ep = w.generate_rollouts()
+        np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
+        got, want = w.Q_history[-1], d['r%d_Q_history_last' % r]
+        assert np.asarray(got).dtype == want.dtype and np.asarray(got).tobytes() == want.tobytes()
+        cm = np.asarray(w.current_mean_Q())
+        assert cm.dtype == d['r%d_current_mean_Q' % r].dtype and cm.tobytes() == d['r%d_current_mean_Q' % r].tobytes()
+        assert dict(w.logs())['worker/mean_Q'] == cm
