@@ -29,14 +29,24 @@ class VariantInfo(C.Structure):
 
 
 class RolloutArgs(C.Structure):
+    """bpg_rollout_args; struct_size is filled in with this mirror's size (BPG_ROLLOUT_ARGS_INIT) unless given."""
     _fields_ = [
-        ('T', C.c_int32), ('reset_first', C.c_int32), ('d_num_grey', C.c_void_p),
+        ('struct_size', C.c_uint32), ('T', C.c_int32), ('reset_first', C.c_int32), ('rollouts', C.c_int32),
+        ('d_num_grey', C.c_void_p),
         ('d_masks', C.c_void_p), ('d_reward_tb', C.c_void_p), ('d_flags_tb', C.c_void_p),
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
         ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
-        ('d_G', C.c_void_p), ('gamma', C.c_double), ('rollouts', C.c_int32), ('reserved_', C.c_int32),
+        ('d_G', C.c_void_p), ('gamma', C.c_double), ('d_episode_return', C.c_void_p),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not args and 'struct_size' not in kw:
+            self.struct_size = C.sizeof(RolloutArgs)
+
+
+ROLLOUT_ARGS_MIN_SIZE = 120
 
 
 class PhysState(C.Structure):

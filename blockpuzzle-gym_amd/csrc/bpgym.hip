@@ -30,6 +30,7 @@
 #pragma STDC FP_CONTRACT OFF
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -156,7 +157,8 @@ struct bpg_batch {
     int8_t *d_id2obj;   // [BPG_MAX_MODELS][BPG_MAX_GEOMS]
     int ngeom[BPG_MAX_MODELS];
     unsigned long long *d_count_shards;   // COUNT_SHARDS words on 128-byte lines of their own (block_count_add)
-    uint64_t *d_okbits;                   // n words: the step-ok bits of the last rollout that asked for G
+    uint64_t *d_okbits;                   // n words: the step-ok bits of the last rollout that asked for G; allocated by
+                                          // the first bpg_rollout call with d_G (NULL until then)
 };
 
 namespace bpgk {   // kernels + launch helpers (named so profiles read bpgk::k_*)
@@ -923,12 +925,13 @@ __device__ unsigned long long *bpg_timeline = nullptr;
 #define BPG_TL(slot) do { } while (0)
 #endif
 template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
-          bool MULTI = false>
+          bool MULTI = false, bool RET = false>
 __global__ void __launch_bounds__(LB)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks_all,
           uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
-          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts)
+          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts,
+          uint32_t *__restrict__ ep_return_all)
 {
     static_assert(!MULTI || (RESET && !OKB), "several rollouts per launch: each starts with its reset; no step-ok words");
     using Vec = typename LaneVec<EPL>::vec;
@@ -944,6 +947,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const uint32_t *__restrict__ masks = masks_all + (MULTI ? (int64_t)ro * T * ld_masks : 0);
     uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
     uint8_t *__restrict__ flags_tb = flags_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
+    uint32_t *__restrict__ ep_return = ep_return_all ? ep_return_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
     uint32_t nsucc = 0;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
@@ -960,6 +964,12 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         // step_core turned into sign-bit arithmetic -- 11 instead of ~20 instructions per env-step.
         uint32_t cm[EPL], ev[EPL], el[EPL], lat[EPL], stk[EPL];
         uint64_t okb[EPL];                          // OKB: bit t = the success condition held at step t
+        // RET: steps of this launch whose success condition held, counted for every env (one subtraction per
+        // env-step): the undiscounted episode return is -(T - nok), bpg_rollout_args.d_episode_return.  Compile-time,
+        // because the contacts-in-kernel form lives on occupancy and loses a wave per SIMD to the two extra registers.
+        // With OKB the count is the population of the step-ok word and costs nothing per step.
+        constexpr bool COUNT = RET && !OKB;
+        uint32_t nok[EPL] = {};
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
             if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
@@ -989,6 +999,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                 const uint32_t bad = (c.want_touch & ~cm[k]) | (c.want_never & ev[k]);    // < 2^21
                 const uint32_t okm = (uint32_t)((int32_t)(bad - 1u) >> 31);               // ~0 iff bad == 0
                 lat[k] |= okm;
+                if (COUNT) nok[k] -= okm;                                                 // okm is 0 or -1
                 if (OKB) okpart[k] |= okm & ubit;
                 el[k] = min(el[k] + 1u, ELAPSED_MAX);
                 const uint32_t dn = ((c.max_steps - 1u - el[k]) >> 30) & (uint32_t)BPG_FLAG_DONE;   // el >= max_steps
@@ -1093,6 +1104,18 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         if constexpr (OKB) {
 #pragma unroll
             for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
+        }
+        if constexpr (RET || OKB) {
+            if (ep_return) {                        // uniform (an OKB launch may or may not be asked for the return)
+                // r[0] + r[1] + ... of T float32 rewards in {-1.0f, -0.0f}: -(number of -1.0f), -0.0f if there is none
+                uint32_t rt[EPL];
+#pragma unroll
+                for (int k = 0; k < EPL; k++) {
+                    const uint32_t held = OKB ? (uint32_t)__popcll(okb[k]) : nok[k];
+                    rt[k] = __float_as_uint(-(float)((uint32_t)T - held));
+                }
+                reinterpret_cast<Vec *>(ep_return)[v] = pack<EPL>(rt);
+            }
         }
         if (tl_pass < 2) BPG_TL(3 + 4 * tl_pass);
         tl_pass++;
@@ -1689,7 +1712,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
           int64_t n, int T, int64_t ldm, int64_t ldo, int RC, int R, StepConst c, SynthConst s, PairTable tabv,
-          ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits_out)
+          ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits_out, float *__restrict__ ep_return)
 {
     // The T+1 matrices of an episode are produced in chunks of RC rows (one chunk = the whole
     // episode for T <= 63): a short step phase (lane = env, state in registers, packed rows of
@@ -1708,6 +1731,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const int64_t i = base + (active ? lane : 0);
     uint32_t a = 0, e = 0;
     uint64_t okb = 0ull;                 // bit t = the success condition held at step t (t < 64): the step rewards
+    uint32_t nfail = 0;                  // steps whose success condition did not hold: the episode return is -nfail
     SynthLane sl = {};
     if (active) {
         a = now[i]; e = ever[i];
@@ -1739,6 +1763,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                         step_core(a, e, m, c, rb, fl);
                         my[t + 1 - r0] = make_uint2(a, e);
                         okb |= (uint64_t)((fl >> 2) & 1u) << (t & 63);
+                        nfail += ((fl >> 2) & 1u) ^ 1u;
                         if (reward_tb) reward_tb[(int64_t)t * ldo + i] = rb;
                         if (flags_tb) flags_tb[(int64_t)t * ldo + i] = (uint8_t)fl;
                     }
@@ -1769,6 +1794,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         // the step rewards of the episode as one word per env: k_returns_from_okbits turns it into the env's
         // G row (policy_gradient/rollout.py:255-258)
         if (okbits_out) okbits_out[i] = okb;
+        if (ep_return) ep_return[i] = -(float)nfail;              // bpg_rollout_args.d_episode_return
     }
     if (ca.count && lane < 64) {
         const unsigned long long nb = (unsigned long long)__popcll(__ballot(active && (e >> 31) != 0));
@@ -2197,7 +2223,7 @@ constexpr int DR_LANE_WPB = 4;              // waves per block (each wave: 64 en
 template <int TT, int MODE, int WPB, int TR = G_TILE_ROWS>
 __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
-                         double *__restrict__ G)
+                         double *__restrict__ G, int allow_plain)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2220,7 +2246,9 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
             acc[t] = __fma_rn(gamma, acc[t + 1], (double)__uint_as_float(r[t]));
         });
     } else {
-        bool plain = true;                    // every reward of this env is -1.0f or -0.0f
+        // every reward of this env is -1.0f or -0.0f -- and every gamma**k is finite and >= 0 (allow_plain, see
+        // gamma_is_subtractable()): only then is the conditional subtraction the reference's product + sum bit for bit
+        bool plain = allow_plain != 0;
         uint64_t ok = 0ull;
         static_for<0, TT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -2557,12 +2585,12 @@ constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
 struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
-                                 const void *flags)
+                                 const void *flags, const void *ep_return = nullptr)
 {
     // 2 envs per lane need an even batch, even row strides and 8-byte aligned mask / reward streams
     // (2-byte flags)
     const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
-                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0;
+                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0 && ((uintptr_t)ep_return & 7u) == 0;
     RolloutGeometry g;
     g.unroll = 5;
     if (ok2 && n >= 131072 && !masks) {
@@ -2652,7 +2680,7 @@ using namespace bpgk;
 extern "C" {
 
 const char *bpg_last_error(void) { return g_err.c_str(); }
-int bpg_version(void) { return 103; }    // 100 + round
+int bpg_version(void) { return 104; }    // 100 + round
 
 int bpg_variant_from_id(const char *env_id)
 {
@@ -2722,7 +2750,6 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     if (e3 == hipSuccess) e3 = hipMalloc(&b->d_reset_counter, 2 * sizeof(uint32_t));
     const size_t shard_bytes = (size_t)COUNT_SHARDS * COUNT_SHARD_STRIDE * sizeof(unsigned long long);
     if (e3 == hipSuccess) e3 = hipMalloc(&b->d_count_shards, shard_bytes);
-    if (e3 == hipSuccess) e3 = hipMalloc(&b->d_okbits, (size_t)((n_envs + 1) & ~(int64_t)1) * sizeof(uint64_t));
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         bpg_destroy(b);
         return fail(BPG_ERR_HIP, "hipMalloc failed for the packed state");
@@ -3281,9 +3308,33 @@ static int launch_returns_from_okbits(const uint64_t *d_okbits, double *d_G, int
     return check_launch("k_returns_from_okbits");
 }
 
-int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
+// gamma for which the conditional-subtract form of the return (returns_from_okbits, the `plain` waves of
+// k_discounted_return_lane) has the reference's bits: every gamma**k, k < T, finite and >= 0.  With gamma < 0 the
+// reference's `+= gamma**k * r` turns a -0.0 accumulator into +0.0 (the product of an odd power and -0.0 is +0.0), and
+// an overflowing power makes inf * -0.0 = NaN; both need the real product + sum.
+static bool gamma_is_subtractable(double gamma, int T)
 {
-    if (!b || !a) return fail(BPG_ERR_ARG, "NULL argument");
+    if (!(gamma >= 0.0) || std::signbit(gamma)) return false;      // -0.0 too: (-0.0)**k * -0.0 is +0.0 for odd k
+    return std::isfinite(std::pow(gamma, (double)(T > 1 ? T - 1 : 1)));
+}
+
+int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
+{
+    if (!b || !args) return fail(BPG_ERR_ARG, "NULL argument");
+    // struct versioning (include/bpgym.h): fields the caller's header did not have are zero; bytes this library does
+    // not know must be zero
+    static_assert(offsetof(bpg_rollout_args, gamma) + sizeof(double) == BPG_ROLLOUT_ARGS_MIN_SIZE, "BPG_ROLLOUT_ARGS_MIN_SIZE");
+    const size_t caller_size = args->struct_size;
+    if (caller_size < BPG_ROLLOUT_ARGS_MIN_SIZE || caller_size > 4096 || caller_size % 8 != 0)
+        return fail(BPG_ERR_ARG, "bpg_rollout_args.struct_size is not set (use BPG_ROLLOUT_ARGS_INIT; this library is "
+                                 "bpg_version() 104)");
+    bpg_rollout_args local;
+    std::memset(&local, 0, sizeof(local));
+    std::memcpy(&local, args, caller_size < sizeof(local) ? caller_size : sizeof(local));
+    for (size_t i = sizeof(local); i < caller_size; i++)
+        if (reinterpret_cast<const unsigned char *>(args)[i] != 0)
+            return fail(BPG_ERR_UNSUPPORTED, "bpg_rollout_args carries fields this library (bpg_version() 104) does not know");
+    const bpg_rollout_args *a = &local;
     if (a->T < 1 || a->T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
     if ((a->d_success_count && ((uintptr_t)a->d_success_count & 7u)) ||
         (a->d_zero_count && ((uintptr_t)a->d_zero_count & 7u)))
@@ -3308,10 +3359,27 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     if (a->d_G) {
         if (!(a->gamma == a->gamma)) return fail(BPG_ERR_ARG, "gamma is NaN");
         if (((uintptr_t)a->d_G & 7u) != 0) return fail(BPG_ERR_ARG, "d_G must be 8-byte aligned");
-        if (a->T <= 64) gmode = G_OKBITS;
+        if (a->T <= 64 && gamma_is_subtractable(a->gamma, a->T)) gmode = G_OKBITS;
         else if (a->T > DR_TMAX) return fail(BPG_ERR_ARG, "d_G needs T <= 319");
-        else if (!a->d_reward_tb) return fail(BPG_ERR_ARG, "d_G with T > 64 needs d_reward_tb (the return is computed from the reward stream)");
+        else if (!a->d_reward_tb)
+            return fail(BPG_ERR_ARG, "d_G with T > 64, a negative gamma or overflowing powers of gamma needs d_reward_tb "
+                                     "(the return is then computed from the reward stream)");
         else gmode = G_FROM_REWARD;
+    }
+    if (a->d_episode_return && ((uintptr_t)a->d_episode_return & 3u) != 0)
+        return fail(BPG_ERR_ARG, "d_episode_return must be 4-byte aligned");
+    if (gmode == G_OKBITS && !b->d_okbits) {
+        // the step-ok words are handle-owned scratch, allocated by the first call that asks for d_G: a hipMalloc is not
+        // a stream operation, so that call must not sit inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(BPG_ERR_ARG, "the first bpg_rollout call with d_G allocates the handle's step-ok words: make it once "
+                                     "outside the stream capture (a warm-up call does)");
+        if (hipMalloc(&b->d_okbits, (size_t)((b->n + 1) & ~(int64_t)1) * sizeof(uint64_t)) != hipSuccess) {
+            b->d_okbits = nullptr;
+            return fail(BPG_ERR_HIP, "hipMalloc failed for the step-ok words");
+        }
     }
     uint64_t *okbits = gmode == G_OKBITS ? b->d_okbits : nullptr;
     // several rollouts in one launch (stream path only): rollout r = reset + T steps + count on rows r*T .. of the streams
@@ -3322,12 +3390,19 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
     int rcode = BPG_OK;
     if (!episode) {
         const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
-        const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb);
+        const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb,
+                                                     a->d_episode_return);
         const dim3 grid(geo.grid), block(geo.block);
-#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI)                                    \
-        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, MULTI>), grid, block, 0, st, \
+#define BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, RET)                               \
+        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, MULTI, RET>), grid, block, 0, st, \
                            b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits,  \
-                           rollouts)
+                           rollouts, reinterpret_cast<uint32_t *>(a->d_episode_return))
+        // the in-loop counter only where the return is asked for and there is no step-ok word to take it from
+#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI)                                    \
+        do {                                                                                                  \
+            if (a->d_episode_return && !(OKB)) BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, false, MULTI, true); \
+            else BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, false);                   \
+        } while (0)
 #define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
         do {                                                                                                  \
             if (rollouts > 1) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, false, true);           \
@@ -3362,6 +3437,7 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
 #undef BPG_LAUNCH_ROLLOUT_1
 #undef BPG_LAUNCH_ROLLOUT_2
 #undef BPG_LAUNCH_ROLLOUT_3
+#undef BPG_LAUNCH_ROLLOUT_4
         rcode = check_launch("k_rollout");
     } else {
         if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
@@ -3385,21 +3461,14 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *a, void *stream)
         const bool synth = (a->d_masks == nullptr);
         rcode = dispatch_side(b->info.side, [&](auto side) {
             constexpr int S = decltype(side)::value;
-            const void *fn = synth ? reinterpret_cast<const void *>(k_episode<S, SRC_SYNTH, false>)
-                                   : reinterpret_cast<const void *>(k_episode<S, SRC_MASKS, false>);
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess)
-                    return fail(BPG_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-            }
             if (synth)
                 hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
-                                   tab, rc, ca, okbits);
+                                   tab, rc, ca, okbits, a->d_episode_return);
             else
                 hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, a->d_masks, rw,
                                    a->d_flags_tb, a->d_ep_ag, a->d_ep_g, a->d_ep_success, b->n, a->T, ldm, ldo, RC, R, c, s,
-                                   tab, rc, ca, okbits);
+                                   tab, rc, ca, okbits, a->d_episode_return);
             return BPG_OK;
         });
         if (rcode == BPG_OK) rcode = check_launch("k_episode");
@@ -3439,14 +3508,15 @@ int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, in
     if ((T == 50 || T == 25 || T == 10) && ld < ((int64_t)1 << 28) && aligned16(d_G)) {
         // register-resident path for the horizons in use (T = max_episode_steps = 50): one env per lane
         const PowTable tab = pow_table(gamma, T);
+        const int plain_ok = gamma_is_subtractable(gamma, T) ? 1 : 0;
         const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
         hipStream_t st = (hipStream_t)stream;
         if (T == 50)
-            hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
+            hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
         else if (T == 25)
-            hipLaunchKernelGGL((k_discounted_return_lane<25, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
+            hipLaunchKernelGGL((k_discounted_return_lane<25, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
         else
-            hipLaunchKernelGGL((k_discounted_return_lane<10, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G);
+            hipLaunchKernelGGL((k_discounted_return_lane<10, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
         return check_launch("k_discounted_return_lane");
     }
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
@@ -3475,7 +3545,7 @@ int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, 
         std::memset(&none, 0, sizeof(none));
         const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
         hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, DR_LANE_WPB>), pgrid, pblock, 0, (hipStream_t)stream,
-                           none, d_reward_tb, n, ld, gamma, d_G);
+                           none, d_reward_tb, n, ld, gamma, d_G, 0);
         return check_launch("k_discounted_return_lane<scan>");
     }
     const int R = T | 1;

@@ -66,14 +66,27 @@ def make_sharded(env_id, total_envs, rank, world_size, device=None, seed=0, refe
     return make(env_id, num_envs=stop - start, device=device, seed=seed, env_id_base=start, **kw)
 
 
-def global_success_rate(local_success_count, local_num_envs):
-    """One all-reduce of (successes, envs) per rollout -> global success rate."""
-    t = torch.stack([torch.as_tensor(local_success_count).reshape(()).to(torch.float64),
-                     torch.as_tensor(float(local_num_envs), dtype=torch.float64,
-                                     device=torch.as_tensor(local_success_count).device)])
+def global_success_counts(local_success_count, local_num_envs, device=None):
+    """One all-reduce of (successes, envs) per rollout; the summed pair comes back as a 2-element float64 tensor ON THE
+    DEVICE of `local_success_count` -- no host sync: the caller divides (or .item()s) where it synchronises anyway, once
+    per epoch in the reference (train.py:67-76)."""
+    c = torch.as_tensor(local_success_count)
+    if device is not None:
+        c = c.to(device)
+    t = torch.stack([c.reshape(()).to(torch.float64),
+                     torch.as_tensor(float(local_num_envs), dtype=torch.float64, device=c.device)])
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t[0].item() / t[1].item())
+    return t
+
+
+def global_success_rate(local_success_count, local_num_envs, as_tensor=False):
+    """`success_rate = np.mean(successful)` (rollout.py:163-167) over the envs of ALL ranks: one all-reduce of
+    (successes, envs).  as_tensor=True returns the rate as a 0-dim device tensor without synchronising the host (use it
+    per rollout); the default reads it back as a Python float (one host sync: per epoch, as train.py:67-76 logs it)."""
+    t = global_success_counts(local_success_count, local_num_envs)
+    rate = t[0] / t[1]
+    return rate if as_tensor else float(rate.item())
 
 
 def mpi_average(value, device=None):
@@ -97,24 +110,49 @@ def mpi_average(value, device=None):
     return float(t[0].item() / t[1].item())
 
 
-def all_gather_per_env(local_values, shard_sizes=None):
-    """All-gather of a per-env statistic (final is_success / episode return) into
-    global env order: one collective per rollout (4 B/env; 2 MB per GPU at
-    4 194 304 envs over 8 GPUs).  Ragged shards are padded to the largest."""
+def shard_sizes_of(total_envs, world_size):
+    """Sizes of the contiguous shards of shard_range(), rank order: known to every rank without communication."""
+    return [b - a for a, b in (shard_range(total_envs, r, world_size) for r in range(world_size))]
+
+
+def all_gather_per_env(local_values, total_envs=None, shard_sizes=None, out=None, async_op=False):
+    """All-gather of a per-env statistic (the episode return bpg_rollout_args.d_episode_return writes, 4 B/env: 2 MB
+    per GPU at 4 194 304 envs over 8 GPUs; or the final is_success) into global env order -- the ONE collective of a
+    rollout (`mpi_average` of train.py:21-26 is its reduced form).
+
+    The shard sizes follow from shard_range(total_envs, r, world) on every rank, so nothing is exchanged to learn them:
+    pass `total_envs` (or the explicit `shard_sizes` list).  Equal shards (total % world == 0, BASELINE configs[3]):
+    exactly one all_gather_into_tensor straight into `out` (a (total, ...) tensor, allocated if None) -- no padding, no
+    concatenation, nothing but the collective touches the data.  Ragged shards: the shards are padded to the longest
+    (at most one extra env), still one collective, and the result is compacted on the device.
+    async_op=True (equal shards only) returns (out, work) without waiting.
+    Without a process group (or world == 1) the input is returned as is."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
-        return local_values
+        return (local_values, None) if async_op else local_values
     world = dist.get_world_size()
     n_local = local_values.shape[0]
     if shard_sizes is None:
-        sizes = torch.zeros(world, dtype=torch.int64, device=local_values.device)
-        sizes[dist.get_rank()] = n_local
-        dist.all_reduce(sizes)
-        shard_sizes = [int(s) for s in sizes.tolist()]
+        if total_envs is None:
+            raise ValueError('all_gather_per_env needs total_envs (or shard_sizes): shard sizes are derived, not exchanged')
+        shard_sizes = shard_sizes_of(total_envs, world)
+    shard_sizes = [int(x) for x in shard_sizes]
+    if len(shard_sizes) != world or shard_sizes[dist.get_rank()] != n_local:
+        raise ValueError('shard_sizes %s do not match this rank\'s %d values' % (shard_sizes, n_local))
+    tail = tuple(local_values.shape[1:])
     m = max(shard_sizes)
-    pad = torch.zeros((m,) + tuple(local_values.shape[1:]), dtype=local_values.dtype,
-                      device=local_values.device)
+    if min(shard_sizes) == m:                                   # equal shards: the collective writes the result
+        if out is None:
+            out = torch.empty((world * m,) + tail, dtype=local_values.dtype, device=local_values.device)
+        work = dist.all_gather_into_tensor(out, local_values.contiguous(), async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op:
+        raise ValueError('async_op needs equal shards')
+    pad = torch.zeros((m,) + tail, dtype=local_values.dtype, device=local_values.device)
     pad[:n_local] = local_values
-    out = torch.empty((world * m,) + tuple(local_values.shape[1:]), dtype=local_values.dtype,
-                      device=local_values.device)
-    dist.all_gather_into_tensor(out, pad)
-    return torch.cat([out[r * m:r * m + shard_sizes[r]] for r in range(world)])
+    buf = torch.empty((world * m,) + tail, dtype=local_values.dtype, device=local_values.device)
+    dist.all_gather_into_tensor(buf, pad)
+    res = torch.cat([buf[r * m:r * m + shard_sizes[r]] for r in range(world)])
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

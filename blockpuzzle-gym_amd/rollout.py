@@ -338,7 +338,7 @@ class RolloutStudent:
         return self._finish(dict(self._graph_ep), self._graph_Qs)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
-                                want_reward=False, materialize_constants=False, gamma=None):
+                                want_reward=False, materialize_constants=False, gamma=None, episode_return=False):
         """Whole rollout in ONE kernel launch (no policy between steps): contacts
         come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
         source when None.  Same episode dict as generate_rollouts; `o` is the
@@ -348,7 +348,10 @@ class RolloutStudent:
         which makes the kernel write contiguous float32 copies of them as well.
         gamma: also return `G` (B, T) float64, the policy-gradient return of the rollout
         (policy_gradient/rollout.py:255-258, bit-identical), computed by the same call from the
-        step-ok bits of the launch -- no reward stream is written or read for it."""
+        step-ok bits of the launch -- no reward stream is written or read for it.
+        episode_return: also return `episode_return` (B,) float32, every env's undiscounted return
+        r[0] + ... + r[T-1] (bpg_rollout_args.d_episode_return: the per-env array a multi-GPU job
+        all-gathers, distributed.all_gather_per_env), from a counter of the same launch."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
@@ -362,8 +365,10 @@ class RolloutStudent:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device))               # stored as given (rollout.py:147)
         reward = time_major_empty(T, B, torch.float32, self.device) if want_reward else None
         G = torch.empty((B, T), dtype=torch.float64, device=self.device) if gamma is not None else None
+        ret = torch.empty(B, dtype=torch.float32, device=self.device) if episode_return else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
                                 d_G=None if G is None else G.data_ptr(), gamma=0.0 if gamma is None else float(gamma),
+                                d_episode_return=None if ret is None else ret.data_ptr(),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
                                 d_ep_ag=ep['ag'].data_ptr(),
                                 d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
@@ -379,10 +384,12 @@ class RolloutStudent:
             out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
         if G is not None:
             out['G'] = G if self.output == 'torch' else G.cpu().numpy()
+        if ret is not None:
+            out['episode_return'] = ret if self.output == 'torch' else ret.cpu().numpy()
         return out
 
     def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
-                                flags_tb=None):
+                                flags_tb=None, episode_return=None):
         """The evaluator's test loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)`
         (train.py:63-64, play.py:59) -- with the contacts of all K rollouts read from one stream, in ONE
         launch: rollout r is reset + T steps on rows r*T .. r*T+T-1 of `masks` ((K*T, B) int32 device
@@ -390,7 +397,8 @@ class RolloutStudent:
         generate_rollouts_fused would (rollout.py:163-170); no episode dict is kept, as the test loop
         drops it.  num_grey: (K, B) explicit draws for BlocksTouchVariation, or None for the env's
         generator (its next K draws).  reward_tb / flags_tb: optional (K*T, B) float32 / uint8 streams
-        the launch fills (step reward; bit 0 is_success, bit 1 done).  Returns the K success rates."""
+        the launch fills (step reward; bit 0 is_success, bit 1 done); episode_return: optional (K, B) float32
+        the launch fills with every env's undiscounted return of each rollout.  Returns the K success rates."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         assert masks.dim() == 2 and masks.shape[1] == B and masks.shape[0] % T == 0 and masks.element_size() == 4 \
             and masks.stride(1) == 1 and masks.is_cuda
@@ -415,7 +423,11 @@ class RolloutStudent:
         # (set_test only re-places the cubes, rollout.py:53-55: with the contacts read from the stream the
         # placement has no reader, so nothing is placed here)
         counts = torch.zeros(K, dtype=torch.int64, device=self.device)
+        if episode_return is not None:
+            assert episode_return.shape == (K, B) and episode_return.dtype == torch.float32 \
+                and episode_return.is_contiguous() and episode_return.is_cuda
         args = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld_out,
+                                d_episode_return=None if episode_return is None else episode_return.data_ptr(),
                                 d_num_grey=None if ng is None else ng.data_ptr(),
                                 d_reward_tb=None if reward_tb is None else reward_tb.data_ptr(),
                                 d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
@@ -526,12 +538,12 @@ class PGRolloutStudent(RolloutStudent):
         return o_, g_, ag_
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None, want_reward=False,
-                                materialize_constants=False, gamma=None):
+                                materialize_constants=False, gamma=None, episode_return=False):
         """The whole pg rollout in one call without a policy between the steps: the episode arrays and
         the return `G` for this worker's gamma (policy_gradient/rollout.py:255-258, :283-288)."""
         return super().generate_rollouts_fused(test=test, masks=masks, num_grey=num_grey, actions=actions,
                                                want_reward=want_reward, materialize_constants=materialize_constants,
-                                               gamma=self.gamma if gamma is None else gamma)
+                                               gamma=self.gamma if gamma is None else gamma, episode_return=episode_return)
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference

@@ -91,8 +91,7 @@ int main()
     CHECK(bpg_synth_masks(h, 0, T, d_m0, nullptr));
     CHECK(bpg_synth_masks_ld(h, 0, T, d_m1, ld, nullptr));
     unsigned long long *d_c2; HIP(hipMalloc(&d_c2, 16)); HIP(hipMemset(d_c2, 0, 16));
-    bpg_rollout_args ra;
-    std::memset(&ra, 0, sizeof(ra));
+    bpg_rollout_args ra = BPG_ROLLOUT_ARGS_INIT;      // struct_size = sizeof(bpg_rollout_args), every other field zero
     ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_reward_tb = d_r0; ra.d_flags_tb = d_f0; ra.d_success_count = d_c2;
     CHECK(bpg_rollout(h, &ra, nullptr));
     ra.d_masks = d_m1; ra.d_reward_tb = d_r1; ra.d_flags_tb = d_f1; ra.d_success_count = d_c2 + 1;
@@ -121,7 +120,7 @@ int main()
     // first launch (float64, gamma ** k as C pow, products and sums rounded separately).
     double *d_G; HIP(hipMalloc(&d_G, (size_t)B * T * 8));
     const double gamma = 1.0 - 1.0 / T;
-    std::memset(&ra, 0, sizeof(ra));
+    ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
     ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_G = d_G; ra.gamma = gamma;
     CHECK(bpg_rollout(h, &ra, nullptr));
     HIP(hipDeviceSynchronize());
@@ -154,11 +153,11 @@ int main()
     HIP(hipMalloc(&d_mk, (size_t)K * T * B * 4)); HIP(hipMalloc(&d_fk, (size_t)K * T * B));
     HIP(hipMalloc(&d_ck, 2 * K * 8)); HIP(hipMemset(d_ck, 0, 2 * K * 8));
     CHECK(bpg_synth_masks(h2, 0, K * T, d_mk, nullptr));
-    std::memset(&ra, 0, sizeof(ra));
+    ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
     ra.T = T; ra.reset_first = 1; ra.rollouts = K; ra.d_masks = d_mk; ra.d_flags_tb = d_fk; ra.d_success_count = d_ck;
     CHECK(bpg_rollout(h2, &ra, nullptr));
     for (int k = 0; k < K; k++) {
-        std::memset(&ra, 0, sizeof(ra));
+        ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
         ra.T = T; ra.reset_first = 1; ra.d_masks = d_mk + (size_t)k * T * B; ra.d_success_count = d_ck + K + k;
         CHECK(bpg_rollout(h3, &ra, nullptr));
     }

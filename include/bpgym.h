@@ -308,10 +308,22 @@ int bpg_trim_expert_inputs(const float *d_o, const float *d_g, const float *d_ag
 /* RolloutStudent.generate_rollouts inner loop (rollout.py:100-153) for T steps
  * in ONE launch: state stays in registers, every array below is optional
  * (NULL = not produced).  With reset_first the launch also performs the
- * reset_all_rollouts of rollout.py:79; otherwise call bpg_reset first. */
+ * reset_all_rollouts of rollout.py:79; otherwise call bpg_reset first.
+ * Versioning: the caller sets struct_size = sizeof(bpg_rollout_args) of the header it was built against
+ * (BPG_ROLLOUT_ARGS_INIT does).  Fields are only ever appended; a library that knows more fields than the caller
+ * passed treats the missing ones as zero, a library that knows fewer accepts the call only if the bytes it does not
+ * know are all zero (BPG_ERR_UNSUPPORTED otherwise).  struct_size < BPG_ROLLOUT_ARGS_MIN_SIZE is BPG_ERR_ARG. */
 typedef struct {
+    uint32_t struct_size;      /* sizeof(bpg_rollout_args) as the caller compiled it */
     int32_t T;
     int32_t reset_first;       /* 1: reset every env (bpg_reset semantics) inside the launch, before step 0 */
+    int32_t rollouts;          /* 0 / 1: one rollout.  K > 1 (stream path, reset_first = 1, no d_ep_*, no d_G): K consecutive
+                                  rollouts in this ONE launch -- generate_rollouts called K times in a row with nothing
+                                  between the calls (rollout.py:75-172) -- rollout r = reset + T steps on rows r*T .. r*T+T-1
+                                  of d_masks / d_reward_tb / d_flags_tb (K*T rows each), its success count added to
+                                  d_success_count[r] (K words), row r of d_episode_return, explicit d_num_grey (K, n_envs) or
+                                  the generator's next K draws.  Same results as K calls; the fixed cost of a launch is paid
+                                  once. */
     const int32_t *d_num_grey; /* reset_first on Variation: explicit num_grey draws, NULL = generator */
     const uint32_t *d_masks;   /* (T, n_envs) time-major contact masks; NULL = synthetic source */
     float *d_reward_tb;        /* (T, n_envs) float32 step rewards                */
@@ -325,20 +337,26 @@ typedef struct {
     int64_t ld_out;            /* row stride of d_reward_tb and d_flags_tb in elements; 0 = n_envs */
     double *d_G;               /* (n_envs, T) float64 batch-major: the policy-gradient return of the rollout
                                   (policy_gradient/rollout.py:217-231, :255-258), bit-identical to the reference's
-                                  float64 accumulation, WITHOUT a reward stream: for T <= 64 the rollout launch keeps
-                                  each env's step rewards as one 64-bit step-ok word (8 bytes per env, handle-owned)
-                                  and a second launch enqueued by the same call expands the words into the rows;
-                                  64 < T <= 319: computed from d_reward_tb, which is then required.  8-byte aligned
+                                  float64 accumulation, WITHOUT a reward stream: for T <= 64 and 0 <= gamma with finite
+                                  powers the rollout launch keeps each env's step rewards as one 64-bit step-ok word
+                                  (8 bytes per env, handle-owned, allocated by the first call that asks for d_G -- make
+                                  that call outside a stream capture) and a second launch enqueued by the same call
+                                  expands the words into the rows; 64 < T <= 319, or a gamma that is negative or whose
+                                  powers overflow: computed from d_reward_tb, which is then required.  8-byte aligned
                                   (16 for the fast T = 50 / 10 forms).  NULL = not produced */
     double gamma;              /* discount of d_G (config.py:83: 1 - 1/T) */
-    int32_t rollouts;          /* 0 / 1: one rollout.  K > 1 (stream path, reset_first = 1, no d_ep_*, no d_G): K consecutive
-                                  rollouts in this ONE launch -- generate_rollouts called K times in a row with nothing
-                                  between the calls (rollout.py:75-172) -- rollout r = reset + T steps on rows r*T .. r*T+T-1
-                                  of d_masks / d_reward_tb / d_flags_tb (K*T rows each), its success count added to
-                                  d_success_count[r] (K words), explicit d_num_grey (K, n_envs) or the generator's next K
-                                  draws.  Same results as K calls; the fixed cost of a launch is paid once. */
-    int32_t reserved_;
+    float *d_episode_return;   /* (n_envs) float32, or (rollouts, n_envs) with rollouts = K: every env's UNDISCOUNTED episode
+                                  return r[0] + r[1] + ... + r[T-1] of the float32 step rewards, accumulated in step order
+                                  starting from r[0] -- the reference's own accumulation of returns[0]
+                                  (policy_gradient/rollout.py:255-258) at gamma = 1 -- = -(number of steps whose success
+                                  condition did not hold), and -0.0f when it held at every step (a sum that starts from r[0]
+                                  keeps the sign of zero; numerically equal to np.sum(rewards, axis=0)).  BASELINE.json's
+                                  "aggregated rollout return": 4 bytes per env from a per-env counter in registers, no reward
+                                  stream written or read for it; the one per-env array a multi-GPU job exchanges
+                                  (all-gather).  4-byte aligned.  NULL = not produced */
 } bpg_rollout_args;
+#define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma */
+#define BPG_ROLLOUT_ARGS_INIT { (uint32_t)sizeof(bpg_rollout_args) }
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 
 /* rollout.py:163-167 `successful = successes[-1]`: number of envs whose

@@ -280,6 +280,19 @@ def discounted_return(r, gamma):
     return G
 
 
+def episode_return(reward_tb):
+    """The undiscounted return of every env's episode from the (T, B) float32 step rewards: the reference's own
+    accumulation of `returns[0]` (policy_gradient/rollout.py:255-258: `returns.append(r_new.copy())`, then
+    `returns[0] += gamma ** t * r_new` for t = 1 .. T-1) at gamma = 1, i.e. r[0] + r[1] + ... in step order, in
+    float32.  With rewards in {-1.0, -0.0} that is -(number of failed steps), and -0.0 when no step failed (a sum
+    that STARTS from r[0] keeps the sign; np.sum, which starts from +0.0 for short rows, gives +0.0 there)."""
+    r = np.asarray(reward_tb, np.float32)
+    acc = r[0].copy()
+    for t in range(1, r.shape[0]):
+        acc = (acc + r[t]).astype(np.float32)
+    return acc
+
+
 def generate_rollouts(env_id, B, T, masks, num_grey=None, envs=None, want_reward=True):
     """Batch rollout (rollout.py:75-172).  Returns dict + the env array so a
     caller can chain rollouts (quirk Q1 persistence)."""
@@ -300,4 +313,7 @@ def generate_rollouts(env_id, B, T, masks, num_grey=None, envs=None, want_reward
                                    None if ng is None else _p(ng, C.c_int),
                                    _p(ag, C.c_float), _p(g, C.c_float), _p(succ, C.c_float),
                                    _p(rew, C.c_float) if want_reward else None)
-    return dict(ag=ag, g=g, info_is_success=succ, reward=rew, success_rate=rate), envs
+    out = dict(ag=ag, g=g, info_is_success=succ, reward=rew, success_rate=rate)
+    if want_reward:
+        out['episode_return'] = episode_return(rew)
+    return out, envs

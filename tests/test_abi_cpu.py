@@ -133,7 +133,10 @@ def test_row_stride_helper_is_a_pure_host_function():
         assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
-    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 8 + 9 * 8 + 16 + 16 + 8
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 16 + 9 * 8 + 16 + 16 + 8
+    # BPG_ROLLOUT_ARGS_INIT: the mirror fills in its own size; the minimum the library accepts ends behind gamma
+    assert a.struct_size == C.sizeof(_lib.RolloutArgs) == 128
+    assert _lib.RolloutArgs.gamma.offset + 8 == _lib.ROLLOUT_ARGS_MIN_SIZE == 120
 
 
 def test_every_kernel_stub_has_a_device_kernel_of_the_same_name():
@@ -167,9 +170,16 @@ def test_no_kernel_uses_scratch_memory():
     bad = [(r['name'], r['scratch']) for r in rows if r['scratch']]
     assert not bad, bad[:5]
     # the fused rollout is never launched with more lanes than its launch bound, and holds its registers
+    # (template arguments: ..., LB = the block size the instantiation is launched with, OKB, MULTI, RET): 1024 lanes are
+    # 4 waves per SIMD = 128 registers each; the 256-lane shapes must keep at least two waves per SIMD
+    seen = 0
     for r in rows:
-        if 'k_rollout<' in r['name']:
-            assert r['vgpr'] <= 128, r
+        m = re.search(r'k_rollout<(.*)>', r['name'])
+        if m:
+            lb = int(m.group(1).split(',')[8])
+            assert lb in (256, 1024) and r['vgpr'] <= (128 if lb == 1024 else 256), r
+            seen += 1
+    assert seen >= 100
 
 
 def test_register_with_gym_against_a_recording_stand_in(monkeypatch):
@@ -232,4 +242,4 @@ def test_every_entry_point_is_exercised_somewhere():
     idle = [n for n in declared
             if not re.search(r'\b%s\b' % n, tests) and len(re.findall(r'\b%s\b' % n, pkg)) < 2]      # 1 = the signature table only
     assert idle == ['bpg_version'], idle            # bpg_version: below
-    assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 103
+    assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 104

@@ -1,0 +1,331 @@
+"""Round-4 GPU tests (through the C-ABI, bit-exact):
+
+* the 2-envs-per-lane launch shapes of the fused rollout -- 256-lane and 1024-lane blocks, grid-stride trips, the
+  bench headline's own instantiation -- compared DIRECTLY with the oracle (O.OracleEnv, the matrix-form restatement of
+  fetch_env.py:135-167, :275-281) on env windows that cover lane-group, block and grid-stride boundaries;
+* bpg_rollout_args.d_episode_return (the per-env undiscounted return, BASELINE's "aggregated rollout return") in every
+  form that produces it: in-loop counter, population of the step-ok word, several rollouts per launch, episode writer;
+* struct versioning of bpg_rollout_args, a negative gamma, the lazily allocated step-ok words.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import blockpuzzle_gym_amd as bpg
+from oracle import bpg_oracle as O
+from util import VARIANTS, legal_masks, valid_by_n, pack_oracle_env
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ENV_ID = 'BlocksTouchVariation-v0'
+L = bpg._lib.lib()
+P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+
+
+def bits32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def same_bits64(a, b):
+    np.testing.assert_array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+def oracle_G(reward_tb, gamma):
+    r = np.asarray(reward_tb)
+    return np.stack([O.discounted_return(r[:, b].astype(np.float64), gamma) for b in range(r.shape[1])])
+
+
+def windows(B):
+    """Env windows of a 2-envs-per-lane launch: the first lanes, the edge between two blocks (512 / 2048 envs), the edge
+    between two grid-stride trips (256 x 1024 x 2 = 1024 x 256 x 2 = 524 288 envs), an odd offset in the middle, the
+    last lanes."""
+    w = [(0, 128), (2048 - 64, 128), ((B // 2) | 1, 129), (B - 130, 130)]
+    if B > 524288 + 64:
+        w.append((524288 - 64, 128))
+    idx = np.unique(np.concatenate([np.arange(lo, lo + n) for lo, n in w]))
+    return idx[(idx >= 0) & (idx < B)]
+
+
+def fill_device_masks(out, ng, gen, raw_every=7):
+    """out (T, B) int32 <- contact masks generated on the device: two random words ANDed (about a quarter of the pairs),
+    restricted to the pairs of objects present in the env's episode (ng (B,): num_grey) -- except for the envs with
+    index % raw_every == 5, which keep raw masks (pairs of absent objects: the reference keeps those set,
+    fetch_env.py:154-157 demotes only i, j < num_objs)."""
+    T, B = out.shape
+    m = torch.randint(0, 1 << 21, (T, B), device=DEV, generator=gen, dtype=torch.int32)
+    m &= torch.randint(0, 1 << 21, (T, B), device=DEV, generator=gen, dtype=torch.int32)
+    vb = torch.as_tensor(valid_by_n().astype(np.int32), device=DEV)
+    valid = vb[(4 + ng).long()]
+    raw = (torch.arange(B, device=DEV) % raw_every) == 5
+    out.copy_(torch.where(raw[None, :], m, m & valid[None, :]))
+
+
+@pytest.mark.parametrize('B,pow2_rows', [(262144, False), (524288 + 2, False), (1048576, False), (4194304, True),
+                                         (4194304, False)])
+def test_two_envs_per_lane_shapes_directly_against_the_oracle(B, pow2_rows):
+    """One batch, four launches in a row, every one compared with the oracle on the windows above -- reward bits, flag
+    bytes, the undiscounted episode return, G where asked for, and after each launch the packed state:
+      A  reset_first = 1, reward + flags + success count + episode return      (in-loop counter, RET)
+      B  reset_first = 0 (steps 51..100 of the same episode, per-lane elapsed counters, done set), reward + flags +
+         d_G + episode return                                                    (step-ok words, OKB)
+      C  rollouts = 3 in one launch, reward + flags + 3 counts + (3, B) returns  (MULTI + RET)
+      D  reset_first = 1, reward + flags + count: the bench headline's instantiation, nothing else asked for.
+    Rows are bpg_row_stride(B) apart (B + 256 at 1 M and 4 M envs) or, with pow2_rows, exactly B apart (at 4 M envs that
+    is the aliased case, for which rollout_geometry picks 256-lane blocks)."""
+    T, K, gamma = 50, 3, 0.98
+    gen = torch.Generator(device=DEV).manual_seed(B % 9973 + (1 if pow2_rows else 0))
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=3)
+    ld = B if pow2_rows else int(L.bpg_row_stride(B))
+    assert ld % 2 == 0
+    rows = (1 + 1 + K + 1) * T
+
+    def tm(dtype):
+        return torch.empty((rows, ld), dtype=dtype, device=DEV)[:, :B]
+    ng = torch.randint(0, 3, (2 + K, B), device=DEV, generator=gen, dtype=torch.int32)      # A/B, C x 3, D
+    masks = tm(torch.int32)
+    for seg, k in enumerate([0, 0] + list(range(1, 2 + K))):          # launches A, B share an episode
+        fill_device_masks(masks[seg * T:(seg + 1) * T], ng[k], gen)
+    reward, flags = tm(torch.float32), tm(torch.uint8)
+    cnt = torch.zeros(8, dtype=torch.int64, device=DEV)
+    ret = torch.full((2 + K, B), 7.0, dtype=torch.float32, device=DEV)
+    G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+
+    def launch(row0, **kw):
+        a = bpg._lib.RolloutArgs(T=T, d_masks=masks[row0].data_ptr(), d_reward_tb=reward[row0].data_ptr(),
+                                 d_flags_tb=flags[row0].data_ptr(), ld_masks=ld, ld_out=ld, **kw)
+        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        return env.state_now.clone(), env.state_ever.clone()
+
+    states = {}
+    states['A'] = launch(0, reset_first=1, d_num_grey=ng[0].data_ptr(), d_success_count=cnt[0:].data_ptr(),
+                         d_episode_return=ret[0].data_ptr())
+    states['B'] = launch(T, reset_first=0, d_G=G.data_ptr(), gamma=gamma, d_episode_return=ret[1].data_ptr())
+    states['C'] = launch(2 * T, reset_first=1, rollouts=K, d_num_grey=ng[1].data_ptr(), d_success_count=cnt[1:].data_ptr(),
+                         d_episode_return=ret[2].data_ptr())
+    states['D'] = launch((2 + K) * T, reset_first=1, d_num_grey=ng[1 + K].data_ptr(), d_success_count=cnt[4:].data_ptr())
+    torch.cuda.synchronize()
+
+    # whole-batch identities on the device: counts against the flags of each rollout's last step, returns against rewards
+    for c, row in zip(cnt[:5].tolist(), [T - 1, 3 * T - 1, 4 * T - 1, 5 * T - 1, 6 * T - 1]):   # A, C x 3, D
+        assert c == int((flags[row] & 1).sum()) and 0 < c <= B
+    for k, row0 in ((0, 0), (1, T), (2, 2 * T), (3, 3 * T), (4, 4 * T)):
+        fails = (reward[row0:row0 + T] != 0).sum(0)                                  # -1.0 != 0, -0.0 == 0
+        assert torch.equal(ret[k], -(fails.float()))
+        assert bool(torch.signbit(ret[k]).all())                                     # -0.0f where nothing failed
+
+    # the oracle on the windows
+    idx = windows(B)
+    di = torch.as_tensor(idx, device=DEV)
+    m_w = masks[:, di].cpu().numpy().view(np.uint32)
+    r_w, f_w = bits32(reward[:, di].contiguous()), flags[:, di].cpu().numpy()
+    ret_w, ng_w, G_w = ret[:, di].cpu().numpy(), ng[:, di].cpu().numpy(), G[di].cpu().numpy()
+    st_w = {k: (v[0][di].cpu().numpy().view(np.uint32), v[1][di].cpu().numpy().view(np.uint32)) for k, v in states.items()}
+    exp_r = np.zeros_like(r_w)
+    exp_f = np.zeros_like(f_w)
+    for j in range(len(idx)):
+        e = O.OracleEnv(ENV_ID)
+        row = 0
+
+        def steps(n):
+            nonlocal row
+            for _ in range(n):
+                _, r, done, succ = e.step_mask(int(m_w[row, j]))
+                exp_r[row, j] = np.float32(r).view(np.uint32)
+                exp_f[row, j] = int(succ) | (int(done) << 1) | (int(r == 0) << 2)
+                row += 1
+        e.reset(num_grey=int(ng_w[0, j]))
+        steps(T)
+        assert (st_w['A'][0][j], st_w['A'][1][j]) == pack_oracle_env(e), ('A', idx[j])
+        steps(T)                                                                     # B: no reset
+        assert (st_w['B'][0][j], st_w['B'][1][j]) == pack_oracle_env(e), ('B', idx[j])
+        for k in range(K):
+            e.reset(num_grey=int(ng_w[1 + k, j]))
+            steps(T)
+        assert (st_w['C'][0][j], st_w['C'][1][j]) == pack_oracle_env(e), ('C', idx[j])
+        e.reset(num_grey=int(ng_w[1 + K, j]))
+        steps(T)
+        assert (st_w['D'][0][j], st_w['D'][1][j]) == pack_oracle_env(e), ('D', idx[j])
+    np.testing.assert_array_equal(r_w, exp_r)
+    np.testing.assert_array_equal(f_w, exp_f)
+    assert (exp_f[T:2 * T] & 2).all() and not (exp_f[:T - 1] & 2).any()            # launch B runs behind the TimeLimit
+    rew_f = exp_r.view(np.float32)
+    for k in range(2 + K):
+        want = O.episode_return(rew_f[k * T:(k + 1) * T])
+        np.testing.assert_array_equal(ret_w[k].view(np.uint32), want.view(np.uint32))
+    same_bits64(G_w, oracle_G(rew_f[T:2 * T], gamma))
+
+
+@pytest.mark.parametrize('env_id', ['GripperTouch-v0', 'BlocksTouchChoose-v0', 'BlocksTouchVariation-v0', 'ToppleTower-v0'])
+@pytest.mark.parametrize('B', [1, 1003, 4096, 131072 + 2])
+def test_episode_return_of_every_launch_form_vs_oracle(env_id, B):
+    """d_episode_return == r[0] + r[1] + ... of the oracle's step rewards (bit-exact, -0.0f when every step succeeded):
+    stream path with and without the reward stream, with d_G (taken from the step-ok word), with the synthetic source,
+    from the episode writer, and for T = 70 (> 64: no step-ok word exists)."""
+    rng = np.random.RandomState(B + len(env_id))
+    v = VARIANTS[env_id]
+    for T in (50, 70):
+        ng = rng.randint(3, size=B).astype(np.int32)
+        nobj = 4 + ng if 'Variation' in env_id else np.full(B, v['num_objs'])
+        masks = legal_masks(rng, T, B, nobj, density=2)
+        # make a few envs succeed at every step and a few never, whatever the goal of the variant
+        info = bpg._lib.variant_info(L.bpg_variant_from_id(env_id.encode()))
+        masks[:, ::5] |= np.uint32(info.want_touch)
+        masks[:, ::5] &= ~np.uint32(info.want_never)
+        nB = min(B, 600)                                                  # oracle envs (the rest: device-side identity)
+        ref, _ = O.generate_rollouts(env_id, nB, T, masks[:, :nB], num_grey=ng[:nB])
+        want = ref['episode_return']
+        assert want.dtype == np.float32 and (np.signbit(want)).all()
+        if B >= 5:
+            assert (want == 0).any() and (want < 0).any()
+        dm = torch.as_tensor(masks.view(np.int32), device=DEV)
+        dng = torch.as_tensor(ng, device=DEV)
+
+        def run(**kw):
+            env = bpg.make(env_id, num_envs=B, device=DEV, seed=1)
+            ret = torch.full((B,), 3.0, dtype=torch.float32, device=DEV)
+            a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=dng.data_ptr(), d_masks=dm.data_ptr(),
+                                     d_episode_return=ret.data_ptr(), **kw)
+            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            return ret
+        rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+        fl = torch.empty((T, B), dtype=torch.uint8, device=DEV)
+        G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+        ag = torch.empty((B, T + 1, v['dimg']), dtype=torch.float32, device=DEV)
+        forms = [dict(), dict(d_reward_tb=rew.data_ptr()), dict(d_flags_tb=fl.data_ptr()),
+                 dict(d_reward_tb=rew.data_ptr(), d_flags_tb=fl.data_ptr()), dict(d_ep_ag=ag.data_ptr())]
+        if T <= 64:
+            forms += [dict(d_G=G.data_ptr(), gamma=0.98), dict(d_G=G.data_ptr(), gamma=0.98, d_ep_ag=ag.data_ptr())]
+        else:
+            forms += [dict(d_G=G.data_ptr(), gamma=0.99, d_reward_tb=rew.data_ptr())]
+        for kw in forms:
+            got = run(**kw)
+            np.testing.assert_array_equal(got[:nB].cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=str(sorted(kw)))
+            if 'd_reward_tb' in kw:
+                assert torch.equal(got, -((rew != 0).sum(0).float()))
+    # synthetic source: the return equals the sum of the reward stream the same launch wrote
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=5)
+    T = 50
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    ret = torch.empty(B, dtype=torch.float32, device=DEV)
+    for reset_first in (1, 0):
+        a = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_reward_tb=rew.data_ptr(), d_episode_return=ret.data_ptr())
+        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        assert torch.equal(ret, -((rew != 0).sum(0).float())) and bool(torch.signbit(ret).all())
+
+
+def test_worker_returns_the_episode_return():
+    """RolloutStudent.generate_rollouts_fused(episode_return=True) / evaluate_rollouts_fused(episode_return=(K, B)): the
+    worker-level view of the same array."""
+    B, T, K = 3000, 50, 4
+    rng = np.random.RandomState(2)
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=DEV), None,
+                           dict(o=87, u=4, g=36, info_is_success=1), None, T, rollout_batch_size=B)
+    ng = rng.randint(3, size=(K, B)).astype(np.int32)
+    masks = np.concatenate([legal_masks(rng, T, B, 4 + ng[k], density=2) for k in range(K)])
+    ep = w.generate_rollouts_fused(masks=torch.as_tensor(masks[:T].view(np.int32), device=DEV), num_grey=ng[0],
+                                   want_reward=True, episode_return=True)
+    ref, _ = O.generate_rollouts(ENV_ID, B, T, masks[:T], num_grey=ng[0])
+    np.testing.assert_array_equal(ep['episode_return'].view(np.uint32), ref['episode_return'].view(np.uint32))
+    np.testing.assert_array_equal(ep['reward_tb'].view(np.uint32), ref['reward'].view(np.uint32))
+    ret = torch.empty((K, B), dtype=torch.float32, device=DEV)
+    rates = w.evaluate_rollouts_fused(torch.as_tensor(masks.view(np.int32), device=DEV), num_grey=ng, episode_return=ret)
+    for k in range(K):
+        ref, _ = O.generate_rollouts(ENV_ID, B, T, masks[k * T:(k + 1) * T], num_grey=ng[k])
+        np.testing.assert_array_equal(ret[k].cpu().numpy().view(np.uint32), ref['episode_return'].view(np.uint32))
+        assert rates[k] == pytest.approx(ref['success_rate'], abs=1e-6)
+
+
+def test_rollout_args_struct_versioning():
+    """struct_size (include/bpgym.h): unset -> BPG_ERR_ARG; a caller built before d_episode_return existed (120 bytes)
+    works and the field is taken as NULL even if the bytes behind its struct are garbage; a caller with MORE bytes than
+    this library knows is accepted only if they are zero."""
+    B, T = 512, 10
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+    fl = torch.zeros((T, B), dtype=torch.uint8, device=DEV)
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr())
+    assert a.struct_size == C.sizeof(bpg._lib.RolloutArgs)
+    a.struct_size = 0
+    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'struct_size' in L.bpg_last_error()
+    a.struct_size = bpg._lib.ROLLOUT_ARGS_MIN_SIZE
+    a.d_episode_return = 0xdead0000                      # behind the caller's struct: must not be read
+    assert L.bpg_rollout(env._h, C.byref(a), None) == 0
+    torch.cuda.synchronize()
+    assert int((fl[T - 1] & 2).sum()) == 0 and int(fl.sum()) >= 0
+
+    class Bigger(C.Structure):
+        _fields_ = [('base', bpg._lib.RolloutArgs), ('future_field', C.c_void_p)]
+    big = Bigger()
+    big.base = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr())
+    big.base.struct_size = C.sizeof(Bigger)
+    fn = L.bpg_rollout
+    rc = fn(env._h, C.cast(C.pointer(big), C.POINTER(bpg._lib.RolloutArgs)), None)
+    assert rc == 0
+    big.future_field = 1
+    rc = fn(env._h, C.cast(C.pointer(big), C.POINTER(bpg._lib.RolloutArgs)), None)
+    assert rc == bpg._lib.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('gamma', [-0.5, -0.0, 1e200, 0.0, 1.0, 1.5])
+def test_return_for_gammas_outside_the_subtractable_set(gamma):
+    """With gamma < 0 (or -0.0) the reference's `+= gamma**k * r` turns -0.0 accumulators into +0.0, with overflowing
+    powers inf * -0.0 is NaN: the conditional-subtract shortcut does not apply, and both entry points must take the
+    general product + sum.  bpg_rollout then needs the reward stream for d_G."""
+    T, B = 50, 64 * 3 + 5
+    rng = np.random.RandomState(4)
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=2)
+    ng = rng.randint(3, size=B).astype(np.int32)
+    masks = legal_masks(rng, T, B, 4 + ng, density=2)
+    masks[:, ::4] |= np.uint32(env.info.want_touch)
+    dm, dng = torch.as_tensor(masks.view(np.int32), device=DEV), torch.as_tensor(ng, device=DEV)
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+    with np.errstate(over='ignore'):
+        subtractable = gamma >= 0 and not np.signbit(gamma) and np.isfinite(np.float64(gamma) ** (T - 1))
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=dng.data_ptr(), d_masks=dm.data_ptr(), d_G=G.data_ptr(), gamma=gamma)
+    rc = L.bpg_rollout(env._h, C.byref(a), None)
+    assert (rc == 0) == bool(subtractable), (gamma, rc)
+    a.d_reward_tb = rew.data_ptr()
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    with np.errstate(all='ignore'):
+        want = oracle_G(rew.cpu().numpy(), gamma)
+    for got in (G.cpu().numpy(), bpg.discounted_return(rew, gamma).cpu().numpy()):
+        # an invalid operation yields the hardware's default NaN (sign bit set on x86, clear on gfx950): NaNs are
+        # compared by position, everything else bit for bit
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        same_bits64(np.where(np.isnan(want), 0.0, got), np.where(np.isnan(want), 0.0, want))
+    if gamma == -0.5:
+        assert (want == 0).any() and not np.signbit(want[want == 0]).all()       # the +0.0 the shortcut would have missed
+    if gamma == 1e200:
+        assert np.isnan(want).any()
+
+
+def test_step_ok_words_are_allocated_on_first_use_only():
+    """A handle that never asks for d_G holds 8 bytes per env (now + ever); the step-ok words (8 more) appear with the
+    first d_G call."""
+    B = 1 << 22
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    h = C.c_void_p()
+    bpg._lib.check(L.bpg_create(C.byref(h), L.bpg_variant_from_id(ENV_ID.encode()), B, 0, 50, 1, 0))
+
+    class Raw:
+        _h = h
+    env = Raw()
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert 8 * B <= held < 8 * B + (24 << 20), held
+    a = bpg._lib.RolloutArgs(T=10, reset_first=1)
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    assert free0 - torch.cuda.mem_get_info()[0] == held
+    G = torch.empty((B, 10), dtype=torch.float64, device=DEV)
+    free1 = torch.cuda.mem_get_info()[0]
+    a = bpg._lib.RolloutArgs(T=10, reset_first=1, d_G=G.data_ptr(), gamma=0.9)
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    torch.cuda.synchronize()
+    assert 8 * B <= free1 - torch.cuda.mem_get_info()[0] < 8 * B + (8 << 20)
+    del G
+    bpg._lib.check(L.bpg_destroy(h))

@@ -40,3 +40,26 @@ def fixture_masks(env_id, contacts, ncon, model_idx):
         for t in range(T):
             out[t, b] = O.contacts_to_mask(id2obj, contacts[b, t, :ncon[b, t]])
     return out
+
+
+def pack_oracle_env(e):
+    """The packed (now, ever) words of include/bpgym.h for the state of an O.OracleEnv: pairs whose matrix entry is 1 /
+    is not -1, the elapsed-step counter (saturating at 1023), num_objs of the episode, the has_succeeded latch."""
+    L = O.lib()
+    env = e.e
+    side = env.side
+    now = ever = 0
+    for i in range(side):
+        for j in range(i, side):
+            v = env.achieved_goal[i * side + j]
+            assert v == env.achieved_goal[j * side + i]
+            bit = 1 << L.orc_pair_index(i, j)
+            if v == 1.0:
+                now |= bit
+            if v != -1.0:
+                ever |= bit
+    now |= min(int(env.elapsed_steps), 1023) << 21
+    ever |= (int(env.num_objs) & 7) << 21
+    if env.has_succeeded:
+        ever |= 1 << 31
+    return now, ever
