@@ -9,8 +9,11 @@ and the success-count reduction; with N>1 GPUs the (successes, envs) rows are
 all-reduced over RCCL in slabs of `--reduce-every` rollouts (default 50 = one epoch of the
 reference's training loop, which averages across ranks once per epoch), asynchronously.
 Weak scaling by default: every GPU holds `--envs` envs (BASELINE configs[2] per GPU).
-`--total-envs E` fixes the JOB size instead and shards it over the ranks (strong scaling):
-`--gpus 8 --total-envs 4194304` is BASELINE configs[3] as written (524 288 envs per GPU).
+`--total-envs E` fixes the JOB size instead and shards it over the ranks (strong scaling).
+With N>1 the run has a SECOND timed leg, reported under `extra.config3_as_written`: BASELINE configs[3] as written --
+4 194 304 envs in total sharded over the N ranks (524 288 per GPU at N = 8), the rollout launch writes every env's
+episode return (4 B/env, bpg_rollout_args.d_episode_return) and the ranks all-gather those returns over RCCL once per
+rollout (`--gpus 8 --total-envs 4194304 --collective allgather --reduce-every 1` makes that leg the headline instead).
 
     python bench.py [--gpus N --steps K --warmup W] [--total-envs E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -39,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ENV_ID = 'BlocksTouchVariation-v0'
+CONFIG3_TOTAL = 4194304        # BASELINE.json configs[3]: 4 194 304 envs over the GPUs of one node
 
 
 def parse():
@@ -54,8 +58,12 @@ def parse():
     p.add_argument('--buffers', type=int, default=4, help='independent mask/output buffer sets used round-robin')
     p.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     p.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
-                   help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of the '
-                        'per-env final flag bytes [1 B/env]')
+                   help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of every '
+                        'env\'s episode return [4 B/env, written by the rollout launch]')
+    p.add_argument('--config3-total', type=int, default=CONFIG3_TOTAL,
+                   help='N>1: total envs of the second timed leg (BASELINE configs[3] as written: sharded over the ranks, '
+                        'all-gather of the episode returns once per rollout), reported under extra.config3_as_written')
+    p.add_argument('--no-config3', action='store_true', help='N>1: skip that second leg')
     p.add_argument('--reduce-every', type=int, default=50,
                    help='N>1: rollouts per collective (the statistics rows of R rollouts travel in one all-reduce; the '
                         'reference averages across ranks once per epoch of n_cycles = 50 rollouts, train.py:21-26,67-76, '
@@ -122,6 +130,14 @@ def cpu_baseline(T, seconds):
                                        'mask generation %.1f s)' % (cores, per, T, max(times), wall))
     except Exception as e:  # noqa: BLE001
         out['all_cores'] = {'error': repr(e)[:200]}
+    # the reference's OWN Python on one core, measured in the build container by tests/golden/time_reference.py (the
+    # reference cannot travel to this box): quoted verbatim
+    rf = os.path.join(ROOT, 'profiles', 'reference_cpu_timing.json')
+    if os.path.exists(rf):
+        try:
+            out['reference_python'] = json.load(open(rf))
+        except ValueError as e:
+            out['reference_python'] = {'error': repr(e)[:200]}
     return out
 
 
@@ -252,58 +268,29 @@ def main():
         sys.exit(2)
 
 
-def run(a):
-    import torch
-    import torch.distributed as dist
-    import blockpuzzle_gym_amd as bpg
-    from blockpuzzle_gym_amd import _lib, distributed as D
-
-    if a.single_device:
-        os.environ['LOCAL_RANK'] = '0'
-    rank, world, local = D.init_from_env(backend=a.backend)
-    force_dist = os.environ.get('BPG_BENCH_FORCE_DIST') == '1'     # rehearsal: RCCL path on one rank
-    if force_dist and world == 1 and not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        torch.cuda.set_device(local)
-        dist.init_process_group(a.backend or 'nccl', rank=0, world_size=1, device_id=torch.device('cuda', local))
-    if world != a.gpus:
-        raise RuntimeError('--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts the ranks '
-                           'itself) or under torchrun --nproc-per-node N' % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise RuntimeError('bench.py needs a GPU (no CPU fallback)')
-    multi = world > 1 or force_dist          # take the collective code path
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    L = _lib.lib()
-    T = a.T
-    if a.total_envs:
-        total = a.total_envs
-        lo, hi = D.shard_range(total, rank, world)
-        B = hi - lo
-    else:
-        B = a.envs
-        total = B * world
+def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_probe=False):
+    """One timed leg: W warm-up + exactly K timed fused rollouts of this rank's B-env shard of a `total`-env job, bracketed
+    by barrier + synchronize, MAX over ranks.  collective (N > 1 or forced): 'allreduce' = the [successes, envs] rows in
+    slabs of R rollouts (16 B per rollout); 'allgather' = every env's episode return (bpg_rollout_args.d_episode_return,
+    4 B/env, written by the rollout launch itself) all-gathered into global env order once per R rollouts -- the
+    exchange BASELINE configs[3] names.  Collectives are asynchronous: RCCL runs them on its own stream, so the
+    exchange of rollout i overlaps the kernel of rollout i+1; a return buffer is reused only after its gather is done."""
+    torch, dist, _lib, D, L, a = cx.torch, cx.dist, cx._lib, cx.D, cx.L, cx.a
+    dev, stream, rank, world, multi, T = cx.dev, cx.stream, cx.rank, cx.world, cx.multi, cx.T
     env = D.make_sharded(ENV_ID, total, rank, world, device=dev, seed=a.seed)
     assert env.num_envs == B
-    if not a.default_stream:
-        # a dedicated stream: the legacy default stream serialises against the RCCL stream
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-
-    # inputs resident in HBM before the timed region: (T, B) contact masks from the
-    # synthetic source (global env index keyed), outputs preallocated
-    # Variation draws num_grey per episode (fetch_env.py:647); fixed explicit draws keep every
-    # rollout's episode consistent with the pre-generated contact masks
+    # inputs resident in HBM before the timed region: (T, B) contact masks from the synthetic source (global env index
+    # keyed), outputs preallocated.  Variation draws num_grey per episode (fetch_env.py:647); fixed explicit draws keep
+    # every rollout's episode consistent with the pre-generated contact masks
     num_grey = ((torch.arange(B, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
     env.reset(num_grey=num_grey)
-    # NBUF independent input/output buffer sets, used round-robin, so that no launch finds its
-    # contact masks in the 256 MiB Infinity Cache from a previous launch: inputs come from HBM
-    # (a set is B * 450 bytes: enough sets that two consecutive uses of one are > 2 x 256 MiB apart)
+    # NBUF independent input/output buffer sets, used round-robin, so that no launch finds its contact masks in the
+    # 256 MiB Infinity Cache from a previous launch: inputs come from HBM (a set is B * 450 bytes: enough sets that two
+    # consecutive uses of one are > 2 x 256 MiB apart)
     NBUF = max(a.buffers, int(2.5 * 256 * 2**20 // (B * T * 9)) + 1)
-    # time-major (T, B) streams whose rows are LD = bpg_row_stride(B) elements apart (B + 256 for the
-    # power-of-two batch sizes): rows a power of two apart land on the same HBM channels.
-    # The pad is never read or written and is not counted in the bytes.  --contiguous-rows: LD = B.
+    # time-major (T, B) streams whose rows are LD = bpg_row_stride(B) elements apart (B + 256 for the power-of-two batch
+    # sizes): rows a power of two apart land on the same HBM channels (DESIGN.md 4).  The pad is never read or written
+    # and is not counted in the bytes.  --contiguous-rows: LD = B.
     LD = B if a.contiguous_rows else int(L.bpg_row_stride(B))
 
     def tm_empty(dtype):
@@ -317,47 +304,62 @@ def run(a):
         reward.append(tm_empty(torch.float32))
         flags.append(tm_empty(torch.uint8))
     env.seed(a.seed)
-    # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167).
-    # Rollout i adds its success count straight into row i of `stats` = [successes, envs]; with
-    # N>1 GPUs that row is all-reduced asynchronously (RCCL runs it on its own stream, so the
-    # collective of rollout i overlaps the kernel of rollout i+1).
-    n_it = a.warmup + a.steps
+    gather = multi and collective == 'allgather'
+    equal_shards = total % world == 0
+    # ONE launch per rollout: reset (rollout.py:79) + T steps + success count (rollout.py:163-167) [+ the per-env episode
+    # return].  Rollout i adds its success count straight into row i of `stats` = [successes, envs].
+    n_it = warmup + steps
     stats = torch.zeros((n_it, 2), dtype=torch.int64, device=dev)
     stats[:, 1] = B
-    rows = [stats[i] for i in range(n_it)]
+    R = max(1, R)
+    # a collective follows every R-th rollout, the last warm-up rollout and the last rollout; grp[i] = number of
+    # collectives before rollout i = the exchange that will carry rollout i's results
+    coll_after = [multi and ((i + 1) % R == 0 or i == n_it - 1 or i == warmup - 1) for i in range(n_it)]
+    grp = [sum(coll_after[:i]) for i in range(n_it)]
+    ret = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    gathered = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(),
                              d_masks=masks[i % NBUF].data_ptr(), d_reward_tb=reward[i % NBUF].data_ptr(),
                              d_flags_tb=flags[i % NBUF].data_ptr(), ld_masks=LD, ld_out=LD,
+                             d_episode_return=ret[grp[i] % 2].data_ptr() if gather else None,
                              d_success_count=stats.data_ptr() + 16 * i) for i in range(n_it)]
-    # ONE pair of HIP events on the launch stream around the K timed launches: the kernel's average
-    # duration = elapsed / K.  (An event pair around every launch puts two marker packets between
-    # consecutive kernels: +2.4 us per launch on this stream, measured with round 2's tools/tune_geometry.)
+    # ONE pair of HIP events on the launch stream around the K timed launches: the kernel's average duration =
+    # elapsed / K.  (An event pair around every launch puts two marker packets between consecutive kernels: +2.4 us per
+    # launch on this stream, measured with round 2's tools/tune_geometry.)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    works = []
+    works = []                     # all-reduce handles
+    gworks = {}                    # group index -> all-gather handle
     pending = [0]                  # first statistics row that has not been all-reduced yet
-    R = max(1, a.reduce_every)
-    gathered = [torch.empty(world * B, dtype=torch.uint8, device=dev) for _ in range(2)] \
-        if (multi and a.collective == 'allgather') else None
+    ncoll = [0]
 
     def one_rollout(i, k=None):
+        if gather and (i == 0 or coll_after[i - 1]):
+            w = gworks.pop(grp[i] - 2, None)      # this group's return buffer was read by the gather two groups ago
+            if w is not None:
+                w.wait()                            # stream-level wait, no host block
         if k == 0:
             ev0.record()
         _lib.check(L.bpg_rollout(env._h, C.byref(args[i]), stream))
-        if k == a.steps - 1:
+        if k == steps - 1:
             ev1.record()
-        if multi and ((i + 1) % R == 0 or i == n_it - 1 or i == a.warmup - 1):
-            # one collective per R rollouts: the [successes, envs] rows not yet reduced
-            lo, pending[0] = pending[0], i + 1
-            if a.collective == 'allreduce':
+        if coll_after[i]:
+            ncoll[0] += 1
+            if not gather:
+                # one collective per R rollouts: the [successes, envs] rows not yet reduced
+                lo, pending[0] = pending[0], i + 1
                 works.append(dist.all_reduce(stats[lo:i + 1], async_op=True))
-            else:   # per-env final (is_success | done<<1 | step_ok<<2) bytes of every shard, global env order
-                works.append(dist.all_gather_into_tensor(gathered[(i // R) % 2], flags[i % NBUF][T - 1],
-                                                         async_op=True))
+            elif equal_shards:     # one all_gather_into_tensor straight into the (total,) result
+                g = grp[i]
+                gworks[g] = D.all_gather_per_env(ret[g % 2], total_envs=total, out=gathered[g % 2], async_op=True)[1]
+            else:                  # ragged shards: padded, still one collective, compacted on the device
+                D.all_gather_per_env(ret[grp[i] % 2], total_envs=total, out=gathered[grp[i] % 2])
 
     def drain():
         while works:
             works.pop().wait()
+        for g in sorted(gworks):
+            gworks.pop(g).wait()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -368,9 +370,9 @@ def run(a):
     # Row-stride probe (set-up, untimed part of the run; `value` always uses LD above): the headline launch at
     # rows B, B + 256 and B + 768 elements apart on THIS box -- DESIGN.md 3 derives bpg_row_stride from a handful
     # of boxes, this records what the box the bench ran on says.
-    stride_probe = None
-    if rank == 0 and not a.no_stride_probe and B >= (1 << 19):
-        stride_probe = {}
+    probe = None
+    if stride_probe and rank == 0 and not a.no_stride_probe and B >= (1 << 19):
+        probe = {}
         pads = tuple(int(x) for x in a.stride_pads.split(','))
         probes = {}
         try:
@@ -405,30 +407,31 @@ def run(a):
                         best[pad].append(p0.elapsed_time(p1) / 60)
             for pad in pads:
                 ms = min(best[pad])
-                stride_probe['ld_B_plus_%d' % pad] = {'kernel_ms': ms, 'frac_hbm_peak': B * (T * 9 + 12) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                      'runs_ms': best[pad]}
+                probe['ld_B_plus_%d' % pad] = {'kernel_ms': ms, 'frac_hbm_peak': B * (T * 9 + 12) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               'runs_ms': best[pad]}
         except Exception as e:  # noqa: BLE001
-            stride_probe['error'] = repr(e)[:200]
-        stride_probe['library_choice'] = int(L.bpg_row_stride(B)) - B
-        stride_probe['how'] = 'three interleaved passes over the pads (first discarded), 60 launches each, HIP events; min of the two kept'
+            probe['error'] = repr(e)[:200]
+        probe['library_choice'] = int(L.bpg_row_stride(B)) - B
+        probe['how'] = 'three interleaved passes over the pads (first discarded), 60 launches each, HIP events; min of the two kept'
         del probes
         torch.cuda.empty_cache()
 
-    if a.prewarm > 0:                      # set-up, not measurement: same launch, scratch statistics row
-        scratch = torch.zeros(2, dtype=torch.int64, device=dev)
-        pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
-                                d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(), ld_masks=LD, ld_out=LD,
-                                d_success_count=scratch.data_ptr()) for k in range(NBUF)]
-        for i in range(a.prewarm):
+    scratch = torch.zeros(2, dtype=torch.int64, device=dev)
+    pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
+                            d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(), ld_masks=LD, ld_out=LD,
+                            d_episode_return=ret[0].data_ptr() if gather else None,
+                            d_success_count=scratch.data_ptr()) for k in range(NBUF)]
+    if prewarm > 0:                        # set-up, not measurement: same launch, scratch statistics row
+        for i in range(prewarm):
             _lib.check(L.bpg_rollout(env._h, C.byref(pre[i % NBUF]), stream))
         torch.cuda.synchronize(dev)
-    for i in range(a.warmup):
+    for i in range(warmup):
         one_rollout(i)
     drain()
     fence()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_rollout(a.warmup + k, k)
+    for k in range(steps):
+        one_rollout(warmup + k, k)
     host_dt = time.perf_counter() - t0          # time to ENQUEUE the K steps (host side only)
     drain()
     fence()
@@ -437,39 +440,114 @@ def run(a):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    kernel_ms = ev0.elapsed_time(ev1) / a.steps
+    kernel_ms = ev0.elapsed_time(ev1) / steps
+    # Spread (untimed, after the measurement): three more groups of K launches of the same kernel on the same buffers,
+    # each between its own event pair, no collectives -- how much the launch duration moves on this box, and at N > 1
+    # the launch duration without the waits for the collective that the timed region's events include
+    groups = []
+    for g in range(3):
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for i in range(steps):
+            _lib.check(L.bpg_rollout(env._h, C.byref(pre[(g * steps + i) % NBUF]), stream))
+        g1.record()
+        torch.cuda.synchronize(dev)
+        groups.append(g0.elapsed_time(g1) / steps)
+    spread = {'min': min(groups + [kernel_ms]), 'max': max(groups + [kernel_ms]), 'timed_region': kernel_ms, 'later_groups': groups,
+              'how': 'the K timed launches + 3 untimed groups of K launches after them, one HIP event pair per group'}
     rank_kernel_ms = [kernel_ms]
     if multi:                                   # every rank's own HIP-event figure (the headline uses rank 0's)
         km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
         allk = [torch.zeros_like(km) for _ in range(dist.get_world_size())]
         dist.all_gather(allk, km)
         rank_kernel_ms = [float(k.item()) for k in allk]
-    if multi and a.collective == 'allgather':
-        succ_rate = float((gathered[((n_it - 1) // R) % 2] & 1).float().mean().item())
+    last = stats[-1].clone()
+    if gather:                                  # untimed: the global success rate of the last rollout
+        dist.all_reduce(last)
+    last = last.tolist()
+    succ_rate = last[0] / last[1]               # global: the row was all-reduced when world > 1
+    checksum = None
+    if gather:
+        # the gathered (total,) returns of the LAST rollout, reduced to two integers any single-batch run can reproduce:
+        # failed steps summed over all envs, and the same weighted by (global env index mod 65521) + 1
+        gl = gathered[grp[n_it - 1] % 2]
+        nf = (-gl).to(torch.int64)
+        wts = (torch.arange(total, device=dev, dtype=torch.int64) % 65521) + 1
+        checksum = {'failed_steps': int(nf.sum().item()), 'weighted': int((nf * wts).sum().item()),
+                    'all_negative_zero_or_below': bool(torch.signbit(gl).all().item()),
+                    'mask_buffer_set': (n_it - 1) % NBUF, 'seed': a.seed + (n_it - 1) % NBUF}
+    return dict(env=env, masks=masks, reward=reward, flags=flags, B=B, total=total, LD=LD, NBUF=NBUF, R=R, dt=dt,
+                host_dt=host_dt, kernel_ms=kernel_ms, rank_kernel_ms=rank_kernel_ms, spread=spread, succ_rate=succ_rate,
+                checksum=checksum, probe=probe, collectives=ncoll[0], gather=gather, steps=steps, warmup=warmup)
+
+
+def run(a):
+    import types
+    import torch
+    import torch.distributed as dist
+    import blockpuzzle_gym_amd as bpg
+    from blockpuzzle_gym_amd import _lib, distributed as D
+
+    if a.single_device:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, world, local = D.init_from_env(backend=a.backend)
+    force_dist = os.environ.get('BPG_BENCH_FORCE_DIST') == '1'     # rehearsal: RCCL path on one rank
+    if force_dist and world == 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        torch.cuda.set_device(local)
+        dist.init_process_group(a.backend or 'nccl', rank=0, world_size=1, device_id=torch.device('cuda', local))
+    if world != a.gpus:
+        raise RuntimeError('--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (starts the ranks '
+                           'itself) or under torchrun --nproc-per-node N' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU (no CPU fallback)')
+    multi = world > 1 or force_dist          # take the collective code path
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    L = _lib.lib()
+    T = a.T
+    if a.total_envs:
+        total = a.total_envs
+        lo, hi = D.shard_range(total, rank, world)
+        B = hi - lo
     else:
-        last = stats[-1].tolist()
-        succ_rate = last[0] / last[1]        # global: the row was all-reduced when world > 1
+        B = a.envs
+        total = B * world
+    if not a.default_stream:
+        # a dedicated stream: the legacy default stream serialises against the RCCL stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    cx = types.SimpleNamespace(torch=torch, dist=dist, _lib=_lib, D=D, L=L, a=a, dev=dev, stream=stream, rank=rank,
+                               world=world, multi=multi, T=T)
+
+    h = rollout_leg(cx, total, B, a.collective, a.reduce_every, a.steps, a.warmup, a.prewarm, stride_probe=True)
+    dt, kernel_ms, LD, NBUF, R = h['dt'], h['kernel_ms'], h['LD'], h['NBUF'], h['R']
 
     # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env the packed state 8 B out (the in-launch Variation reset
     # overwrites the whole state, so the old state is not an input) + the explicit num_grey draw 4 B in
-    bytes_per_launch = B * (T * 9 + 8 + 4)
+    # (+ the episode return 4 B out when the leg all-gathers it)
+    bytes_per_launch = B * (T * 9 + 8 + 4 + (4 if h['gather'] else 0))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tf):
         t = json.load(open(tf)).get('k_rollout_masks')
-        if t and t.get('envs') == B and t.get('T') == T:
+        if t and t.get('envs') == B and t.get('T') == T and not h['gather']:
             traffic = t['hbm_bytes_per_launch']
+            traffic_source = ('committed constant, NOT measured by this run: profiles/traffic.json <- %s (rocprofv3 --pmc '
+                              'FETCH_SIZE / WRITE_SIZE passes of the same launch, corrected as MI355X_MICROARCH.md prescribes; '
+                              'counters cannot be collected from inside the bench)' % t.get('source', 'tools/collect_profiles.sh'))
 
     # rocprofv3 --kernel-trace --stats means of the committed profile of this same command
-    # (tools/collect_profiles.sh -> profiles/r02_pmc/kernel_means.json), quoted beside the live HIP-event figures
-    prof_means = {}
-    mf = os.path.join(ROOT, 'profiles', 'r03_pmc', 'kernel_means.json')
-    if not os.path.exists(mf):
-        mf = os.path.join(ROOT, 'profiles', 'r02_pmc', 'kernel_means.json')
-    if os.path.exists(mf):
-        prof_means = json.load(open(mf))
+    # (tools/collect_profiles.sh -> profiles/r0N_pmc/kernel_means.json), quoted beside the live HIP-event figures
+    prof_means, mf = {}, None
+    for rnd in ('r04', 'r03', 'r02'):
+        mf = os.path.join(ROOT, 'profiles', rnd + '_pmc', 'kernel_means.json')
+        if os.path.exists(mf):
+            prof_means = json.load(open(mf))
+            break
 
     def rocprof_of(label, nbytes):
         m = prof_means.get(label)
@@ -478,39 +556,43 @@ def run(a):
         return {'mean_us': m['mean_us'], 'calls': m['calls'],
                 'frac_hbm_peak': nbytes / (m['mean_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'source': os.path.relpath(mf, ROOT)}
 
+    coll = (a.collective if multi else None)
     out = {
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-        'host_enqueue_ms_per_step': host_dt / a.steps * 1e3,
+        'host_enqueue_ms_per_step': h['host_dt'] / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'strong' if a.total_envs else 'weak', 'vs_baseline': None, 'dtype': 'u32',
         'data': 'synthetic',
         'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
                                '(rows %d elements apart) resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
-                               'env-step' % (ENV_ID, B, T, LD),
+                               'env-step%s' % (ENV_ID, B, T, LD, ', episode return f32 per env' if h['gather'] else ''),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'row_stride_elements': LD,
                    'parallelism': 'env-shard x%d' % world,
-                   'buffer_sets': NBUF, 'collective': (a.collective if multi else None),
+                   'buffer_sets': NBUF, 'collective': coll,
                    'rollouts_per_collective': (R if multi else None),
-                   'success_rate': succ_rate},
+                   'success_rate': h['succ_rate']},
         # what the collective path actually ran with (observed, not requested)
         'rccl_world_size': (dist.get_world_size() if dist.is_initialized() else 1),
         'backend': (dist.get_backend() if dist.is_initialized() else None),
-        'collective': (a.collective if multi else None),
-        'collective_bytes_per_rollout': (None if not multi else
-                                         (world * B if a.collective == 'allgather' else 16)),
-        'gathered_bytes_per_rollout': (world * B if (multi and a.collective == 'allgather') else None),
-        'kernel_ms_per_rank': {'min': min(rank_kernel_ms), 'max': max(rank_kernel_ms), 'all': rank_kernel_ms},
+        'collective': coll,
+        'collectives_issued': (h['collectives'] if multi else None),
+        'collective_bytes_per_rollout': (None if not multi else (4 * total if h['gather'] else 16)),
+        'gathered_bytes_per_rollout': (4 * total if h['gather'] else None),
+        'gathered_return_checksum': h['checksum'],
+        'kernel_ms_per_rank': {'min': min(h['rank_kernel_ms']), 'max': max(h['rank_kernel_ms']), 'all': h['rank_kernel_ms']},
+        'kernel_ms_spread': h['spread'],
         'roofline': {'bound': 'hbm', 'kernel': 'k_rollout<masks, %s, reward+flags, reset>' % ('2 envs/lane x 1024 lanes' if B >= 524288 else ('2 envs/lane x 256 lanes' if B >= 229376 else '1 env/lane x 256 lanes, pipelined')), 'achieved': achieved,
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'bytes_per_launch': bytes_per_launch,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': bytes_per_launch / (B * T), 'kernel_ms': kernel_ms,
-                     'rocprofv3_committed': rocprof_of('k_rollout_masks_bench', bytes_per_launch) if B == (1 << 20) and T == 50 else None},
+                     'kernel_ms_spread': {'min': h['spread']['min'], 'max': h['spread']['max']},
+                     'rocprofv3_committed': rocprof_of('k_rollout_masks_bench', bytes_per_launch) if B == (1 << 20) and T == 50 and not h['gather'] else None},
     }
-    if stride_probe is not None:
-        out['row_stride_probe'] = stride_probe
+    if h['probe'] is not None:
+        out['row_stride_probe'] = h['probe']
 
     if rank == 0 and world == 1 and not a.no_extras:
-        out['extra'] = extras(torch, bpg, _lib, env, masks[0], reward[0], flags[0], B, T, dev, stream)
+        out['extra'] = extras(torch, bpg, _lib, h['env'], h['masks'][0], h['reward'][0], h['flags'][0], B, T, dev, stream)
         # SURVEY 8(d)'s per-step accounting (25 B/env-step: state read+written every step) for the
         # one-launch-per-step form of the same path, next to the fused headline above
         one = out['extra'].get('step_masks_single_launch_hbm_cold', {})
@@ -524,6 +606,35 @@ def run(a):
                 'rocprofv3_committed': rocprof_of('k_step_vec4_masks', 25 * B) if B == (1 << 20) else None,
                 'graph_replay_of_T_launches': {k: grp.get(k) for k in ('ms', 'GB/s', 'frac_hbm_peak',
                                                                       'env_steps_per_sec')}}
+
+    # BASELINE configs[3] as written, as a second timed leg of the same run whenever the job has a collective path
+    # (N > 1, or the one-rank RCCL rehearsal): 4 194 304 envs in total sharded over the ranks, every env's episode return
+    # all-gathered once per rollout.  The headline above stays the weak-scaling figure the driver's scaling curve needs.
+    if multi and not a.no_config3 and not (h['gather'] and total == a.config3_total and R == 1):
+        del h
+        torch.cuda.empty_cache()
+        c_lo, c_hi = D.shard_range(a.config3_total, rank, world)
+        c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50))
+        cb = c['B'] * (T * 9 + 16)
+        out.setdefault('extra', {})['config3_as_written'] = {
+            'workload': '%s, %d envs in total = %d per GPU x %d GPUs, T=%d fused rollout per step, every env\'s episode return '
+                        '(f32, written by the rollout launch) all-gathered into global env order once per rollout'
+                        % (ENV_ID, c['total'], c['B'], world, T),
+            'value': c['total'] * T * c['steps'] / c['dt'], 'unit': 'env-steps/s', 'scaling': 'strong',
+            'steps': c['steps'], 'warmup': c['warmup'], 'ms_per_step': c['dt'] / c['steps'] * 1e3,
+            'host_enqueue_ms_per_step': c['host_dt'] / c['steps'] * 1e3,
+            'total_envs': c['total'], 'envs_per_gpu': c['B'], 'row_stride_elements': c['LD'], 'buffer_sets': c['NBUF'],
+            'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+            'collective': 'allgather', 'rollouts_per_collective': 1, 'collectives_issued': c['collectives'],
+            'sent_bytes_per_rank_per_rollout': 4 * c['B'], 'gathered_bytes_per_rollout': 4 * c['total'],
+            'gathered_return_checksum': c['checksum'], 'success_rate': c['succ_rate'],
+            'stream_ms_per_rollout_incl_collective_waits': c['kernel_ms'],
+            'kernel_ms_no_collective': c['spread']['later_groups'],
+            'kernel_ms_per_rank': {'min': min(c['rank_kernel_ms']), 'max': max(c['rank_kernel_ms']), 'all': c['rank_kernel_ms']},
+            'roofline_kernel_only': {'bound': 'hbm', 'bytes_per_launch': cb, 'kernel_ms': min(c['spread']['later_groups']),
+                                     'frac': cb / (min(c['spread']['later_groups']) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        del c
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
     if multi:
@@ -581,6 +692,14 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
             res['rollout_masks_%d_envs' % Bx] = rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line)
         except Exception as e:  # noqa: BLE001
             res['rollout_masks_%d_envs' % Bx] = {'error': repr(e)[:200]}
+    # ... configs[3]'s per-GPU shard with the per-env episode return the 8 GPUs all-gather (4 B/env more), and the headline
+    # batch with it
+    for Bx in (524288, B):
+        try:
+            res['rollout_masks_%d_envs_with_episode_return' % Bx] = rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line,
+                                                                               episode_return=True)
+        except Exception as e:  # noqa: BLE001
+            res['rollout_masks_%d_envs_with_episode_return' % Bx] = {'error': repr(e)[:200]}
     # ... and the evaluator's n_test_rollouts = 10 (config.py:43) rollouts of configs[1] in ONE launch
     try:
         res['rollout_masks_65536_envs_10_rollouts_per_launch'] = rollout_at(torch, bpg, _lib, 65536, T, dev, stream, timed,
@@ -633,7 +752,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     def step_record():
         _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
                                      C.c_void_p(flags.data_ptr()), C.c_void_p(succ_f.data_ptr()),
-                                     C.c_void_p(agrec.data_ptr()), env.dimg, None, None, stream))
+                                     C.c_void_p(agrec.data_ptr()), env.dimg, None, None, None, stream))
     res['step_record_single_launch'] = line(timed(step_record, 100), (29 + 4 * env.dimg) * B, B)
     del agrec, succ_f
 
@@ -819,7 +938,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     return res
 
 
-def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1):
+def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1, episode_return=False):
     """The bench headline (one fused reset + T-step + success-count launch, masks from HBM) at
     another batch size; rollouts = K > 1: K consecutive rollouts (the evaluator's loop, train.py:63-64)
     in ONE launch, every figure per rollout."""
@@ -837,15 +956,17 @@ def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1):
         _lib.check(L.bpg_synth_masks_ld(e._h, 0, K * T, C.c_void_p(m.data_ptr()), ld, stream))
         sets.append((m, bpg.time_major_empty(K * T, Bx, torch.float32, dev), bpg.time_major_empty(K * T, Bx, torch.uint8, dev)))
     cnt = torch.zeros(max(2, K), dtype=torch.int64, device=dev)
+    ret = torch.empty((K, Bx), dtype=torch.float32, device=dev) if episode_return else None
     args = [_lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=ld,
-                             ld_out=ld, d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
+                             ld_out=ld, d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr(),
+                             d_episode_return=ret.data_ptr() if episode_return else None)
             for m, r, f in sets]
     it = [0]
 
     def go():
         _lib.check(L.bpg_rollout(e._h, C.byref(args[it[0] % nset]), stream))
         it[0] += 1
-    out = line(timed(go, max(40, 2 * nset)) / K, Bx * (T * 9 + 12), Bx * T)
+    out = line(timed(go, max(40, 2 * nset)) / K, Bx * (T * 9 + 12 + (4 if episode_return else 0)), Bx * T)
     out['buffer_sets'] = nset
     out['note'] = 'ms = events around a train of back-to-back launches (includes the launch gaps; see launch_floor_smallest_kernel)'
     if K > 1:

@@ -86,7 +86,7 @@ SIGNATURES = {
     'bpg_contacts_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bpg_contacts_csr_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'bpg_step_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks_ld': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -1247,55 +1247,90 @@ k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, in
 // float32 obs['achieved_goal'] row (at out + e*ld: a dense (n, dimg) array or the time slot
 // of an episode buffer) and info['is_success'] as float32, in ONE launch -- the packed state
 // never makes a second trip through HBM and the host issues one launch instead of five.
-template <int SIDE, int SRC, bool VEC4>
-__global__ void __launch_bounds__(64)
+// A wave owns tiles of 64 consecutive envs: lane = env for the step, then the wave streams the tile's
+// contiguous 64 x dimg float region from a wave-private LDS copy of the packed states -- no block-wide
+// barrier, so the WPB waves of a block come and go on their own.  count (optional): += the number of envs
+// whose has_succeeded latch is set after this step -- `successful = successes[-1]` of rollout.py:163-167
+// inside the LAST step's launch of a rollout instead of a launch of its own.
+// NT: the write-once outputs (achieved_goal rows, is_success, reward, flags, the action copy) leave as nontemporal
+// stores.  Plain stores allocate in the L2 and are written back when the kernel ends, behind the last wave: in a
+// graph-replayed train of step launches at 65 536 envs that put 1.4 us of store drain inside every launch and 0.8 us
+// of write-back behind it (5.9 -> 4.1 us per step; 35.0 -> 33.3 us at 1 M envs, 152 -> 115 us at 4 M;
+// tools/tune_round4.hip, profiles/r04_tune_step_train.log).  The packed state, re-read by the next step, stays plain.
+#ifdef BPG_TIMELINE
+// tools/tune_round4.hip: entry / exit time of every block of every node of a replayed train of step launches; the node
+// is told by the time slot the launch writes its achieved_goal rows into
+__device__ unsigned long long *bpg_tl_step = nullptr;
+__device__ const float *bpg_tl_ag_base = nullptr;
+__device__ long long bpg_tl_ag_slot = 1;
+#define BPG_TL_STEP(slot, agp) do { if (threadIdx.x == 0 && bpg_tl_step) { \
+        if (slot) __builtin_amdgcn_s_waitcnt(0); \
+        const long long node_ = ((agp) - bpg_tl_ag_base) / bpg_tl_ag_slot; \
+        bpg_tl_step[((size_t)node_ * gridDim.x + blockIdx.x) * 2 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define BPG_TL_STEP(slot, agp) do { } while (0)
+#endif
+template <int SIDE, int SRC, bool VEC4, int WPB = 1, bool NT = false>
+__global__ void __launch_bounds__(64 * WPB)
 k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
               uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, float *__restrict__ succ_f32,
               float *__restrict__ ag, int64_t ld, int64_t n, StepConst c, SynthConst s, PairTable tabv,
-              const float4 *__restrict__ u_in, float4 *__restrict__ u_out)
+              const float4 *__restrict__ u_in, float4 *__restrict__ u_out, CountArgs ca)
 {
     constexpr int DIMG = SIDE * SIDE;
-    __shared__ uint2 hist[64];
-    __shared__ PairTable tab;
-    const int lane = threadIdx.x;
-    if (lane == 0) tab = tabv;
-    const int64_t base = (int64_t)blockIdx.x * 64;
-    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-    if (lane < nvalid) {
-        const int64_t i = base + lane;
-        uint32_t a = now[i], e = ever[i], rb, fl;
-        const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, (uint32_t)i, s);
-        step_core(a, e, mk, c, rb, fl);
-        now[i] = a; ever[i] = e;
-        hist[lane] = make_uint2(a, e);
-        if (reward) reward[i] = rb;
-        if (flags) flags[i] = (uint8_t)fl;
-        if (succ_f32) succ_f32[i] = (fl & BPG_FLAG_SUCCESS) ? 1.0f : 0.0f;
-        if (u_out) u_out[i] = u_in[i];              // acts.append(u.copy()) of rollout.py:147, same launch
-    }
-    __syncthreads();
-    if (!ag) return;
-    float *o = ag + base * ld;
-    if (VEC4) {
-        constexpr int QPR = DIMG / 4;
-        for (int cidx = lane; cidx < nvalid * QPR; cidx += 64) {
-            const int e = cidx / QPR, q = cidx - e * QPR;
-            const uint2 h = hist[e];
-            const uint32_t pw = tab.quad[q];
-            float4 v;
-            v.x = tern(h.x, h.y, pw & 31u);
-            v.y = tern(h.x, h.y, (pw >> 5) & 31u);
-            v.z = tern(h.x, h.y, (pw >> 10) & 31u);
-            v.w = tern(h.x, h.y, (pw >> 15) & 31u);
-            *reinterpret_cast<float4 *>(o + e * ld + 4 * q) = v;
+    __shared__ uint2 hist_all[WPB][64];
+    __shared__ PairTable tab_all[WPB];
+    BPG_TL_STEP(0, ag);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint2 *hist = hist_all[wave];
+    PairTable *tab = &tab_all[wave];
+    if (lane == 0) *tab = tabv;
+    uint32_t nsucc = 0;
+    const int64_t ntiles = (n + 63) >> 6;
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+        const int64_t base = tile * 64;
+        const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
+        if (lane < nvalid) {
+            const int64_t i = base + lane;
+            uint32_t a = now[i], e = ever[i], rb, fl;
+            const uint32_t mk = fetch_mask<SRC>(SRC == SRC_MASKS ? masks[i] : 0u, a, e, (uint32_t)i, s);
+            step_core(a, e, mk, c, rb, fl);
+            now[i] = a; ever[i] = e;
+            hist[lane] = make_uint2(a, e);
+            nsucc += fl & BPG_FLAG_SUCCESS;
+            if (reward) st_1<NT>(&reward[i], rb);
+            if (flags) st_1<NT>(&flags[i], (uint8_t)fl);
+            if (succ_f32) st_1<NT>(&succ_f32[i], (fl & BPG_FLAG_SUCCESS) ? 1.0f : 0.0f);
+            if (u_out) st_f4<NT>(&u_out[i], u_in[i]);   // acts.append(u.copy()) of rollout.py:147, same launch
         }
-    } else {
-        for (int f = lane; f < nvalid * DIMG; f += 64) {
-            const int e = f / DIMG, k = f - e * DIMG;
-            const uint2 h = hist[e];
-            o[e * ld + k] = tern(h.x, h.y, tab.flat[k]);
+        wave_lds_sync();
+        if (ag) {
+            float *o = ag + base * ld;
+            if (VEC4) {
+                constexpr int QPR = DIMG / 4;
+                for (int cidx = lane; cidx < nvalid * QPR; cidx += 64) {
+                    const int e = cidx / QPR, q = cidx - e * QPR;
+                    const uint2 h = hist[e];
+                    const uint32_t pw = tab->quad[q];
+                    float4 v;
+                    v.x = tern(h.x, h.y, pw & 31u);
+                    v.y = tern(h.x, h.y, (pw >> 5) & 31u);
+                    v.z = tern(h.x, h.y, (pw >> 10) & 31u);
+                    v.w = tern(h.x, h.y, (pw >> 15) & 31u);
+                    st_f4<NT>(reinterpret_cast<float4 *>(o + e * ld + 4 * q), v);
+                }
+            } else {
+                for (int f = lane; f < nvalid * DIMG; f += 64) {
+                    const int e = f / DIMG, k = f - e * DIMG;
+                    const uint2 h = hist[e];
+                    st_1<NT>(&o[e * ld + k], tern(h.x, h.y, tab->flat[k]));
+                }
+            }
         }
+        wave_lds_sync();                                 // the tile is written again by the next trip
     }
+    if (ca.count) block_count_add(nsucc, ca);            // uniform
+    BPG_TL_STEP(1, ag);
 }
 
 // Geom-id contact lists -> packed pair masks (fetch_env.py:158-167 up to the matrix write), so
@@ -2971,9 +3006,11 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
 }
 
 int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, float *d_success_f32,
-                    float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out, void *stream)
+                    float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out, unsigned long long *d_success_count,
+                    void *stream)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if ((uintptr_t)d_success_count & 7u) return fail(BPG_ERR_ARG, "counters must be 8-byte aligned");
     if ((d_u_out != nullptr) != (d_u_in != nullptr)) return fail(BPG_ERR_ARG, "d_u_in and d_u_out go together");
     if (!aligned16(d_u_in) || !aligned16(d_u_out)) return fail(BPG_ERR_ARG, "action buffers must be 16-byte aligned");
     if (d_ag && ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
@@ -2983,6 +3020,7 @@ int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint
     const StepConst c = step_const(b);
     const SynthConst s = synth_const(b);
     const PairTable tab = pair_table(b->info);
+    const CountArgs ca = count_args(b, d_success_count, nullptr);
     const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
     const bool vec = (b->info.side % 2 == 0) && (ld % 4 == 0) && aligned16(d_ag);
     const bool synth = (d_masks == nullptr);
@@ -2992,9 +3030,9 @@ int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint
         constexpr int S = decltype(side)::value;
         constexpr bool EVEN = (S % 2 == 0);
 #define BPG_LAUNCH_SR(SRC, V)                                                                                  \
-        hipLaunchKernelGGL((k_step_record<S, SRC, V>), grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags, \
+        hipLaunchKernelGGL((k_step_record<S, SRC, V, 1, true>), grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags, \
                            d_success_f32, d_ag, ld, b->n, c, s, tab, reinterpret_cast<const float4 *>(d_u_in),     \
-                           reinterpret_cast<float4 *>(d_u_out))
+                           reinterpret_cast<float4 *>(d_u_out), ca)
         if (synth) {
             if (vec) BPG_LAUNCH_SR(SRC_SYNTH, EVEN); else BPG_LAUNCH_SR(SRC_SYNTH, false);
         } else {

@@ -126,8 +126,9 @@ def all_gather_per_env(local_values, total_envs=None, shard_sizes=None, out=None
     concatenation, nothing but the collective touches the data.  Ragged shards: the shards are padded to the longest
     (at most one extra env), still one collective, and the result is compacted on the device.
     async_op=True (equal shards only) returns (out, work) without waiting.
-    Without a process group (or world == 1) the input is returned as is."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    Without a process group the input is returned as is; a one-rank group still runs the collective (the rehearsal of
+    the RCCL path on a single GPU)."""
+    if not dist.is_initialized():
         return (local_values, None) if async_op else local_values
     world = dist.get_world_size()
     n_local = local_values.shape[0]

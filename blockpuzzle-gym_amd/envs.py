@@ -402,8 +402,10 @@ class BatchedBlocksEnv:
         return self._get_obs(ag_out=achieved_goal_out)
 
     def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None,
-                   u_out=None):
-        """Launches one env step; returns (reward, flags, achieved_goal) device tensors."""
+                   u_out=None, count_out=None):
+        """Launches one env step; returns (reward, flags, achieved_goal) device tensors.
+        count_out: int64 device tensor; the launch adds the number of envs whose has_succeeded latch is set after the
+        step (the rollout worker passes it with the last step of a rollout, rollout.py:163-167)."""
         a = self._to_dev(action, torch.float32)
         if a is not None:
             a = a.reshape(self.num_envs, self.dimu)
@@ -461,8 +463,10 @@ class BatchedBlocksEnv:
             u_in = a if a.is_contiguous() else a.contiguous()
         # step + float achieved_goal (+ float success, + the action store) in one launch; NULL masks =
         # the synthetic source
+        if count_out is not None:
+            assert count_out.dtype == torch.int64 and count_out.numel() >= 1 and count_out.is_cuda
         _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
-                                           _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), st))
+                                           _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), _ptr(count_out), st))
         return reward, flags, ag
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):
@@ -631,15 +635,24 @@ def mat2euler(mat, device=None):
 def compute_reward(achieved_goal, goal, device=None):
     """Stateless BlocksEnv.compute_reward on the GPU.  numpy in -> numpy float32 out,
     torch in -> torch float32 out (on `device`).  The products and their sum are taken in the precision NumPy
-    would use for `achieved_goal * goal` (fetch_env.py:141): float64 unless both arrays are float32 (the
-    reference's own call passes a float64 matrix, robot_env.py:66; HER's replay arrays are float32), and in
-    NumPy's summation order -- for the ternary rows of the env any order is exact."""
+    would use for `achieved_goal * goal` (fetch_env.py:141) -- np.result_type of the two arrays: float64 for the
+    reference's own call (a float64 matrix, robot_env.py:66), float32 for HER's float32 replay arrays -- and in
+    NumPy's summation order; for the ternary rows of the env any order is exact.  float64 rows longer than 159
+    entries raise ValueError."""
     L = _lib.lib()
     np_in = not torch.is_tensor(achieved_goal)
     dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
     ag = torch.as_tensor(np.asarray(achieved_goal) if np_in else achieved_goal)
     g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal)
-    wide = not (ag.dtype == torch.float32 and g.dtype == torch.float32) and ag.shape[-1] <= 159
+    # the precision of `achieved_goal * goal` by NumPy's promotion rules (float32 x int8 / int16 / bool / float16 stays
+    # float32; float32 x int32 / int64 / float64 is float64; integer x integer stays integer -- exact, run in float64)
+    rt = np.result_type(*(np.dtype(str(t.dtype).replace('torch.', '')) for t in (ag, g)))
+    if rt == np.float16:
+        raise NotImplementedError('compute_reward on float16 x float16 rows (NumPy would sum in float16)')
+    wide = rt != np.float32
+    if wide and ag.shape[-1] > 159:
+        raise ValueError('compute_reward: float64 rows are limited to 159 entries (bpg_compute_reward_f64); got %d -- '
+                         'pass float32 arrays if float32 arithmetic is what is wanted' % ag.shape[-1])
     ft = torch.float64 if wide else torch.float32
     ag = ag.to(dev, ft).contiguous()
     g = g.to(dev, ft)

@@ -113,6 +113,12 @@ class RolloutStudent:
         self.Q_history = deque(maxlen=history_len)
         self.n_episodes = 0
         self._watch_o, self._nan_flag = False, None
+        # running total of successful envs over all rollouts of this worker: the LAST step launch of a rollout (or the
+        # fused launch) adds the rollout's count, _finish reads the total once and takes the difference -- no launch of
+        # its own for `successful = successes[-1]` (rollout.py:163-167), nothing to zero between rollouts (hipGraph
+        # replays included)
+        self._succ_total = torch.zeros(1, dtype=torch.int64, device=env.device)
+        self._succ_seen = 0
         f32 = dict(dtype=torch.float32, device=self.device)
         self.g = torch.empty((B, dims['g']), **f32)
         self.initial_o = torch.empty((B, dims['o']), **f32)
@@ -170,11 +176,21 @@ class RolloutStudent:
             ep['g'] = torch.empty(shp(T, d['g']), **f32)
         return ep
 
-    def _finish(self, episode, Qs=()):
+    def _resync_success_total(self):
+        """After a rollout body whose result is thrown away (restart, graph warm-up): forget what it counted."""
+        self._succ_seen = int(self._succ_total.item())
+
+    def _finish(self, episode, Qs=(), counted=False):
         # rollout.py:163-167 `successful = successes[-1]; success_rate = np.mean(successful)`: the last
         # column of info_is_success is the has_succeeded latch of the state the rollout ended in, so
-        # the mean is the HIP success count over B (exact in float64, as NumPy's mean of 0/1 values)
-        success_rate = float(self.env.success_count().item()) / self.rollout_batch_size
+        # the mean is the HIP success count over B (exact in float64, as NumPy's mean of 0/1 values).
+        # counted: the rollout's launches added that count to the worker's running total themselves
+        if counted:
+            total = int(self._succ_total.item())
+            successes, self._succ_seen = total - self._succ_seen, total
+        else:
+            successes = int(self.env.success_count().item())
+        success_rate = float(successes) / self.rollout_batch_size
         self.success_history.append(success_rate)
         if self.compute_Q and len(Qs):
             # rollout.py:168-169 `self.Q_history.append(np.mean(Qs))`: NumPy's mean over the stacked per-step arrays, in
@@ -198,12 +214,14 @@ class RolloutStudent:
                 ep, Qs = self._rollout_body(test, num_grey, compute_Attention)
             except PhysicsError as e:
                 self._log('warning', 'physics backend failed during rollout generation (%s). Trying again...' % e)
+                self._resync_success_total()
                 continue
             if self._nan_caught():
                 self._log('warning', 'NaN caught during rollout generation. Trying again...')
+                self._resync_success_total()
                 self.reset_all_rollouts(test, num_grey=num_grey)
                 continue
-            return self._finish(ep, Qs)
+            return self._finish(ep, Qs, counted=True)
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
 
     def _log(self, level, msg):
@@ -246,19 +264,20 @@ class RolloutStudent:
     def _step_into(self, u, ep, t, reward_out=None, u_store=None):
         """One env step that writes obs['achieved_goal'] / info['is_success'] (and, through the
         backend, obs['observation']; optionally the step reward) straight into time slot t+1 / t
-        of the episode."""
+        of the episode.  The last step of the rollout also adds the success count to the worker's total."""
         env = self.env
+        cnt = self._succ_total if t == self.T - 1 else None
         if self._watch_o:
             slot = env.observation = ep['o'][t + 1]          # the backend's write lands in the episode
             env._observation_checked = False
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt)
             if not env._observation_checked:                 # written by other means than assemble_observation
                 _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
                                                        _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt)
         return r
 
     def _rollout_body(self, test, num_grey, compute_Attention=False):
@@ -325,6 +344,7 @@ class RolloutStudent:
                 self.env.load_state_dict(snapshot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
+            self._resync_success_total()                       # the warm-up pass counted: not a rollout
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._graph_ep, self._graph_Qs = self._graph_body(test, ng)
@@ -335,7 +355,7 @@ class RolloutStudent:
         if self._nan_caught():
             raise FloatingPointError('NaN in the observations of a graph-replayed rollout (the replay cannot be '
                                      'restarted from the host: use generate_rollouts)')
-        return self._finish(dict(self._graph_ep), self._graph_Qs)
+        return self._finish(dict(self._graph_ep), self._graph_Qs, counted=True)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
                                 want_reward=False, materialize_constants=False, gamma=None, episode_return=False):
@@ -373,13 +393,14 @@ class RolloutStudent:
                                 d_ep_ag=ep['ag'].data_ptr(),
                                 d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
                                 d_ep_success=ep['info_is_success'].data_ptr(),
+                                d_success_count=self._succ_total.data_ptr(),
                                 ld_out=0 if reward is None else int(reward.stride(0)))
         if masks is not None:            # rows may be padded (time_major_empty): any row stride >= B
             assert masks.shape == (T, B) and masks.stride(1) == 1 and masks.element_size() == 4 \
                 and (T == 1 or masks.stride(0) >= B)
             args.ld_masks = int(masks.stride(0)) if T > 1 else B
         _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
-        out = self._finish(ep)
+        out = self._finish(ep, counted=True)
         if want_reward:
             out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
         if G is not None:
@@ -552,9 +573,10 @@ class PGRolloutStudent(RolloutStudent):
             ep = self._pg_body(test, exploit, num_grey)
             if self._nan_caught():
                 self._log('info', 'NaN caught during rollout generation. Trying again...')
+                self._resync_success_total()
                 self.reset_all_rollouts(test, num_grey=num_grey)
                 continue
-            return self._finish(ep)
+            return self._finish(ep, counted=True)
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
 
     def _graph_body(self, test, num_grey):
@@ -567,7 +589,16 @@ class PGRolloutStudent(RolloutStudent):
         if self.expert is not None:
             raise NotImplementedError('a rollout with an expert decides per step on the host: use generate_rollouts')
         self._graph_exploit = bool(exploit)
-        return super().generate_rollouts_graphed(test=test, num_grey=num_grey, _key=('pg', bool(exploit)))
+        # The reference draws np.random.rand() once per step even when beta is 0 (policy_gradient/rollout.py:196), and so
+        # does the eager path.  A replay runs no host code, and warm-up + capture run the body twice: put the global
+        # NumPy stream back where it was and consume exactly T draws per rollout, so that whatever else reads
+        # np.random after set_global_seeds (exploration noise, HER sampling) sees the stream an eager rollout leaves.
+        state = np.random.get_state()
+        try:
+            return super().generate_rollouts_graphed(test=test, num_grey=num_grey, _key=('pg', bool(exploit)))
+        finally:
+            np.random.set_state(state)
+            np.random.rand(self.T)
 
     def _pg_body(self, test, exploit, num_grey):
         env, B, T = self.env, self.rollout_batch_size, self.T

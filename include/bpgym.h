@@ -173,10 +173,12 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
  * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32),
  * info['is_success'] as float32 d_success_f32[n_envs], and the step's actions d_u_in (n_envs, 4)
  * float32 stored into the episode's action slot d_u_out (`acts.append(u.copy())`, rollout.py:147).
- * Every output pointer is optional (d_u_in / d_u_out go together). */
+ * d_success_count (8-byte aligned): += the number of envs whose has_succeeded latch is set after this step --
+ * `successful = successes[-1]` (rollout.py:163-167) inside the LAST step's launch of a rollout instead of a
+ * bpg_success_count launch of its own.  Every output pointer is optional (d_u_in / d_u_out go together). */
 int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
                     float *d_success_f32, float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out,
-                    void *stream);
+                    unsigned long long *d_success_count, void *stream);
 
 /* One step whose contacts come from the build-defined counter-based synthetic
  * source keyed (seed, global env id, elapsed step) -- physics stand-in for

@@ -95,31 +95,101 @@ def test_sharded_rollout_gathers_the_returns_of_a_single_batch(world, total, fro
         assert rate == pytest.approx(float(cnt.item()) / total, abs=1e-12)
 
 
-def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
-    """`python bench.py --gpus 2` with no WORLD_SIZE set: the parent (which never touches the GPU) starts
-    two fresh rank processes -- the reference's mpi_fork, train.py:113-119 -- here both on cuda:0 with gloo
-    (one card on the box), relays rank 0's JSON line and exits 0.  --total-envs = BASELINE configs[3]'s
-    per-GPU shard size x 1 (524 288 envs over the two ranks), all-gather of the per-env final flag bytes."""
+def _bench(args, extra_env=None, timeout=900):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-device', '--backend', 'gloo',
-           '--total-envs', '524288', '--steps', '4', '--warmup', '2', '--prewarm', '4', '--collective', 'allgather',
-           '--reduce-every', '2', '--no-extras', '--no-cpu-baseline', '--launch-timeout', '500']
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
-    assert 'error' not in line
+    assert 'error' not in line, line
+    return line
+
+
+def _single_batch_checksum(total, seed):
+    """What bench.py's gathered_return_checksum must be: ONE batch of `total` envs, the masks of the synthetic source
+    seeded `seed` (global env index keyed), the bench's explicit num_grey draws, one fused rollout with the episode
+    return; failed steps summed over the envs, plain and weighted by (global env index mod 65521) + 1."""
+    import ctypes as C
+    import blockpuzzle_gym_amd as bpg
+    L = bpg._lib.lib()
+    env = bpg.make(ENV_ID, num_envs=total, device='cuda:0', seed=seed)
+    masks = bpg.time_major_empty(T, total, torch.int32, env.device)
+    bpg._lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(masks.data_ptr()), int(masks.stride(0)), None))
+    ng = (torch.arange(total, device=env.device, dtype=torch.int32) * 7) % 3
+    ret = torch.empty(total, dtype=torch.float32, device=env.device)
+    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
+                             ld_masks=int(masks.stride(0)), d_episode_return=ret.data_ptr())
+    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    nf = (-ret).to(torch.int64)
+    w = (torch.arange(total, device=env.device, dtype=torch.int64) % 65521) + 1
+    return int(nf.sum()), int((nf * w).sum())
+
+
+def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
+    """`python bench.py --gpus 2` with no WORLD_SIZE set: the parent (which never touches the GPU) starts
+    two fresh rank processes -- the reference's mpi_fork, train.py:113-119 -- here both on cuda:0 with gloo
+    (one card on the box), relays rank 0's JSON line and exits 0.  Headline: 524 288 envs over the two ranks,
+    all-gather of the per-env episode returns every second rollout; the config3 leg at a reduced job size."""
+    line = _bench(['--gpus', '2', '--single-device', '--backend', 'gloo', '--total-envs', '524288', '--steps', '4',
+                   '--warmup', '2', '--prewarm', '4', '--collective', 'allgather', '--reduce-every', '2', '--no-extras',
+                   '--no-cpu-baseline', '--launch-timeout', '500', '--config3-total', '1048576'])
     assert line['n_gpus'] == 2 and line['rccl_world_size'] == 2 and line['backend'] == 'gloo'
     assert line['scaling'] == 'strong' and line['config']['total_envs'] == 524288
     assert line['config']['envs_per_gpu'] == 262144
-    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 524288
+    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 4 * 524288
+    assert line['collectives_issued'] == 1 + 2                     # end of the warm-up, then every second timed rollout
     km = line['kernel_ms_per_rank']
     assert len(km['all']) == 2 and 0 < km['min'] <= km['max']
     assert line['launcher']['rank_exit_codes'] == [0, 0]
     assert line['value'] > 0 and 0 <= line['config']['success_rate'] <= 1
+    cs = line['gathered_return_checksum']
+    assert cs['all_negative_zero_or_below'] and (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(524288, cs['seed'])
+    c3 = line['extra']['config3_as_written']
+    assert c3['total_envs'] == 1048576 and c3['envs_per_gpu'] == 524288 and c3['collective'] == 'allgather'
+    assert c3['collectives_issued'] == 2 + 4 and c3['gathered_bytes_per_rollout'] == 4 * 1048576
+
+
+def test_bench_config3_as_written_on_four_ranks_of_one_card():
+    """BASELINE configs[3] end to end as far as one card allows: 4 194 304 envs sharded over FOUR rank processes on
+    cuda:0 (the box admits 6 processes on its card, this one included; the 8-rank collective layer runs on CPU tensors in
+    tests/test_distributed_cpu.py), every rollout launch writes its shard's episode returns, one all-gather per rollout
+    (gloo here, RCCL in the next test) assembles the (4 194 304,) array in global env order -- and that array equals the
+    returns of ONE 4 194 304-env batch."""
+    line = _bench(['--gpus', '4', '--single-device', '--backend', 'gloo', '--total-envs', '4194304', '--steps', '3',
+                   '--warmup', '1', '--prewarm', '2', '--collective', 'allgather', '--reduce-every', '1', '--no-extras',
+                   '--no-cpu-baseline', '--launch-timeout', '800'])
+    assert line['n_gpus'] == 4 and line['rccl_world_size'] == 4 and line['config']['envs_per_gpu'] == 1048576
+    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 4 * 4194304
+    assert line['collectives_issued'] == 1 + 3 and 'config3_as_written' not in line.get('extra', {})   # the headline IS that config
+    cs = line['gathered_return_checksum']
+    assert cs['all_negative_zero_or_below'] and cs['failed_steps'] > 0
+    assert (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(4194304, cs['seed'])
+    assert line['launcher']['rank_exit_codes'] == [0, 0, 0, 0]
+
+
+def test_bench_rccl_path_on_one_rank():
+    """BPG_BENCH_FORCE_DIST=1: a one-rank RCCL (`nccl` backend) process group, so that RCCL initialisation, the
+    asynchronous all-reduce of the statistics rows and -- in the config3 leg, 4 194 304 envs -- the all-gather of the
+    per-env episode returns run on device buffers under every GPU test run, not only on an 8-GPU node."""
+    line = _bench(['--gpus', '1', '--steps', '6', '--warmup', '2', '--prewarm', '10', '--no-extras', '--no-cpu-baseline',
+                   '--reduce-every', '3'], extra_env={'BPG_BENCH_FORCE_DIST': '1'})
+    assert line['n_gpus'] == 1 and line['rccl_world_size'] == 1 and line['backend'] == 'nccl'
+    assert line['collective'] == 'allreduce' and line['collective_bytes_per_rollout'] == 16
+    assert line['collectives_issued'] == 4 and line['config']['envs_per_gpu'] == 1048576     # after rollouts 1 (warm-up end), 2, 5, 7
+    c3 = line['extra']['config3_as_written']
+    assert c3['backend'] == 'nccl' and c3['rccl_world_size'] == 1 and c3['total_envs'] == 4194304
+    assert c3['collectives_issued'] == 2 + 6 and c3['gathered_bytes_per_rollout'] == 4 * 4194304
+    cs = c3['gathered_return_checksum']
+    assert (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(4194304, cs['seed'])
+    assert 0 < c3['roofline_kernel_only']['frac'] < 1 and c3['value'] > 0
+    sp = line['kernel_ms_spread']
+    assert 0 < sp['min'] <= sp['timed_region'] <= sp['max'] and len(sp['later_groups']) == 3
+    assert line['roofline']['traffic_source'] and 'NOT measured by this run' in line['roofline']['traffic_source']
 
 
 def test_bench_under_torchrun_two_ranks_on_one_card():
@@ -132,7 +202,7 @@ def test_bench_under_torchrun_two_ranks_on_one_card():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-device',
            '--backend', 'gloo', '--envs', '65536', '--steps', '4', '--warmup', '2', '--prewarm', '4', '--reduce-every', '2',
-           '--no-extras', '--no-cpu-baseline']
+           '--no-extras', '--no-cpu-baseline', '--config3-total', '262144']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = []
@@ -150,3 +220,6 @@ def test_bench_under_torchrun_two_ranks_on_one_card():
     assert line['n_gpus'] == 2 and line['rccl_world_size'] == 2 and line['scaling'] == 'weak'
     assert line['config']['total_envs'] == 131072 and line['collective'] == 'allreduce'
     assert line['collective_bytes_per_rollout'] == 16 and len(line['kernel_ms_per_rank']['all']) == 2
+    c3 = line['extra']['config3_as_written']                       # the second leg of every N > 1 run
+    assert c3['total_envs'] == 262144 and c3['envs_per_gpu'] == 131072 and c3['rccl_world_size'] == 2
+    assert c3['collective'] == 'allgather' and c3['gathered_return_checksum']['failed_steps'] > 0

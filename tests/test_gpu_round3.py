@@ -737,9 +737,18 @@ def test_graphed_pg_rollout_equals_eager():
     we, src_e = worker()
     for r, exploit in enumerate((False, False, True, True)):          # a change of `exploit` re-captures
         ng = rng.randint(3, size=B).astype(np.int32)
+        # the global NumPy stream: the reference draws np.random.rand() once per step (policy_gradient/rollout.py:196);
+        # capture (r = 0, 2) and replay (r = 1, 3) must both leave it where the eager rollout leaves it
+        np.random.seed(100 + r)
         epg = wg.generate_rollouts_graphed(exploit=exploit, num_grey=ng)
+        after_graphed = np.random.rand()
         src_e.t = 0
+        np.random.seed(100 + r)
         epe = we.generate_rollouts(exploit=exploit, num_grey=ng)
+        assert np.random.rand() == after_graphed
+        np.random.seed(100 + r)
+        np.random.rand(T)
+        assert np.random.rand() == after_graphed                       # = T draws of the reference's loop
         assert set(epg) == set(epe) and 'G' in epg and 'sigma' in epg
         for k in epe:
             assert epg[k].dtype == epe[k].dtype and epg[k].shape == epe[k].shape, k

@@ -329,3 +329,44 @@ def test_step_ok_words_are_allocated_on_first_use_only():
     assert 8 * B <= free1 - torch.cuda.mem_get_info()[0] < 8 * B + (8 << 20)
     del G
     bpg._lib.check(L.bpg_destroy(h))
+
+
+def test_compute_reward_precision_follows_numpys_promotion():
+    """bpg.compute_reward picks the arithmetic NumPy would use for `achieved_goal * goal` (fetch_env.py:141):
+    float32 x int8 / bool stays float32, float32 x int64 / float64 is float64 -- on rows built so that the two
+    precisions DISAGREE about `sum == count` -- and float64 rows longer than 159 entries raise instead of being
+    narrowed silently."""
+    rng = np.random.RandomState(5)
+    rows = []
+    g8 = np.array([3, 3, 3, 0, 0, 0, 0, 0], np.int8)       # three non-zero entries: count_nonzero(g) = 3
+    while len(rows) < 40:                                   # d == c in float32 arithmetic, d != c in float64 (or vice versa)
+        x = rng.rand(3).astype(np.float32)
+        x[2] = np.float32(1.0) - (x[0] + x[1])
+        ag = np.concatenate([x, rng.rand(5).astype(np.float32)])
+        d32 = np.sum(ag * g8.astype(np.float32))
+        d64 = np.sum(ag.astype(np.float64) * g8)
+        if (d32 == 3) != (d64 == 3):
+            rows.append(ag)
+    ag = np.stack(rows)
+    g = np.tile(g8.astype(np.int64), (len(rows), 1))
+    g[::3, 2] = 0                                           # some rows with another count: != in both precisions
+    def numpy_says(a, b):                                   # the reference's expression, NumPy's own promotion
+        d = np.sum(a * b, axis=-1)
+        c = np.count_nonzero(b, axis=-1)
+        return -(d != c).astype(np.float32)
+    seen = set()
+    for gdt in (np.int8, np.bool_, np.float32, np.int64, np.float64, np.int32):
+        for adt in (np.float32, np.float64):
+            a, b = ag.astype(adt), g.astype(gdt)
+            want = numpy_says(a, b)
+            got = bpg.compute_reward(a, b)
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg='%s x %s' % (adt, gdt))
+            gt = bpg.compute_reward(torch.as_tensor(a, device=DEV), torch.as_tensor(b, device=DEV))
+            np.testing.assert_array_equal(bits32(gt), want.view(np.uint32))
+            seen.add(want.tobytes())
+    assert len(seen) >= 2                                   # the two precisions really answered differently (bool goals: a third)
+    with pytest.raises(ValueError):
+        bpg.compute_reward(np.zeros((4, 160)), np.zeros((4, 160)))
+    assert bpg.compute_reward(np.zeros((4, 160), np.float32), np.zeros((4, 160), np.int8)).shape == (4,)
+    with pytest.raises(NotImplementedError):
+        bpg.compute_reward(np.zeros((2, 8), np.float16), np.zeros((2, 8), np.float16))

@@ -114,11 +114,15 @@ int main(int argc, char **argv)
         const int RC = T + 1, R = RC | 1;
         const size_t lds = (size_t)64 * R * sizeof(uint2) + sizeof(PairTable);
         CountArgs ca{};
+        TIME("k_episode<6, synth, NONTEMPORAL stores>, ag only, 2 waves per block", bytes,
+             hipLaunchKernelGGL((k_episode<6, SRC_SYNTH, true>), dim3((unsigned)nregions), dim3(128), lds, 0, now, ever,
+                                (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, reinterpret_cast<float *>(o),
+                                (float *)nullptr, (float *)nullptr, B, T, B, B, RC, R, c, s, tab, rc, ca, (uint64_t *)nullptr, (float *)nullptr));
         for (int waves : {1, 2}) {                  // the kernel's launch bound is 128 lanes
             snprintf(nm, 200, "k_episode<6, synth>, ag only, %d waves per block", waves);
             TIME(nm, bytes, hipLaunchKernelGGL((k_episode<6, SRC_SYNTH, false>), dim3((unsigned)nregions), dim3(64 * waves), lds, 0, now, ever,
                                                (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, reinterpret_cast<float *>(o),
-                                               (float *)nullptr, (float *)nullptr, B, T, B, B, RC, R, c, s, tab, rc, ca, (uint64_t *)nullptr));
+                                               (float *)nullptr, (float *)nullptr, B, T, B, B, RC, R, c, s, tab, rc, ca, (uint64_t *)nullptr, (float *)nullptr));
         }
     }
     return 0;

@@ -117,7 +117,7 @@ static PowTable mk_pw(int T) { PowTable p{}; for (int k = 0; k < T && k < 64; k+
         const double bytes = (double)B * (T * (4 + ((OUT & 1) ? 4 : 0) + ((OUT & 2) ? 1 : 0)) + 12 + (OKB ? 8 : 0)); \
         TIME(nm, bytes, hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, EPL, OUT, true, UNR, PIPE, true, LBV, (OKB != 0)>), dim3((unsigned)grid), \
                                     dim3(BLOCK), 0, 0, b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca,  \
-                                    OKB ? b.okbits : nullptr, 1));                                                \
+                                    OKB ? b.okbits : nullptr, 1, (uint32_t *)nullptr));                                                \
     } while (0)
 
 // The return kernels' traffic without their transposition: every lane widens float4 -> 4 doubles at the same linear
@@ -178,7 +178,7 @@ static int run(char mode, int64_t B)
         for (int rep = 0; rep < 2; rep++) {
             ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024);                       // round 2: reward + flags streams ...
             TIME("  + k_discounted_return_lane<50, exact>", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
             ROLL(2, 1024, 5, false, 2, 2, 1, 1, 1024);                       // flags + step-ok words ...
             ROLL(2, 1024, 5, false, 0, 2, 1, 1, 1024);                       // (G alone: no per-step stream at all)
             TIME("  + k_returns_from_okbits_lane<50>", gbytes,
@@ -192,11 +192,11 @@ static int run(char mode, int64_t B)
         for (int k = 0; k < b.NB; k++) { rot = k; ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); }
         for (int rep = 0; rep < 3; rep++) {
             TIME("k_discounted_return_lane<50, exact> (plain rewards)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
             TIME("k_discounted_return_lane<50, scan>", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
             TIME("k_discounted_return_lane<50, exact> (masks as floats: general path)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG, 1));
             TIME("k_returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),
                  hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), lg, lb, 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
             {   // the same bytes with no transposition (rows of the padded reward stream are read as one linear array)
@@ -210,9 +210,9 @@ static int run(char mode, int64_t B)
             do {                                                                                                                   \
                 const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
                 TIME("  waves/block " #W ": lane<50, exact>", rbytes,                                                              \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG)); \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1)); \
                 TIME("  waves/block " #W ": lane<50, scan>", rbytes,                                                               \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));  \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));  \
                 TIME("  waves/block " #W ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),                                 \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
@@ -220,9 +220,9 @@ static int run(char mode, int64_t B)
             do {                                                                                                                   \
                 const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
                 TIME("  waves/block " #W " tile rows " #TRR ": lane<50, exact>", rbytes,                                            \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG)); \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1)); \
                 TIME("  waves/block " #W " tile rows " #TRR ": lane<50, scan>", rbytes,                                             \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG));  \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));  \
                 TIME("  waves/block " #W " tile rows " #TRR ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),               \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W, TRR>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
@@ -292,7 +292,7 @@ static int run_skew(int64_t B)
             for (int k = 0; k < NSET; k++) {
                 CK(hipEventRecord(e0, 0));
                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
-                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (r >= 2) per_set[k] += ms / REPSE;
@@ -302,7 +302,7 @@ static int run_skew(int64_t B)
         for (int r = 0; r < 10; r++)
             for (int k = 0; k < NSET; k++)
                 hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false>), dim3(256), dim3(1024), 0, 0,
-                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
+                                   now, ever, M_[k], R_[k], F_[k], B, T, LD, LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float tot; CK(hipEventElapsedTime(&tot, e0, e1));
         double mn = 1e9, mx = 0, mean = 0;
@@ -345,7 +345,7 @@ static int run_timeline(int64_t B)
         rot++;
         CK(hipEventRecord(b.e0, 0));
         hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false, false>), dim3(grid), dim3(1024), 0, 0,
-                           b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1);
+                           b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
         CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));
         float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));
         CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
@@ -392,10 +392,10 @@ static int run_pg_split(int64_t B)
         const RolloutGeometry geo = rollout_geometry(n, b.LD, b.LD, M + off, nullptr, F + off);
         if (geo.epl == 2 && geo.block == 1024)
             hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 2, true, 5, false, true, 1024, true, false>), dim3(geo.grid), dim3(geo.block), 0, st,
-                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1);
+                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1, (uint32_t *)nullptr);
         else
             hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 2, true, 5, false, true, 256, true, false>), dim3(geo.grid), dim3(geo.block), 0, st,
-                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1);
+                               b.now + off, b.ever + off, M + off, (uint32_t *)nullptr, F + off, n, T, b.LD, b.LD, c, s, rc, ca, b.okbits + off, 1, (uint32_t *)nullptr);
     };
     auto expand = [&](hipStream_t st, int64_t off, int64_t n) {
         hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), dim3((unsigned)((n + 64 * WPB - 1) / (64 * WPB))), dim3(64 * WPB), 0, st, pw,
