@@ -341,6 +341,24 @@ template <bool NT, typename V> __device__ __forceinline__ void st_1(V *p, V v)
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+template <bool NT> __device__ __forceinline__ void st_d2(double2 *p, double2 v)
+{
+    if (NT) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); }
+    else *p = v;
+}
+// Write-once outputs of the ONE-SHOT kernels (a step, an observation assembly, a float view, the G rows: every wave
+// loads, computes, stores once and ends): nontemporal.  A plain store allocates in the L2 and is written back when the
+// kernel ends, behind its last wave and before the next launch of the stream may start (MI355X_MICROARCH.md
+// "boundary": + B / 6 TB/s for B dirty bytes); a nontemporal one streams out while the kernel runs.  Measured on the step
+// launch (tools/tune_round4.hip, profiles/r04_tune_step_train.log) and per kernel with -DBPG_OUT_NT=0 against the
+// default on the same box (tools/ab_output_stores.py, profiles/r04_ab_output_stores.log).  The multi-GB episode writer
+// and the reset's observation rows are the exceptions (plain stores: profiles/r04_tune_episode_nontemporal.log; reset
+// + rows 8.4 us plain against 9.6 us at 65 536 envs), and so is everything a later step of the same launch train re-reads
+// (the packed state, contact masks).
+#ifndef BPG_OUT_NT
+#define BPG_OUT_NT 1
+#endif
+constexpr bool OUT_NT = (BPG_OUT_NT != 0);
 
 // envs-per-lane vector types of the streaming kernels
 template <int EPL> struct LaneVec;
@@ -492,7 +510,7 @@ k_reset(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, int64_t n, Rese
                     v[c] = s_tmpl[s_nblocks[e] * so.dimo + k];
                     if (++k == so.dimo) { k = 0; e++; }
                 }
-                reinterpret_cast<float4 *>(o)[q] = make_float4(v[0], v[1], v[2], v[3]);
+                reinterpret_cast<float4 *>(o)[q] = make_float4(v[0], v[1], v[2], v[3]);   // plain: nontemporal measured +14 % at 65 536 envs
             }
             for (int f = 4 * nq + threadIdx.x; f < total; f += 256) {
                 const int e = f / so.dimo;
@@ -563,6 +581,9 @@ k_step_vec4(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint3
             const uint32_t mk = fetch_mask<SRC>(mm[k], an[k], ee[k], (uint32_t)(4 * v + k), s);
             step_core(an[k], ee[k], mk, c, rb[k], fl[k]);
         }
+        // (the state stays a plain store: nontemporal state stores change nothing here -- 5.1-5.4 us per 1 M-env launch
+        // with the state cache-resident, 5.9-6.1 us HBM-cold, either way: the launch is its fixed cost, a load and a
+        // store round trip between two launch boundaries; profiles/r04_ab_output_stores.log)
         reinterpret_cast<uint4 *>(now)[v] = make_uint4(an[0], an[1], an[2], an[3]);
         reinterpret_cast<uint4 *>(ever)[v] = make_uint4(ee[0], ee[1], ee[2], ee[3]);
         // write-once streams: nontemporal, so that they do not push the state (re-read by the next
@@ -889,9 +910,9 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
         if constexpr (PAIRS) {
             const double2 *t2 = reinterpret_cast<const double2 *>(tile);
             double2 *o2 = reinterpret_cast<double2 *>(o);                // first * TT * 8 bytes: 16-byte aligned
-            for (int f = lane; f < rows * (TT / 2); f += 64) o2[f] = t2[f];
+            for (int f = lane; f < rows * (TT / 2); f += 64) st_d2<OUT_NT>(&o2[f], t2[f]);
         } else {
-            for (int f = lane; f < rows * TT; f += 64) o[f] = tile[f];
+            for (int f = lane; f < rows * TT; f += 64) st_1<OUT_NT>(&o[f], tile[f]);
         }
     }
 }
@@ -1099,6 +1120,8 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             ee[k] = ev[k] | (lat[k] & SUCC_BIT);
             nsucc += lat[k] & 1u;
         }
+        // (plain stores: nontemporal state stores were measured 0.8 us SLOWER per 1 M-env launch, 84.8 against 84.0 us
+        // on one box, profiles/r04_ab_state_stores.log -- the 8 MB a launch leaves dirty are not what the boundary costs)
         reinterpret_cast<Vec *>(now)[v] = pack<EPL>(an);
         reinterpret_cast<Vec *>(ever)[v] = pack<EPL>(ee);
         if constexpr (OKB) {
@@ -1232,13 +1255,13 @@ k_get_ag(const uint32_t *__restrict__ now, const uint32_t *__restrict__ ever, in
             v.y = tern(h.x, h.y, (pw >> 5) & 31u);
             v.z = tern(h.x, h.y, (pw >> 10) & 31u);
             v.w = tern(h.x, h.y, (pw >> 15) & 31u);
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + e * ld + 4 * q) = v;
+            st_f4<OUT_NT>(reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + e * ld + 4 * q), v);
         }
     } else {
         for (int f = lane; f < nvalid * DIMG; f += 64) {
             const int e = f / DIMG, k = f - e * DIMG;
             const uint2 h = hist[e];
-            o[e * ld + k] = (OutT)tern(h.x, h.y, tab.flat[k]);
+            st_1<OUT_NT>(&o[e * ld + k], (OutT)tern(h.x, h.y, tab.flat[k]));
         }
     }
 }
@@ -1495,10 +1518,10 @@ k_assemble_obs(const uint32_t *__restrict__ ever, int64_t n, bpg_phys_state ph, 
     if (ld == dimo) {
         OutT *o = out + base * dimo;
         const int total = nvalid * dimo;
-        for (int f = lane; f < total; f += 64) o[f] = tile[f];
+        for (int f = lane; f < total; f += 64) st_1<OUT_NT>(&o[f], tile[f]);
     } else {
         for (int e = 0; e < nvalid; e++)
-            for (int k = lane; k < dimo; k += 64) out[(base + e) * ld + k] = tile[e * dimo + k];
+            for (int k = lane; k < dimo; k += 64) st_1<OUT_NT>(&out[(base + e) * ld + k], tile[e * dimo + k]);
     }
 }
 
@@ -1529,7 +1552,7 @@ k_set_action(const float *__restrict__ action, int64_t n, int block_gripper, dou
         }
         __syncthreads();
         double *o = out + base * 9;
-        for (int f = threadIdx.x; f < nvalid * 9; f += 256) o[f] = tile[f];
+        for (int f = threadIdx.x; f < nvalid * 9; f += 256) st_1<OUT_NT>(&o[f], tile[f]);
         __syncthreads();
     }
 }
@@ -2504,7 +2527,7 @@ k_fill_goal(float *__restrict__ out, int64_t total, int dimg, int64_t ld, PairTa
     for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += stride) {
         const int64_t e = f / dimg;
         const int k = (int)(f - e * dimg);
-        out[e * ld + k] = tab.goal[k];
+        st_1<OUT_NT>(&out[e * ld + k], tab.goal[k]);
     }
 }
 
