@@ -746,14 +746,21 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
 
     # (1a) the rollout worker's step: step + float32 achieved_goal row + float32 is_success in one launch:
     # 12 B in, 13 + 4 + 144 B out = 173 B/env-step
-    agrec = torch.empty((B, env.dimg), dtype=torch.float32, device=dev)
-    succ_f = torch.empty(B, dtype=torch.float32, device=dev)
+    # The worker writes the rows of step t into time slot t+1 of the episode's (T+1, B, dimg) slab: a different 151 MB
+    # every step.  (Rounds 1-3 timed this launch rewriting ONE (B, dimg) array, whose lines then never leave the
+    # Infinity Cache; with the nontemporal stores of round 4 the rows go to HBM either way.)
+    agrec = torch.empty((T + 1, B, env.dimg), dtype=torch.float32, device=dev)
+    succ_f = torch.empty((T, B), dtype=torch.float32, device=dev)
+    sr_it = [0]
 
     def step_record():
-        _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks.data_ptr()), C.c_void_p(reward.data_ptr()),
-                                     C.c_void_p(flags.data_ptr()), C.c_void_p(succ_f.data_ptr()),
-                                     C.c_void_p(agrec.data_ptr()), env.dimg, None, None, None, stream))
-    res['step_record_single_launch'] = line(timed(step_record, 100), (29 + 4 * env.dimg) * B, B)
+        t = sr_it[0] % T
+        sr_it[0] += 1
+        _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks[t].data_ptr()), C.c_void_p(reward[t].data_ptr()),
+                                     C.c_void_p(flags[t].data_ptr()), C.c_void_p(succ_f[t].data_ptr()),
+                                     C.c_void_p(agrec[t + 1].data_ptr()), env.dimg, None, None, None, stream))
+    res['step_record_single_launch'] = line(timed(step_record, 2 * T), (29 + 4 * env.dimg) * B, B)
+    res['step_record_single_launch']['note'] = 'rows into rotating time slots of a (T+1, B, dimg) slab, as the worker writes them'
     del agrec, succ_f
 
     # (1b) one env.step launch with the contacts as the reference reads them: geom-id pair lists
@@ -1019,13 +1026,32 @@ def policy_in_loop(torch, bpg, Bx, T, dev):
                                dict(o=dimo, u=4, g=dimg, info_is_success=1), None, T, rollout_batch_size=Bx)
         for mode, fn in (('eager', w.generate_rollouts), ('hipgraph', w.generate_rollouts_graphed)):
             fn()
+            fn()                                     # both episode slabs the worker alternates between exist now
             torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize(dev)
-            ms = (time.perf_counter() - t0) / reps * 1e3
-            out['%s_%s' % (name, mode)] = {'ms': ms, 'env_steps_per_sec': Bx * T / (ms * 1e-3)}
+            each = []
+            for _ in range(reps + 2):                # per rollout, median: memory the process released earlier
+                t0 = time.perf_counter()             # (torch.cuda.empty_cache) is reclaimed by the driver in the
+                fn()                                 # background and stalls a launch for tens of ms now and then
+                torch.cuda.synchronize(dev)
+                each.append((time.perf_counter() - t0) * 1e3)
+            ms = sorted(each)[len(each) // 2]
+            out['%s_%s' % (name, mode)] = {'ms': ms, 'env_steps_per_sec': Bx * T / (ms * 1e-3), 'ms_min': min(each),
+                                           'ms_max': max(each)}
+            if mode == 'hipgraph':
+                # the replayed graph alone (reset + T x (policy, step launch)), HIP events around a train of replays: the
+                # figure above also holds the host's part of a rollout (graph launch, reading the success count back)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                nrep = 10 * reps
+                e0.record()
+                for _ in range(nrep):
+                    w._graph.replay()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                w._resync_success_total()
+                gms = e0.elapsed_time(e1) / nrep
+                nbytes = Bx * T * (12 + 13 + 4 + 4 * dimg + 16)
+                out['%s_%s' % (name, mode)].update(graph_only_ms=gms, graph_only_us_per_step=gms * 1e3 / T,
+                                                   graph_only_env_side_frac_hbm_peak=nbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         del w
         torch.cuda.empty_cache()
     return out

@@ -161,14 +161,16 @@ class RolloutStudent:
             return ts
         return tuple(t.cpu().numpy() for t in ts)
 
-    def _alloc_episode(self, time_major=False, o=True, g=True):
+    def _alloc_episode(self, time_major=False, o=True, g=True, zero_u=True):
         """Episode buffers.  time_major=True allocates (T[+1], B, .) and the caller returns
         transposed views -- exactly what the reference hands out: convert_episode_to_batch_major
-        (util.py:118-128) is a swapaxes(0, 1) VIEW of the time-major arrays."""
+        (util.py:118-128) is a swapaxes(0, 1) VIEW of the time-major arrays.
+        zero_u=False: every action slot is written by the rollout (the step launch stores u, or the body assigns it), so
+        the fill launch -- 52 MB at 65 536 envs, a node of every replayed graph -- is skipped."""
         B, T, d = self.rollout_batch_size, self.T, self.dims
         f32 = dict(dtype=torch.float32, device=self.device)
         shp = (lambda n, k: (n, B, k)) if time_major else (lambda n, k: (B, n, k))
-        ep = dict(u=torch.zeros(shp(T, d['u']), **f32), ag=torch.empty(shp(T + 1, d['g']), **f32),
+        ep = dict(u=(torch.zeros if zero_u else torch.empty)(shp(T, d['u']), **f32), ag=torch.empty(shp(T + 1, d['g']), **f32),
                   info_is_success=torch.empty(shp(T, 1), **f32))
         if o:
             ep['o'] = torch.empty(shp(T + 1, d['o']), **f32)
@@ -285,7 +287,7 @@ class RolloutStudent:
         # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
         # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
         # the next achieved_goal straight into slot t+1
-        ep = self._alloc_episode(time_major=True, g=False, o=False)
+        ep = self._alloc_episode(time_major=True, g=False, o=False, zero_u=False)
         ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])   # slot 0 = initial_ag (rollout.py:82-83)
         Qs = []
         for t in range(T):
@@ -603,7 +605,7 @@ class PGRolloutStudent(RolloutStudent):
     def _pg_body(self, test, exploit, num_grey):
         env, B, T = self.env, self.rollout_batch_size, self.T
         beta = self.beta() if self.expert is not None else 0
-        ep = self._alloc_episode(time_major=True, g=False, o=False)
+        ep = self._alloc_episode(time_major=True, g=False, o=False, zero_u=False)
         ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])
         # "We can't report sigma accurately when we are using the expert": np.zeros((B, dimu)), float64 (:207-209)
         ep['sigma'] = torch.zeros((T, B, self.dims['u']), device=self.device,

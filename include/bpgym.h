@@ -29,6 +29,16 @@
  *   pair index of (i,j), i<=j<6:  i*6 - i*(i-1)/2 + (j-i)   (bpg_pair_index)
  * flags byte written per env-step: bit0 = info['is_success'], bit1 = done,
  * bit2 = the step's reward is -0.0f (success condition holds this step).
+ *
+ * What is NOT the reference's own code behind these entry points (third-party behaviour, absent from the reference
+ * tree and not installable here: restated, and "parity unpinned" -- pinned only to the test harness's stand-ins):
+ *   `done` (flags bit1, the elapsed counter): gym's TimeLimit wrapper, which the reference gets from
+ *       register(max_episode_steps=50) (gym_blocks/__init__.py:6-53) -- restated as done = elapsed_steps >= max_episode_steps,
+ *       counter reset by reset(), saturating at 1023;
+ *   bpg_mat2euler_f64: gym.envs.robotics.rotations.mat2euler;
+ *   the random streams behind bpg_seed / generator-drawn num_grey and placements: gym's seeding (SHA-512 -> MT19937) is
+ *       replaced by a counter-based generator; only the seed ARITHMETIC (seed + 1000 * idx, rollout.py:209-210) is mirrored.
+ * Outside SURVEY.md section 8 (imitation-learning glue of the pg worker, kept from round 3, frozen): bpg_trim_expert_inputs.
  */
 #ifndef BPGYM_H
 #define BPGYM_H
@@ -96,7 +106,11 @@ int bpg_version(void);
 int bpg_variant_from_id(const char *env_id);
 int bpg_get_variant_info(int variant, bpg_variant_info *out);
 
-/* BlocksEnv._geom2objid (fetch_env.py:106-117): geom name -> object id, -1 = None. */
+/* BlocksEnv._geom2objid (fetch_env.py:106-117): geom name -> object id, -1 = None (NULL or unnamed geom).
+ * Names the reference's `int(name[6:])` would raise ValueError on -- "object" with nothing or a non-digit behind the
+ * first six characters, e.g. "object", "myobject3", "objectA" -- cannot occur in the shipped XML models; here the leading
+ * decimal digits behind position 6 are read as C's strtol does and a missing number counts as 0 (-> object id 2)
+ * instead of raising. */
 int bpg_geom2objid(const char *name);
 /* pair index used by every packed mask. */
 int bpg_pair_index(int i, int j);
@@ -291,7 +305,9 @@ int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever,
                               uint32_t want_touch, uint32_t want_never, int64_t n,
                               float *d_out, int device_id, void *stream);
 
-/* RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171, batched branch): the inputs
+/* OUTSIDE SURVEY.md section 8 (section 2 #6 marks expert mixing / trim "imitation-learning glue"): built in round 3, pinned
+ * by fixtures, frozen since.
+ * RolloutStudent.trim of the policy-gradient worker (policy_gradient/rollout.py:105-171, batched branch): the inputs
  * of an expert trained on a smaller puzzle (`self.expert.get_actions(o_, ag_, g_, compute_raw=True)`, :196-200).
  *   d_o (n, dimo_in), d_g / d_ag (n, dimg_in) float32 rows, contiguous.
  *   d_g_out / d_ag_out (n, dimg_out) float32: entries (i, j), i, j < num_objs, of the sqrt(dimg_in)-sided matrices (:139-151);

@@ -6,6 +6,7 @@ rocprofv3 (kernel trace or one --pmc counter set per invocation):
     rocprofv3 --pmc FETCH_SIZE -d out -- python3 tools/prof_kernels.py return
 
 kernels: rollout (fused, masks, 1 M envs), rollout64k / rollout128k / rollout256k / rollout512k (the other launch shapes),
+rolloutret / rolloutret512k (the same with the per-env episode return, bpg_rollout_args.d_episode_return),
 rollout4m (4 M envs, rows a power of two apart), synth (fused, in-kernel contacts), pg (rollout + the policy-gradient
 return from the step-ok words, one call), step (13 batches round-robin), record, return, scan, episode, reward,
 assemble (+ set_action, placement), nan, reset
@@ -28,7 +29,7 @@ P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 TM = lambda B, dtype: bpg.time_major_empty(T, B, dtype, DEV)   # noqa: E731  (T, B) stream, rows bpg_row_stride(B) apart
 
 
-def rollout(B, reps, synth=False, contiguous=False, pg=False):
+def rollout(B, reps, synth=False, contiguous=False, pg=False, ret=False):
     env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
     ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 7) % 3
     env.reset(num_grey=ng)
@@ -42,13 +43,15 @@ def rollout(B, reps, synth=False, contiguous=False, pg=False):
         sets.append((m, None if pg else tm(torch.float32), tm(torch.uint8),
                      torch.empty((B, T), dtype=torch.float64, device=DEV) if pg else None))
     cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
+    er = torch.empty(B, dtype=torch.float32, device=DEV) if ret else None      # bpg_rollout_args.d_episode_return
     for i in range(reps):
         m, r, f, G = sets[i % len(sets)]
         a = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=None if synth else ng.data_ptr(), ld_masks=m.stride(0),
                              ld_out=f.stride(0),
                              d_masks=None if synth else m.data_ptr(), d_reward_tb=None if r is None else r.data_ptr(),
                              d_flags_tb=f.data_ptr(), d_success_count=None if synth else cnt.data_ptr(),
-                             d_G=None if G is None else G.data_ptr(), gamma=0.98)
+                             d_G=None if G is None else G.data_ptr(), gamma=0.98,
+                             d_episode_return=None if er is None else er.data_ptr())
         _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
     torch.cuda.synchronize()
 
@@ -109,6 +112,10 @@ def main():
             rollout(524288, 20)
         elif w == 'rollout4m':
             rollout(4194304, 8, contiguous=True)
+        elif w == 'rolloutret':
+            rollout(B, 20, ret=True)
+        elif w == 'rolloutret512k':
+            rollout(524288, 20, ret=True)
         elif w == 'multi64k':
             multi(65536, 10, 30)
         elif w == 'multi1m':

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Prints the markdown table of profiles/README.md from profiles/<round>_pmc/kernel_means.json and
-traffic_all_kernels.json (tools/publish_profiles.sh writes both):  python tools/profile_table.py [r03]"""
+traffic_all_kernels.json (tools/publish_profiles.sh writes both):  python tools/profile_table.py [r04]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 ROWS = [
     ('k_rollout_masks_bench', '`k_rollout<masks>` (headline, 2/lane × 1024), as `bench.py` issues it', 'reset + 50 steps + success count, 1 M envs'),
     ('k_rollout_masks', 'same, from `prof_kernels.py` (its own process and buffers)', ''),
+    ('k_rollout_masks_with_episode_return', 'same + the per-env episode return (`d_episode_return`, 4 B/env)', ''),
     ('k_rollout_masks_524288', 'same, 524 288 envs', ''),
+    ('k_rollout_masks_524288_with_episode_return', 'same, 524 288 envs + the episode return (configs[3] per GPU)', ''),
     ('k_rollout_masks_262144', 'same, 262 144 envs (2/lane × 256)', ''),
     ('k_rollout_masks_131072', 'same, 131 072 envs (1/lane, 5 rows in flight)', ''),
     ('k_rollout_masks_65536', 'same, 65 536 envs (1/lane, 10 rows in flight)', ''),

@@ -44,9 +44,15 @@ def roll(n):
     return n * (4 * T + 4), n * (5 * T + 8)
 
 
-# template arguments: <SRC, NT, EPL, OUT, RESET, UNROLL, PIPE, NTL, LB, OKB, MULTI>
-FAT = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, false>'
-MID = 'k_rollout<0, true, 2, 3, true, 5, false, true, 256, false, false>'
+# template arguments: <SRC, NT, EPL, OUT, RESET, UNROLL, PIPE, NTL, LB, OKB, MULTI, RET>
+FAT = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, false, false>'
+FAT_RET = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, false, true>'      # + the per-env episode return
+MID = 'k_rollout<0, true, 2, 3, true, 5, false, true, 256, false, false, false>'
+
+
+def roll_ret(n):
+    r, w = roll(n)
+    return r, w + 4 * n
 K_MULTI = 10        # rollouts per launch in tools/prof_kernels.py multi64k / multi1m
 
 
@@ -59,12 +65,14 @@ def roll_k(n):
 KERNELS = [
     (FAT, 256 * 1024, 'k_rollout_masks', 'read8') + roll(B) + ('',),
     (FAT, 256 * 1024, 'k_rollout_masks_524288', 'read8') + roll(524288) + ('2',),
+    (FAT_RET, 256 * 1024, 'k_rollout_masks_with_episode_return', 'read8') + roll_ret(B) + ('',),
+    (FAT_RET, 256 * 1024, 'k_rollout_masks_524288_with_episode_return', 'read8') + roll_ret(524288) + ('2',),
     (MID, 262144 // 2, 'k_rollout_masks_262144', 'read8') + roll(262144) + ('',),
     (MID, 1024 * 256, 'k_rollout_masks_4194304_aliased_rows', 'read8') + roll(4194304) + ('2',),
-    ('k_rollout<0, true, 1, 3, true, 5, true, true, 256, false, false>', 131072, 'k_rollout_masks_131072', 'read4') + roll(131072) + ('',),
-    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, false>', 65536, 'k_rollout_masks_65536', 'read4') + roll(65536) + ('',),
-    ('k_rollout<1, true, 2, 3, true, 10, false, true, 256, false, false>', None, 'k_rollout_synth', 'read8', 0, B * (5 * T + 8), ''),
-    ('k_rollout<0, true, 2, 2, true, 5, false, true, 1024, true, false>', None, 'k_rollout_masks_flags_okbits', 'read8',
+    ('k_rollout<0, true, 1, 3, true, 5, true, true, 256, false, false, false>', 131072, 'k_rollout_masks_131072', 'read4') + roll(131072) + ('',),
+    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, false, false>', 65536, 'k_rollout_masks_65536', 'read4') + roll(65536) + ('',),
+    ('k_rollout<1, true, 2, 3, true, 10, false, true, 256, false, false, false>', None, 'k_rollout_synth', 'read8', 0, B * (5 * T + 8), ''),
+    ('k_rollout<0, true, 2, 2, true, 5, false, true, 1024, true, false, false>', None, 'k_rollout_masks_flags_okbits', 'read8',
      B * (4 * T + 4), B * (T + 8 + 8), ''),
     ('k_returns_from_okbits_lane<50', None, 'k_returns_from_okbits_lane50', 'read8', 8 * B, 8 * T * B, ''),
     ('k_step_vec4<0>', None, 'k_step_vec4_masks', 'read16', 12 * B, 13 * B, ''),
@@ -78,8 +86,8 @@ KERNELS = [
     ('k_set_action', None, 'k_set_action', 'read16', 16 * B, 72 * B, ''),
     ('k_nan_flag<true>', None, 'k_nan_flag', 'read16', B * 4 * 87, 0, ''),
     ('k_trim<true>', None, 'k_trim_variation', 'read16', B * 4 * (87 + 2 * 36), B * (8 * 40 + 2 * 4 * 16), ''),
-    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, true>', 65536, 'k_rollout_masks_65536_x10', 'read4') + roll_k(65536) + ('',),
-    ('k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, true>', 256 * 1024, 'k_rollout_masks_x10', 'read8') + roll_k(B) + ('2',),
+    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, true, false>', 65536, 'k_rollout_masks_65536_x10', 'read4') + roll_k(65536) + ('',),
+    ('k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, true, false>', 256 * 1024, 'k_rollout_masks_x10', 'read8') + roll_k(B) + ('2',),
 ]
 
 
@@ -146,7 +154,7 @@ def main():
     json.dump(res, open(os.path.join(dst, 'traffic_all_kernels.json'), 'w'), indent=1)
     head = res.get('k_rollout_masks_bench') or res.get('k_rollout_masks')
     if head:
-        json.dump({'k_rollout_masks': dict(head, envs=B, T=T,
+        json.dump({'k_rollout_masks': dict(head, envs=B, T=T, source=os.path.join(dst, 'traffic_all_kernels.json'),
                                             method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; '
                                                    'FETCH_SIZE scaled by the factor an 8-B-per-lane read stream of known '
                                                    'size shows in the same session (calibration.json beside this file)',
