@@ -945,9 +945,12 @@ __device__ unsigned long long *bpg_timeline = nullptr;
 #else
 #define BPG_TL(slot) do { } while (0)
 #endif
+#ifndef BPG_ROLLOUT_MINB
+#define BPG_ROLLOUT_MINB 1      // blocks per CU the register budget is sized for (an experiment of tools/tune_round3 only: see DESIGN.md section 4)
+#endif
 template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
           bool MULTI = false, bool RET = false>
-__global__ void __launch_bounds__(LB)
+__global__ void __launch_bounds__(LB, BPG_ROLLOUT_MINB)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks_all,
           uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,

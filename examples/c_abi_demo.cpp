@@ -121,13 +121,21 @@ int main()
     double *d_G; HIP(hipMalloc(&d_G, (size_t)B * T * 8));
     const double gamma = 1.0 - 1.0 / T;
     ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
-    ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_G = d_G; ra.gamma = gamma;
+    // ... and every env's undiscounted episode return r[0] + ... + r[T-1] (what a multi-GPU job all-gathers, 4 bytes per
+    // env) from the same launch: d_episode_return
+    float *d_ret; HIP(hipMalloc(&d_ret, (size_t)B * 4));
+    ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_G = d_G; ra.gamma = gamma; ra.d_episode_return = d_ret;
     CHECK(bpg_rollout(h, &ra, nullptr));
     HIP(hipDeviceSynchronize());
     std::vector<double> G((size_t)B * T), ref(T);
+    std::vector<float> ret((size_t)B);
     HIP(hipMemcpy(G.data(), d_G, G.size() * 8, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(ret.data(), d_ret, ret.size() * 4, hipMemcpyDeviceToHost));
     int bad3 = 0;
     for (int64_t b = 0; b < B; b++) {
+        float acc = r0[(size_t)b];                                               // starts from r[0]: -0.0f stays -0.0f
+        for (int t = 1; t < T; t++) acc = acc + r0[(size_t)t * B + b];
+        bad3 += std::memcmp(&acc, &ret[(size_t)b], 4) != 0;
         for (int t = 0; t < T; t++) {
             const double r = (double)r0[(size_t)t * B + b];
             ref[t] = r;
@@ -138,7 +146,7 @@ int main()
         }
         bad3 += std::memcmp(ref.data(), &G[(size_t)b * T], (size_t)T * 8) != 0;
     }
-    std::printf("policy-gradient return from the rollout call: %d of %lld rows differ from the reference loop\n", bad3, (long long)B);
+    std::printf("policy-gradient return and episode return from the rollout call: %d of %lld rows differ from the reference loops\n", bad3, (long long)B);
 
     // The evaluator's test loop (train.py:62-64: n_test_rollouts consecutive generate_rollouts calls, only the success
     // rates kept) as ONE launch: rollouts = K, masks of all K rollouts in one (K*T, n) stream, one counter word each.
