@@ -983,6 +983,7 @@ def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1, ep
 
 
 def policy_in_loop(torch, bpg, Bx, T, dev):
+    import numpy as np
     """RolloutStudent.generate_rollouts with a device-resident policy between the env steps
     (rollout.py:75-172): eager (one step launch + policy per t) vs the whole loop replayed from a
     hipGraph.  Two policies: a trivial one (isolates the env side: step kernel writing straight
@@ -1053,6 +1054,27 @@ def policy_in_loop(torch, bpg, Bx, T, dev):
                 out['%s_%s' % (name, mode)].update(graph_only_ms=gms, graph_only_us_per_step=gms * 1e3 / T,
                                                    graph_only_env_side_frac_hbm_peak=nbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         del w
+        if name == 'trivial_policy':
+            # the same replayed rollouts from a worker that never reads the success count back inside generate_rollouts
+            # (async_stats: success_history resolves its entries when they are read -- once per epoch in the reference's
+            # loop, train.py:67-76): 20 rollouts back to back, ONE synchronisation at the end
+            wa = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=dev), pol,
+                                    dict(o=dimo, u=4, g=dimg, info_is_success=1), None, T, rollout_batch_size=Bx, async_stats=True)
+            for _ in range(3):
+                wa.generate_rollouts_graphed()
+            torch.cuda.synchronize(dev)
+            nroll = 20
+            t0 = time.perf_counter()
+            for _ in range(nroll):
+                wa.generate_rollouts_graphed()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / nroll * 1e3
+            rate = float(np.mean(wa.success_history))
+            out['trivial_policy_hipgraph_async_stats'] = {
+                'ms': ms, 'env_steps_per_sec': Bx * T / (ms * 1e-3), 'rollouts_back_to_back': nroll,
+                'env_side_frac_hbm_peak': Bx * T * (12 + 13 + 4 + 4 * dimg + 16) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'mean_success_rate_read_afterwards': rate}
+            del wa
         torch.cuda.empty_cache()
     return out
 

@@ -80,17 +80,89 @@ def discounted_return_scan(reward_tb, gamma, out=None):
     return out
 
 
+class _TotalSnapshot:
+    """The worker's running total of successful envs as it stands behind everything enqueued so far, copied to pinned host
+    memory asynchronously; value() waits for that copy only."""
+
+    def __init__(self, total_dev, slot):
+        slot.copy_(total_dev, non_blocking=True)
+        self._slot, self._event, self._value = slot, torch.cuda.Event(), None
+        self._event.record(torch.cuda.current_stream(total_dev.device))
+
+    def value(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = int(self._slot[0])
+            self._slot = self._event = None
+        return self._value
+
+
+class _LazyRate:
+    """success_rate of one rollout = (total after it - total before it) / B, resolved when somebody looks at it."""
+
+    def __init__(self, before, after, batch):
+        self._before, self._after, self._batch, self._rate = before, after, batch, None
+
+    def __float__(self):
+        if self._rate is None:
+            b = self._before if isinstance(self._before, int) else self._before.value()
+            self._rate = float(self._after.value() - b) / self._batch
+            self._before = self._after = None
+        return self._rate
+
+
+class _History(deque):
+    """success_history: a deque of floats to every reader (rollout.py:37, :174-184 read it with np.mean); entries appended
+    by an async_stats worker are resolved the first time they are read."""
+
+    def _settle(self):
+        for i in range(len(self)):
+            x = deque.__getitem__(self, i)
+            if isinstance(x, _LazyRate):
+                deque.__setitem__(self, i, float(x))
+
+    def __iter__(self):
+        self._settle()
+        return deque.__iter__(self)
+
+    def __getitem__(self, i):
+        x = deque.__getitem__(self, i)
+        if isinstance(x, _LazyRate):
+            x = float(x)
+            deque.__setitem__(self, i, x)
+        return x
+
+    def __reversed__(self):
+        self._settle()
+        return deque.__reversed__(self)
+
+    def __repr__(self):
+        self._settle()
+        return deque.__repr__(self)
+
+    def __eq__(self, other):
+        self._settle()
+        return list(deque.__iter__(self)) == list(other)
+
+    __hash__ = None
+
+
 class RolloutStudent:
 
     def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1,
                  exploit=False, use_target_net=False, compute_Q=False, noise_eps=0,
-                 random_eps=0, history_len=100, render=False, output=None, **kwargs):
+                 random_eps=0, history_len=100, render=False, output=None, async_stats=False, **kwargs):
         """Same arguments as the reference (rollout.py:11-14).  `make_env` may
         return a batched env directly (called as make_env(num_envs=B) when it
         accepts that) or a single env, which is re-created with B envs.
         Zero-copy note: the env writes observations / achieved goals straight into the episode a
         rollout returns, so until the next reset `env.observation` IS the last observation slot of
-        the most recent episode (stepping the env by hand in between writes into that episode)."""
+        the most recent episode (stepping the env by hand in between writes into that episode).
+        async_stats=True (build-defined; for device-resident pipelines): generating a rollout never waits for the GPU --
+        the success count of a rollout (rollout.py:163-167) is copied to pinned host memory behind the rollout's
+        launches and `success_history` resolves the entry the first time it is read (np.mean, logs, indexing), as the
+        reference's callers do once per epoch (train.py:67-76).  Default False: a float is appended before
+        generate_rollouts returns, as in the reference."""
         self.make_env, self.policy, self.dims, self.logger, self.T = make_env, policy, dims, logger, T
         self.rollout_batch_size = rollout_batch_size
         self.exploit, self.use_target_net, self.compute_Q = exploit, use_target_net, compute_Q
@@ -109,7 +181,8 @@ class RolloutStudent:
         self.device = env.device
         self.output = output or ('torch' if getattr(policy, 'device_tensors', False) else 'numpy')
         self.info_keys = [key.replace('info_', '') for key in dims.keys() if key.startswith('info_')]
-        self.success_history = deque(maxlen=history_len)
+        self.success_history = _History(maxlen=history_len)
+        self.async_stats = bool(async_stats)
         self.Q_history = deque(maxlen=history_len)
         self.n_episodes = 0
         self._watch_o, self._nan_flag = False, None
@@ -118,7 +191,9 @@ class RolloutStudent:
         # its own for `successful = successes[-1]` (rollout.py:163-167), nothing to zero between rollouts (hipGraph
         # replays included)
         self._succ_total = torch.zeros(1, dtype=torch.int64, device=env.device)
-        self._succ_seen = 0
+        self._succ_seen = 0                  # the total before the next rollout: an int, or a _TotalSnapshot not read yet
+        self._pinned = torch.empty(max(2 * history_len, 64), dtype=torch.int64).pin_memory() if self.async_stats else None
+        self._pinned_next = 0
         f32 = dict(dtype=torch.float32, device=self.device)
         self.g = torch.empty((B, dims['g']), **f32)
         self.initial_o = torch.empty((B, dims['o']), **f32)
@@ -187,12 +262,24 @@ class RolloutStudent:
         # column of info_is_success is the has_succeeded latch of the state the rollout ended in, so
         # the mean is the HIP success count over B (exact in float64, as NumPy's mean of 0/1 values).
         # counted: the rollout's launches added that count to the worker's running total themselves
-        if counted:
-            total = int(self._succ_total.item())
-            successes, self._succ_seen = total - self._succ_seen, total
+        if counted and self.async_stats:
+            n = self._pinned.numel()
+            if self._pinned_next >= n and self._pinned_next % n == 0:
+                self.success_history._settle()           # the ring of pinned slots wraps: everything older is read by now
+                if not isinstance(self._succ_seen, int):
+                    self._succ_seen = self._succ_seen.value()
+            snap = _TotalSnapshot(self._succ_total, self._pinned[self._pinned_next % n:self._pinned_next % n + 1])
+            self._pinned_next += 1
+            success_rate = _LazyRate(self._succ_seen, snap, self.rollout_batch_size)
+            self._succ_seen = snap
         else:
-            successes = int(self.env.success_count().item())
-        success_rate = float(successes) / self.rollout_batch_size
+            if counted:
+                total = int(self._succ_total.item())
+                before = self._succ_seen if isinstance(self._succ_seen, int) else self._succ_seen.value()
+                successes, self._succ_seen = total - before, total
+            else:
+                successes = int(self.env.success_count().item())
+            success_rate = float(successes) / self.rollout_batch_size
         self.success_history.append(success_rate)
         if self.compute_Q and len(Qs):
             # rollout.py:168-169 `self.Q_history.append(np.mean(Qs))`: NumPy's mean over the stacked per-step arrays, in

@@ -243,3 +243,32 @@ def test_every_entry_point_is_exercised_somewhere():
             if not re.search(r'\b%s\b' % n, tests) and len(re.findall(r'\b%s\b' % n, pkg)) < 2]      # 1 = the signature table only
     assert idle == ['bpg_version'], idle            # bpg_version: below
     assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 104
+
+
+def test_lazy_success_history_reads_like_a_deque_of_floats():
+    """The async_stats worker's success_history (rollout.py:37, :174-184 read it with np.mean): entries resolve on first
+    read, from the difference of two running totals; host logic only."""
+    from blockpuzzle_gym_amd.rollout import _History, _LazyRate
+
+    class Snap:
+        reads = 0
+
+        def __init__(self, v):
+            self.v = v
+
+        def value(self):
+            Snap.reads += 1
+            return self.v
+    h = _History(maxlen=3)
+    totals = [Snap(10), Snap(25), Snap(25), Snap(65)]
+    h.append(_LazyRate(0, totals[0], 100))
+    for a, b in zip(totals, totals[1:]):
+        h.append(_LazyRate(a, b, 100))
+    assert len(h) == 3 and Snap.reads == 0              # nothing read yet; the first entry fell out of the window
+    assert np.mean(h) == pytest.approx((0.15 + 0.0 + 0.40) / 3)
+    assert list(h) == [0.15, 0.0, 0.40] and h[-1] == 0.40 and h == [0.15, 0.0, 0.40]
+    assert all(type(x) is float for x in h)
+    h.append(0.5)
+    assert list(h) == [0.0, 0.40, 0.5]
+    h.clear()
+    assert len(h) == 0

@@ -20,8 +20,9 @@ def P(t):
     return C.c_void_p(t.data_ptr())
 
 
-def packed_rollout(env, masks=None):
-    """reset + T steps in one launch; returns (masks, reward, flags, count)."""
+def packed_rollout(env, masks=None, ret=None):
+    """reset + T steps in one launch; returns (masks, reward, flags, count).  ret: optional (B,) float32 that receives
+    the per-env episode return of the same launch."""
     L, B = bpg._lib.lib(), env.num_envs
     if masks is None:
         masks = torch.empty((T, B), dtype=torch.int32, device=DEV)
@@ -30,7 +31,8 @@ def packed_rollout(env, masks=None):
     flags = torch.empty((T, B), dtype=torch.uint8, device=DEV)
     cnt = torch.zeros(2, dtype=torch.int64, device=DEV)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_reward_tb=reward.data_ptr(),
-                             d_flags_tb=flags.data_ptr(), d_success_count=cnt.data_ptr())
+                             d_flags_tb=flags.data_ptr(), d_success_count=cnt.data_ptr(),
+                             d_episode_return=None if ret is None else ret.data_ptr())
     bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
     return masks, reward, flags, cnt
 
@@ -44,17 +46,25 @@ def test_packed_streams_beyond_2_31_elements():
     L = bpg._lib.lib()
     big = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=5)
     # the generator's num_grey draw is taken before anything else consumes a reset index
-    m, r, f, cnt = packed_rollout(big)
+    ret = torch.empty(B, dtype=torch.float32, device=DEV)
+    m, r, f, cnt = packed_rollout(big, ret=ret)
     assert int(cnt[0]) == int((f[T - 1] & 1).sum()) == int(big.success_count()) > 0
+    # the per-env episode return of the same launch == -(failed steps) of the reward stream it wrote, all 45 M envs
+    fails = torch.zeros(B, dtype=torch.int32, device=DEV)
+    for t in range(T):
+        fails += (r[t] != 0)
+    assert torch.equal(ret, -(fails.float())) and bool(torch.signbit(ret).all())
+    del fails
     # a second consumer of the same streams: the return of the policy-gradient worker, (B, T) float64
     G = torch.empty((B, T), dtype=torch.float64, device=DEV)
     bpg._lib.check(L.bpg_discounted_return(P(r), B, T, 0.98, P(G), 0, None))
     # slices of the big batch == small batches keyed by the same global env ids
     for off in offsets(B, K):
         small = bpg.make(ENV_ID, num_envs=K, device=DEV, seed=5, env_id_base=off)
-        ms, rs, fs, cs = packed_rollout(small)
+        rets = torch.empty(K, dtype=torch.float32, device=DEV)
+        ms, rs, fs, cs = packed_rollout(small, ret=rets)
         sl = slice(off, off + K)
-        assert torch.equal(ms, m[:, sl])
+        assert torch.equal(ms, m[:, sl]) and torch.equal(rets.view(torch.int32), ret[sl].view(torch.int32))
         assert torch.equal(rs.view(torch.int32), r[:, sl].view(torch.int32))
         assert torch.equal(fs, f[:, sl])
         assert torch.equal(small.state_now, big.state_now[sl]) and torch.equal(small.state_ever, big.state_ever[sl])

@@ -370,3 +370,45 @@ def test_compute_reward_precision_follows_numpys_promotion():
     assert bpg.compute_reward(np.zeros((4, 160), np.float32), np.zeros((4, 160), np.int8)).shape == (4,)
     with pytest.raises(NotImplementedError):
         bpg.compute_reward(np.zeros((2, 8), np.float16), np.zeros((2, 8), np.float16))
+
+
+def test_async_stats_worker_never_waits_and_reports_the_same_history():
+    """RolloutStudent(async_stats=True): generate_rollouts* append a lazy entry to success_history instead of reading the
+    success count back (no host sync per rollout); the entries resolve on first read to exactly what a synchronous worker
+    appended -- fused, per-step eager and hipGraph-replayed rollouts, across the wrap of the ring of pinned slots."""
+    B, T = 4096, 50
+    rng = np.random.RandomState(11)
+    dims = dict(o=87, u=4, g=36, info_is_success=1)
+
+    class Pol:
+        device_tensors = True
+
+        def get_actions(self, o, ag, g, **kw):
+            return ag[:, :4] * 0.25
+
+    def worker(**kw):
+        return bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=DEV, seed=4), Pol(), dims, None, T,
+                                  rollout_batch_size=B, output='torch', history_len=5, **kw)
+    ws, wa = worker(), worker(async_stats=True)
+    assert wa._pinned.is_pinned() and wa._pinned.numel() == 64
+    n = 0
+    for rep in range(30):                       # 150 rollouts: the 64 pinned slots wrap twice, the history (5) many times
+        ng = rng.randint(3, size=B).astype(np.int32)
+        masks = torch.as_tensor(legal_masks(rng, T, B, 4 + ng, density=3 + rep % 2).view(np.int32), device=DEV)
+        for w in (ws, wa):
+            w.generate_rollouts_fused(masks=masks, num_grey=ng)
+            w.generate_rollouts(num_grey=ng)
+            w.generate_rollouts_graphed(num_grey=ng)
+            w.generate_rollouts_graphed(num_grey=ng)
+            w.generate_rollouts_fused(masks=masks, num_grey=ng, episode_return=True)
+        n += 5
+        if rep % 7 == 3:                        # a reader in the middle (np.mean, as logs() / current_success_rate do)
+            assert wa.current_success_rate() == ws.current_success_rate()
+            assert all(isinstance(x, float) for x in wa.success_history)
+    from collections import deque
+    unresolved = [type(x).__name__ for x in list(deque.__iter__(wa.success_history))]
+    assert '_LazyRate' in unresolved            # the last rollouts have not been read back yet
+    assert list(wa.success_history) == list(ws.success_history) and len(wa.success_history) == 5
+    assert wa.success_history[-1] == ws.success_history[-1] and wa.logs() == ws.logs()
+    assert wa.n_episodes == ws.n_episodes == n * B
+    assert 0 < np.mean(ws.success_history) <= 1
