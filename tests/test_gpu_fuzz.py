@@ -115,11 +115,16 @@ def test_random_api_sequences_vs_oracle(env_id, B):
             rew = torch.empty((Tp, B), dtype=torch.float32, device=DEV)
             flg = torch.empty((Tp, B), dtype=torch.uint8, device=DEV)
             G = torch.empty((B, Tp), dtype=torch.float64, device=DEV)
+            ret = torch.full((B,), 9.0, dtype=torch.float32, device=DEV)
+            with_G = rng.rand() < 0.6               # with d_G the return comes from the step-ok word, without from the counter
             a = bpg._lib.RolloutArgs(T=Tp, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
-                                     d_G=G.data_ptr(), gamma=0.9)
+                                     d_G=G.data_ptr() if with_G else None, gamma=0.9, d_episode_return=ret.data_ptr())
             bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            if not with_G:
+                bpg._lib.check(L.bpg_discounted_return(C.c_void_p(rew.data_ptr()), B, Tp, 0.9, C.c_void_p(G.data_ptr()), 0, None))
             torch.cuda.synchronize()
             rr = rew.cpu().numpy()
+            np.testing.assert_array_equal(bits(ret), O.episode_return(rr).view(np.uint32))
             for b in range(0, B, 17):
                 np.testing.assert_array_equal(G[b].cpu().numpy().view(np.uint64),
                                               O.discounted_return(rr[:, b].astype(np.float64), 0.9).view(np.uint64))
@@ -140,10 +145,16 @@ def test_random_api_sequences_vs_oracle(env_id, B):
             flg = torch.empty((K * Tp, B), dtype=torch.uint8, device=DEV)
             cnt = torch.zeros(K, dtype=torch.int64, device=DEV)
             dng = torch.as_tensor(ngk, device=DEV)
+            ret = torch.full((K, B), 9.0, dtype=torch.float32, device=DEV)
             a = bpg._lib.RolloutArgs(T=Tp, reset_first=1, rollouts=K, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(),
-                                     d_flags_tb=flg.data_ptr(), d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr())
+                                     d_flags_tb=flg.data_ptr(), d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr(),
+                                     d_episode_return=ret.data_ptr() if rng.rand() < 0.7 else None)
             bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
             torch.cuda.synchronize()
+            if a.d_episode_return:
+                rr = rew.cpu().numpy()
+                for k in range(K):
+                    np.testing.assert_array_equal(bits(ret[k]), O.episode_return(rr[k * Tp:(k + 1) * Tp]).view(np.uint32))
             for k in range(K):
                 mir.reset(ngk[k], np.ones(B, bool))
                 for t in range(Tp):
