@@ -268,6 +268,20 @@ def main():
         sys.exit(2)
 
 
+def collective_schedule(n_it, warmup, R, multi):
+    """Which rollouts of a leg are followed by a collective, and which exchange carries each rollout's results.  Pure host
+    logic (CPU-tested): a collective follows every R-th rollout, the last warm-up rollout and the last rollout;
+    grp[i] = number of collectives before rollout i.  Rollouts of group g write the return buffer g % 2; the gather of group
+    g must have finished before group g + 2 starts writing it."""
+    R = max(1, R)
+    coll_after = [bool(multi) and ((i + 1) % R == 0 or i == n_it - 1 or i == warmup - 1) for i in range(n_it)]
+    grp, c = [], 0
+    for i in range(n_it):
+        grp.append(c)
+        c += coll_after[i]
+    return coll_after, grp
+
+
 def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_probe=False):
     """One timed leg: W warm-up + exactly K timed fused rollouts of this rank's B-env shard of a `total`-env job, bracketed
     by barrier + synchronize, MAX over ranks.  collective (N > 1 or forced): 'allreduce' = the [successes, envs] rows in
@@ -314,8 +328,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     R = max(1, R)
     # a collective follows every R-th rollout, the last warm-up rollout and the last rollout; grp[i] = number of
     # collectives before rollout i = the exchange that will carry rollout i's results
-    coll_after = [multi and ((i + 1) % R == 0 or i == n_it - 1 or i == warmup - 1) for i in range(n_it)]
-    grp = [sum(coll_after[:i]) for i in range(n_it)]
+    coll_after, grp = collective_schedule(n_it, warmup, R, multi)
     ret = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     gathered = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
     args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(),

@@ -120,7 +120,7 @@ int main()
     // first launch (float64, gamma ** k as C pow, products and sums rounded separately).
     double *d_G; HIP(hipMalloc(&d_G, (size_t)B * T * 8));
     const double gamma = 1.0 - 1.0 / T;
-    ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
+    ra = BPG_ROLLOUT_ARGS_INIT;
     // ... and every env's undiscounted episode return r[0] + ... + r[T-1] (what a multi-GPU job all-gathers, 4 bytes per
     // env) from the same launch: d_episode_return
     float *d_ret; HIP(hipMalloc(&d_ret, (size_t)B * 4));
@@ -161,11 +161,11 @@ int main()
     HIP(hipMalloc(&d_mk, (size_t)K * T * B * 4)); HIP(hipMalloc(&d_fk, (size_t)K * T * B));
     HIP(hipMalloc(&d_ck, 2 * K * 8)); HIP(hipMemset(d_ck, 0, 2 * K * 8));
     CHECK(bpg_synth_masks(h2, 0, K * T, d_mk, nullptr));
-    ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
+    ra = BPG_ROLLOUT_ARGS_INIT;
     ra.T = T; ra.reset_first = 1; ra.rollouts = K; ra.d_masks = d_mk; ra.d_flags_tb = d_fk; ra.d_success_count = d_ck;
     CHECK(bpg_rollout(h2, &ra, nullptr));
     for (int k = 0; k < K; k++) {
-        ra = bpg_rollout_args BPG_ROLLOUT_ARGS_INIT;
+        ra = BPG_ROLLOUT_ARGS_INIT;
         ra.T = T; ra.reset_first = 1; ra.d_masks = d_mk + (size_t)k * T * B; ra.d_success_count = d_ck + K + k;
         CHECK(bpg_rollout(h3, &ra, nullptr));
     }

@@ -44,6 +44,7 @@
 #define BPGYM_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -374,7 +375,16 @@ typedef struct {
                                   (all-gather).  4-byte aligned.  NULL = not produced */
 } bpg_rollout_args;
 #define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma */
-#define BPG_ROLLOUT_ARGS_INIT { (uint32_t)sizeof(bpg_rollout_args) }
+/* `bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT;` -- struct_size set, every other field zero (C and C++, no warnings under
+ * -Wall -Wextra -pedantic) */
+static inline bpg_rollout_args bpg_rollout_args_init(void)
+{
+    bpg_rollout_args a;
+    memset(&a, 0, sizeof(a));
+    a.struct_size = (uint32_t)sizeof(a);
+    return a;
+}
+#define BPG_ROLLOUT_ARGS_INIT bpg_rollout_args_init()
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 
 /* rollout.py:163-167 `successful = successes[-1]`: number of envs whose

@@ -72,3 +72,19 @@ def test_world_size_mismatch_is_a_json_error_not_an_assert():
     assert out.returncode == 2
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert 'error' in line and 'WORLD_SIZE' in line['error']
+
+
+def test_collective_schedule_of_a_bench_leg():
+    """One collective per R rollouts, plus one behind the warm-up and one behind the last rollout; every rollout belongs to
+    exactly one exchange group and groups advance by one per collective (the two ping-pong return buffers rely on it)."""
+    b = _bench_module()
+    ca, grp = b.collective_schedule(8, 2, 3, True)                    # warm-up 2 + 6 timed, every third rollout
+    assert [i for i, c in enumerate(ca) if c] == [1, 2, 5, 7] and grp == [0, 0, 1, 2, 2, 2, 3, 3]
+    ca, grp = b.collective_schedule(6, 2, 1, True)                    # BASELINE configs[3]: one all-gather per rollout
+    assert all(ca) and grp == list(range(6))
+    ca, grp = b.collective_schedule(110, 10, 50, True)                # the default headline: once per 50 rollouts
+    assert [i for i, c in enumerate(ca) if c] == [9, 49, 99, 109]
+    assert b.collective_schedule(5, 1, 2, False) == ([False] * 5, [0] * 5)
+    for n_it, w, R in [(7, 3, 2), (12, 0, 5), (3, 1, 1)]:
+        ca, grp = b.collective_schedule(n_it, w, R, True)
+        assert ca[-1] and all(grp[i + 1] == grp[i] + ca[i] for i in range(n_it - 1))
