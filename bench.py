@@ -1031,7 +1031,11 @@ def policy_in_loop(torch, bpg, Bx, T, dev):
                 x = torch.relu(x @ w)
             return torch.tanh((x @ self.w[-1]).float())
 
-    out = {'env_side_bytes_per_env_step': 12 + 13 + 4 + 4 * dimg + 16,
+    # per env-step: now + ever + mask 12 in; now + ever 8, is_success 4, the achieved_goal row 4 * dimg and the action copy 16
+    # out (the worker ignores the step reward, rollout.py:123-125, and reads is_success as float: neither the reward nor
+    # the flags byte is produced since round 4 -- 189 B before)
+    env_bytes = 12 + 8 + 4 + 4 * dimg + 16
+    out = {'env_side_bytes_per_env_step': env_bytes,
            'note': 'ms per T=%d rollout of %d envs, reset included; env side = step + f32 achieved_goal row + f32 '
                    'is_success written into the episode slots, actions stored; o is an expanded view (no backend '
                    'writes observations)' % (T, Bx)}
@@ -1063,7 +1067,7 @@ def policy_in_loop(torch, bpg, Bx, T, dev):
                 torch.cuda.synchronize(dev)
                 w._resync_success_total()
                 gms = e0.elapsed_time(e1) / nrep
-                nbytes = Bx * T * (12 + 13 + 4 + 4 * dimg + 16)
+                nbytes = Bx * T * env_bytes
                 out['%s_%s' % (name, mode)].update(graph_only_ms=gms, graph_only_us_per_step=gms * 1e3 / T,
                                                    graph_only_env_side_frac_hbm_peak=nbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         del w
@@ -1085,7 +1089,7 @@ def policy_in_loop(torch, bpg, Bx, T, dev):
             rate = float(np.mean(wa.success_history))
             out['trivial_policy_hipgraph_async_stats'] = {
                 'ms': ms, 'env_steps_per_sec': Bx * T / (ms * 1e-3), 'rollouts_back_to_back': nroll,
-                'env_side_frac_hbm_peak': Bx * T * (12 + 13 + 4 + 4 * dimg + 16) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'env_side_frac_hbm_peak': Bx * T * env_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'mean_success_rate_read_afterwards': rate}
             del wa
         torch.cuda.empty_cache()

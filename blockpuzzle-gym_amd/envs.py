@@ -402,8 +402,10 @@ class BatchedBlocksEnv:
         return self._get_obs(ag_out=achieved_goal_out)
 
     def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None,
-                   u_out=None, count_out=None):
+                   u_out=None, count_out=None, want_reward=True, want_flags=True):
         """Launches one env step; returns (reward, flags, achieved_goal) device tensors.
+        want_reward / want_flags = False: that output is not produced at all (None is returned in its place) -- the rollout
+        worker ignores the step reward (rollout.py:123-125) and reads is_success from succ_out.
         count_out: int64 device tensor; the launch adds the number of envs whose has_succeeded latch is set after the
         step (the rollout worker passes it with the last step of a rollout, rollout.py:163-167)."""
         a = self._to_dev(action, torch.float32)
@@ -423,12 +425,12 @@ class BatchedBlocksEnv:
         st = _stream(self.device)
         # fresh output tensors every call (the reference returns copies, fetch_env.py:225-227);
         # the kernels write straight into them, so this costs an allocation, not a copy
-        if reward_out is None:
-            reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
-        else:
+        if reward_out is not None:
             reward = reward_out
             assert reward.shape == (self.num_envs,) and reward.dtype == torch.float32 and reward.is_contiguous()
-        flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        else:
+            reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device) if want_reward else None
+        flags = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device) if want_flags else None
         if ag_out is None:
             ag = torch.empty(self.num_envs, self.dimg, dtype=torch.float32, device=self.device)
         else:

@@ -360,13 +360,13 @@ class RolloutStudent:
             slot = env.observation = ep['o'][t + 1]          # the backend's write lands in the episode
             env._observation_checked = False
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store, count_out=cnt)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False)
             if not env._observation_checked:                 # written by other means than assemble_observation
                 _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
                                                        _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store, count_out=cnt)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False)
         return r
 
     def _rollout_body(self, test, num_grey, compute_Attention=False):
