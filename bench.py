@@ -769,9 +769,9 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     def step_record():
         t = sr_it[0] % T
         sr_it[0] += 1
-        _lib.check(L.bpg_step_record(env._h, C.c_void_p(masks[t].data_ptr()), C.c_void_p(reward[t].data_ptr()),
-                                     C.c_void_p(flags[t].data_ptr()), C.c_void_p(succ_f[t].data_ptr()),
-                                     C.c_void_p(agrec[t + 1].data_ptr()), env.dimg, None, None, None, stream))
+        sa = _lib.StepArgs(d_masks=masks[t].data_ptr(), d_reward=reward[t].data_ptr(), d_flags=flags[t].data_ptr(),
+                           d_success_f32=succ_f[t].data_ptr(), d_ag=agrec[t + 1].data_ptr(), ld_ag=env.dimg)
+        _lib.check(L.bpg_step_record(env._h, C.byref(sa), stream))
     res['step_record_single_launch'] = line(timed(step_record, 2 * T), (29 + 4 * env.dimg) * B, B)
     res['step_record_single_launch']['note'] = 'rows into rotating time slots of a (T+1, B, dimg) slab, as the worker writes them'
     del agrec, succ_f

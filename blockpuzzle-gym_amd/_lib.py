@@ -49,6 +49,23 @@ class RolloutArgs(C.Structure):
 ROLLOUT_ARGS_MIN_SIZE = 120
 
 
+class StepArgs(C.Structure):
+    """bpg_step_args; struct_size is filled in with this mirror's size (BPG_STEP_ARGS_INIT) unless given."""
+    _fields_ = [
+        ('struct_size', C.c_uint32), ('reserved_', C.c_uint32), ('d_masks', C.c_void_p), ('d_reward', C.c_void_p),
+        ('d_flags', C.c_void_p), ('d_success_f32', C.c_void_p), ('d_ag', C.c_void_p), ('ld_ag', C.c_int64),
+        ('d_u_in', C.c_void_p), ('d_u_out', C.c_void_p), ('d_success_count', C.c_void_p), ('d_return_acc', C.c_void_p),
+    ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not args and 'struct_size' not in kw:
+            self.struct_size = C.sizeof(StepArgs)
+
+
+STEP_ARGS_MIN_SIZE = 88
+
+
 class PhysState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ('d_grip_pos', 'd_grip_velp', 'd_gripper_state', 'd_gripper_vel',
@@ -85,8 +102,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p]),
     'bpg_contacts_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'bpg_contacts_csr_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    'bpg_step_record': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'bpg_step_record': (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
     'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks_ld': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -1301,7 +1301,7 @@ __global__ void __launch_bounds__(64 * WPB)
 k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks,
               uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, float *__restrict__ succ_f32,
               float *__restrict__ ag, int64_t ld, int64_t n, StepConst c, SynthConst s, PairTable tabv,
-              const float4 *__restrict__ u_in, float4 *__restrict__ u_out, CountArgs ca)
+              const float4 *__restrict__ u_in, float4 *__restrict__ u_out, CountArgs ca, float *__restrict__ ret_acc)
 {
     constexpr int DIMG = SIDE * SIDE;
     __shared__ uint2 hist_all[WPB][64];
@@ -1328,6 +1328,7 @@ k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
             if (flags) st_1<NT>(&flags[i], (uint8_t)fl);
             if (succ_f32) st_1<NT>(&succ_f32[i], (fl & BPG_FLAG_SUCCESS) ? 1.0f : 0.0f);
             if (u_out) st_f4<NT>(&u_out[i], u_in[i]);   // acts.append(u.copy()) of rollout.py:147, same launch
+            if (ret_acc) ret_acc[i] = ret_acc[i] + __uint_as_float(rb);          // bpg_step_args.d_return_acc (re-read next step: plain)
         }
         wave_lds_sync();
         if (ag) {
@@ -2735,6 +2736,22 @@ int check_launch(const char *what)
 }  // namespace bpgk
 using namespace bpgk;
 
+// versioned argument structs (include/bpgym.h): copies what the caller passed into a zeroed struct of this library's
+// layout; bytes this library does not know must be zero
+template <typename A>
+static int take_args(A &local, const A *args, size_t min_size, const char *what)
+{
+    const size_t caller_size = args->struct_size;
+    if (caller_size < min_size || caller_size > 4096 || caller_size % 8 != 0)
+        return fail(BPG_ERR_ARG, std::string(what) + ".struct_size is not set (use the _INIT macro; this library is bpg_version() 104)");
+    std::memset(&local, 0, sizeof(local));
+    std::memcpy(&local, args, caller_size < sizeof(local) ? caller_size : sizeof(local));
+    for (size_t i = sizeof(local); i < caller_size; i++)
+        if (reinterpret_cast<const unsigned char *>(args)[i] != 0)
+            return fail(BPG_ERR_UNSUPPORTED, std::string(what) + " carries fields this library (bpg_version() 104) does not know");
+    return BPG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -3031,34 +3048,35 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
     return check_launch("k_contacts_csr_to_masks");
 }
 
-int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags, float *d_success_f32,
-                    float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out, unsigned long long *d_success_count,
-                    void *stream)
+int bpg_step_record(bpg_batch *b, const bpg_step_args *args, void *stream)
 {
-    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
-    if ((uintptr_t)d_success_count & 7u) return fail(BPG_ERR_ARG, "counters must be 8-byte aligned");
-    if ((d_u_out != nullptr) != (d_u_in != nullptr)) return fail(BPG_ERR_ARG, "d_u_in and d_u_out go together");
-    if (!aligned16(d_u_in) || !aligned16(d_u_out)) return fail(BPG_ERR_ARG, "action buffers must be 16-byte aligned");
-    if (d_ag && ld < b->info.dimg) return fail(BPG_ERR_ARG, "ld must be >= dimg");
-    if (!aligned4(d_masks) || !aligned4(d_reward) || !aligned4(d_success_f32) || !aligned4(d_ag))
+    if (!b || !args) return fail(BPG_ERR_ARG, "NULL argument");
+    static_assert(sizeof(bpg_step_args) == BPG_STEP_ARGS_MIN_SIZE, "BPG_STEP_ARGS_MIN_SIZE");
+    bpg_step_args a;
+    if (int rc = take_args(a, args, BPG_STEP_ARGS_MIN_SIZE, "bpg_step_args")) return rc;
+    if ((uintptr_t)a.d_success_count & 7u) return fail(BPG_ERR_ARG, "counters must be 8-byte aligned");
+    if ((a.d_u_out != nullptr) != (a.d_u_in != nullptr)) return fail(BPG_ERR_ARG, "d_u_in and d_u_out go together");
+    if (!aligned16(a.d_u_in) || !aligned16(a.d_u_out)) return fail(BPG_ERR_ARG, "action buffers must be 16-byte aligned");
+    if (a.d_ag && a.ld_ag < b->info.dimg) return fail(BPG_ERR_ARG, "ld_ag must be >= dimg");
+    if (!aligned4(a.d_masks) || !aligned4(a.d_reward) || !aligned4(a.d_success_f32) || !aligned4(a.d_ag) || !aligned4(a.d_return_acc))
         return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
     DeviceGuard guard(b->device);
     const StepConst c = step_const(b);
     const SynthConst s = synth_const(b);
     const PairTable tab = pair_table(b->info);
-    const CountArgs ca = count_args(b, d_success_count, nullptr);
+    const CountArgs ca = count_args(b, a.d_success_count, nullptr);
     const dim3 grid((unsigned)((b->n + 63) / 64)), block(64);
-    const bool vec = (b->info.side % 2 == 0) && (ld % 4 == 0) && aligned16(d_ag);
-    const bool synth = (d_masks == nullptr);
-    uint32_t *rw = reinterpret_cast<uint32_t *>(d_reward);
+    const bool vec = (b->info.side % 2 == 0) && (a.ld_ag % 4 == 0) && aligned16(a.d_ag);
+    const bool synth = (a.d_masks == nullptr);
+    uint32_t *rw = reinterpret_cast<uint32_t *>(a.d_reward);
     hipStream_t st = (hipStream_t)stream;
     int rc = dispatch_side(b->info.side, [&](auto side) {
         constexpr int S = decltype(side)::value;
         constexpr bool EVEN = (S % 2 == 0);
 #define BPG_LAUNCH_SR(SRC, V)                                                                                  \
-        hipLaunchKernelGGL((k_step_record<S, SRC, V, 1, true>), grid, block, 0, st, b->now, b->ever, d_masks, rw, d_flags, \
-                           d_success_f32, d_ag, ld, b->n, c, s, tab, reinterpret_cast<const float4 *>(d_u_in),     \
-                           reinterpret_cast<float4 *>(d_u_out), ca)
+        hipLaunchKernelGGL((k_step_record<S, SRC, V, 1, true>), grid, block, 0, st, b->now, b->ever, a.d_masks, rw, a.d_flags, \
+                           a.d_success_f32, a.d_ag, a.ld_ag, b->n, c, s, tab, reinterpret_cast<const float4 *>(a.d_u_in), \
+                           reinterpret_cast<float4 *>(a.d_u_out), ca, a.d_return_acc)
         if (synth) {
             if (vec) BPG_LAUNCH_SR(SRC_SYNTH, EVEN); else BPG_LAUNCH_SR(SRC_SYNTH, false);
         } else {
@@ -3388,16 +3406,8 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     // struct versioning (include/bpgym.h): fields the caller's header did not have are zero; bytes this library does
     // not know must be zero
     static_assert(offsetof(bpg_rollout_args, gamma) + sizeof(double) == BPG_ROLLOUT_ARGS_MIN_SIZE, "BPG_ROLLOUT_ARGS_MIN_SIZE");
-    const size_t caller_size = args->struct_size;
-    if (caller_size < BPG_ROLLOUT_ARGS_MIN_SIZE || caller_size > 4096 || caller_size % 8 != 0)
-        return fail(BPG_ERR_ARG, "bpg_rollout_args.struct_size is not set (use BPG_ROLLOUT_ARGS_INIT; this library is "
-                                 "bpg_version() 104)");
     bpg_rollout_args local;
-    std::memset(&local, 0, sizeof(local));
-    std::memcpy(&local, args, caller_size < sizeof(local) ? caller_size : sizeof(local));
-    for (size_t i = sizeof(local); i < caller_size; i++)
-        if (reinterpret_cast<const unsigned char *>(args)[i] != 0)
-            return fail(BPG_ERR_UNSUPPORTED, "bpg_rollout_args carries fields this library (bpg_version() 104) does not know");
+    if (int rc = take_args(local, args, BPG_ROLLOUT_ARGS_MIN_SIZE, "bpg_rollout_args")) return rc;
     const bpg_rollout_args *a = &local;
     if (a->T < 1 || a->T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
     if ((a->d_success_count && ((uintptr_t)a->d_success_count & 7u)) ||

@@ -402,10 +402,11 @@ class BatchedBlocksEnv:
         return self._get_obs(ag_out=achieved_goal_out)
 
     def _step_core(self, action, contact_masks=None, contacts=None, ag_out=None, succ_out=None, reward_out=None,
-                   u_out=None, count_out=None, want_reward=True, want_flags=True):
+                   u_out=None, count_out=None, want_reward=True, want_flags=True, return_acc=None):
         """Launches one env step; returns (reward, flags, achieved_goal) device tensors.
         want_reward / want_flags = False: that output is not produced at all (None is returned in its place) -- the rollout
         worker ignores the step reward (rollout.py:123-125) and reads is_success from succ_out.
+        return_acc: (B,) float32 device tensor, += the step reward (the per-env episode return of a per-step rollout).
         count_out: int64 device tensor; the launch adds the number of envs whose has_succeeded latch is set after the
         step (the rollout worker passes it with the last step of a rollout, rollout.py:163-167)."""
         a = self._to_dev(action, torch.float32)
@@ -467,8 +468,13 @@ class BatchedBlocksEnv:
         # the synthetic source
         if count_out is not None:
             assert count_out.dtype == torch.int64 and count_out.numel() >= 1 and count_out.is_cuda
-        _lib.check(self._L.bpg_step_record(self._h, _ptr(m), _ptr(reward), _ptr(flags), _ptr(succ_out),
-                                           _ptr(ag), int(ag.stride(0)), _ptr(u_in), _ptr(u_out), _ptr(count_out), st))
+        if return_acc is not None:
+            assert return_acc.shape == (self.num_envs,) and return_acc.dtype == torch.float32 and return_acc.is_contiguous()
+        dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        a = _lib.StepArgs(d_masks=dp(m), d_reward=dp(reward), d_flags=dp(flags), d_success_f32=dp(succ_out), d_ag=dp(ag),
+                          ld_ag=int(ag.stride(0)), d_u_in=dp(u_in), d_u_out=dp(u_out), d_success_count=dp(count_out),
+                          d_return_acc=dp(return_acc))
+        _lib.check(self._L.bpg_step_record(self._h, C.byref(a), st))
         return reward, flags, ag
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):

@@ -292,15 +292,18 @@ class RolloutStudent:
             return {k: v.cpu().numpy() for k, v in episode.items()}
         return episode
 
-    def generate_rollouts(self, render=False, test=False, compute_Attention=False, num_grey=None):
+    def generate_rollouts(self, render=False, test=False, compute_Attention=False, num_grey=None, episode_return=False):
         """rollout.py:75-172 with the policy in the loop: one HIP step launch
         for the whole batch per time step.  Returns the batch-major episode.
+        episode_return=True: also `episode_return` (B,) float32, every env's undiscounted return r[0] + ... + r[T-1],
+        accumulated by the step launches themselves (bpg_step_args.d_return_acc) -- the per-step counterpart of
+        generate_rollouts_fused(episode_return=True), same bits.
         A backend failure (PhysicsError, the stand-in for MujocoException) restarts the rollout
         (rollout.py:136-137); a NaN in the observations a backend wrote is detected on the device,
         and the rollout is thrown away, everything reset and generated again (rollout.py:139-142)."""
         for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
             try:
-                ep, Qs = self._rollout_body(test, num_grey, compute_Attention)
+                ep, Qs = self._rollout_body(test, num_grey, compute_Attention, episode_return)
             except PhysicsError as e:
                 self._log('warning', 'physics backend failed during rollout generation (%s). Trying again...' % e)
                 self._resync_success_total()
@@ -350,7 +353,7 @@ class RolloutStudent:
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0, achieved_goal_out=ag_out)
         return o0[None].expand(T + 1, B, self.dims['o'])
 
-    def _step_into(self, u, ep, t, reward_out=None, u_store=None):
+    def _step_into(self, u, ep, t, reward_out=None, u_store=None, return_acc=None):
         """One env step that writes obs['achieved_goal'] / info['is_success'] (and, through the
         backend, obs['observation']; optionally the step reward) straight into time slot t+1 / t
         of the episode.  The last step of the rollout also adds the success count to the worker's total."""
@@ -360,17 +363,21 @@ class RolloutStudent:
             slot = env.observation = ep['o'][t + 1]          # the backend's write lands in the episode
             env._observation_checked = False
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False,
+                                     return_acc=return_acc)
             if not env._observation_checked:                 # written by other means than assemble_observation
                 _lib.check(_lib.lib().bpg_nan_flag_f32(_ptr(slot), slot.shape[0], slot.shape[1], int(slot.stride(0)),
                                                        _ptr(self._nan_flag), self.device.index, _stream(self.device)))
         else:
             r, _, _ = env._step_core(u, ag_out=ep['ag'][t + 1], succ_out=ep['info_is_success'][t],
-                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False)
+                                     reward_out=reward_out, u_out=u_store, count_out=cnt, want_reward=False, want_flags=False,
+                                     return_acc=return_acc)
         return r
 
-    def _rollout_body(self, test, num_grey, compute_Attention=False):
+    def _rollout_body(self, test, num_grey, compute_Attention=False, episode_return=False):
         env, B, T = self.env, self.rollout_batch_size, self.T
+        # -0.0f + r[0] + r[1] + ...: the sum that starts from r[0] (-0.0f when every step succeeded)
+        acc = torch.full((B,), -0.0, dtype=torch.float32, device=self.device) if episode_return else None
         # time-major slabs: every per-step write below is one contiguous block; o / ag of step t
         # ARE the episode's time slot t (rollout.py:144-153 appends copies), and the env writes
         # the next achieved_goal straight into slot t+1
@@ -393,19 +400,21 @@ class RolloutStudent:
             u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
             # reward ignored: recomputed for HER (rollout.py:123-125); the step launch also stores the
             # actions into the episode's slot (acts.append(u.copy()), rollout.py:147)
-            self._step_into(u, ep, t, u_store=ep['u'][t])
+            self._step_into(u, ep, t, u_store=ep['u'][t], return_acc=acc)
         if self._watch_o:
             self.initial_o = ep['o'][T]                            # rollout.py:153 `self.initial_o[:] = o`
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
+        if acc is not None:
+            ep['episode_return'] = acc
         # the goal is constant over the episode (rollout.py:151 appends the same array T times)
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         return ep, Qs
 
     def _graph_body(self, test, num_grey):
         """What a replay runs: the rollout body, returning (episode dict, Qs)."""
-        return self._rollout_body(test, num_grey)
+        return self._rollout_body(test, num_grey, episode_return=getattr(self, '_graph_episode_return', False))
 
-    def generate_rollouts_graphed(self, test=False, num_grey=None, _key=()):
+    def generate_rollouts_graphed(self, test=False, num_grey=None, _key=(), episode_return=False):
         """generate_rollouts for DEVICE-RESIDENT policies with the whole T-step loop (reset,
         policy, step kernels, episode writes) captured once into a hipGraph and replayed: below
         ~64 K envs the per-step path is bound by host launches (~50 us per step), a replay is
@@ -419,6 +428,8 @@ class RolloutStudent:
         assert self.output == 'torch' and getattr(self.policy, 'device_tensors', False)
         B = self.rollout_batch_size
         explicit = num_grey is not None
+        self._graph_episode_return = bool(episode_return)
+        _key = tuple(_key) + (bool(episode_return),)
         if (getattr(self, '_graph', None) is None or self._graph_test != bool(test)
                 or self._graph_explicit != explicit or self._graph_key != _key):
             self._static_ng = torch.zeros(B, dtype=torch.int32, device=self.device)
@@ -655,11 +666,13 @@ class PGRolloutStudent(RolloutStudent):
                                                want_reward=want_reward, materialize_constants=materialize_constants,
                                                gamma=self.gamma if gamma is None else gamma, episode_return=episode_return)
 
-    def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None):
+    def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None, episode_return=False):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference
-        (`assert(False)`, :237-241); NaN observations restart the rollout (:243-246)."""
+        (`assert(False)`, :237-241); NaN observations restart the rollout (:243-246).
+        episode_return=True: also `episode_return` (B,) float32 = r[0] + ... + r[T-1] (the reference's returns[0] at
+        gamma = 1), accumulated by the step launches."""
         for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
-            ep = self._pg_body(test, exploit, num_grey)
+            ep = self._pg_body(test, exploit, num_grey, episode_return)
             if self._nan_caught():
                 self._log('info', 'NaN caught during rollout generation. Trying again...')
                 self._resync_success_total()
@@ -669,9 +682,9 @@ class PGRolloutStudent(RolloutStudent):
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
 
     def _graph_body(self, test, num_grey):
-        return self._pg_body(test, self._graph_exploit, num_grey), ()
+        return self._pg_body(test, self._graph_exploit, num_grey, getattr(self, '_graph_episode_return', False)), ()
 
-    def generate_rollouts_graphed(self, test=False, exploit=False, num_grey=None):
+    def generate_rollouts_graphed(self, test=False, exploit=False, num_grey=None, episode_return=False):
         """The policy-gradient rollout (reset, T x (policy, step, reward row), the return kernel) replayed from one
         hipGraph -- see RolloutStudent.generate_rollouts_graphed for the requirements.  Without an expert only: with
         one, every step flips a host-side coin (policy_gradient/rollout.py:196) and calls host code."""
@@ -684,13 +697,15 @@ class PGRolloutStudent(RolloutStudent):
         # np.random after set_global_seeds (exploration noise, HER sampling) sees the stream an eager rollout leaves.
         state = np.random.get_state()
         try:
-            return super().generate_rollouts_graphed(test=test, num_grey=num_grey, _key=('pg', bool(exploit)))
+            return super().generate_rollouts_graphed(test=test, num_grey=num_grey, _key=('pg', bool(exploit)),
+                                                     episode_return=episode_return)
         finally:
             np.random.set_state(state)
             np.random.rand(self.T)
 
-    def _pg_body(self, test, exploit, num_grey):
+    def _pg_body(self, test, exploit, num_grey, episode_return=False):
         env, B, T = self.env, self.rollout_batch_size, self.T
+        acc = torch.full((B,), -0.0, dtype=torch.float32, device=self.device) if episode_return else None
         beta = self.beta() if self.expert is not None else 0
         ep = self._alloc_episode(time_major=True, g=False, o=False, zero_u=False)
         ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])
@@ -716,7 +731,7 @@ class PGRolloutStudent(RolloutStudent):
             ep['u'][t] = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
             if sigma is not None:
                 ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
-            self._step_into(u, ep, t, reward_out=reward[t])
+            self._step_into(u, ep, t, reward_out=reward[t], return_acc=acc)
         if defer and int(self._trim_bad.item()):
             raise ValueError('trim: an observation row did not hold exactly 2 GREEN / BLUE blocks at some step of the '
                              'rollout (policy_gradient/rollout.py:166)')
@@ -725,4 +740,6 @@ class PGRolloutStudent(RolloutStudent):
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}
         ep['g'] = self.g[:, None, :].expand(B, T, self.dims['g'])
         ep['G'] = discounted_return(reward, self.gamma)
+        if acc is not None:
+            ep['episode_return'] = acc
         return ep

@@ -184,16 +184,40 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
                               uint32_t *d_masks, void *stream);
 
 /* One env.step exactly as the rollout worker consumes it (rollout.py:121-131, :144-150), in ONE
- * launch: the step of bpg_step_masks (d_masks NULL = synthetic source) plus obs['achieved_goal'] as
- * float32 rows at d_ag + e*ld (fetch_env.py:219-228; ld as in bpg_get_achieved_goal_f32),
- * info['is_success'] as float32 d_success_f32[n_envs], and the step's actions d_u_in (n_envs, 4)
- * float32 stored into the episode's action slot d_u_out (`acts.append(u.copy())`, rollout.py:147).
- * d_success_count (8-byte aligned): += the number of envs whose has_succeeded latch is set after this step --
- * `successful = successes[-1]` (rollout.py:163-167) inside the LAST step's launch of a rollout instead of a
- * bpg_success_count launch of its own.  Every output pointer is optional (d_u_in / d_u_out go together). */
-int bpg_step_record(bpg_batch *b, const uint32_t *d_masks, float *d_reward, uint8_t *d_flags,
-                    float *d_success_f32, float *d_ag, int64_t ld, const float *d_u_in, float *d_u_out,
-                    unsigned long long *d_success_count, void *stream);
+ * launch: the step of bpg_step_masks plus whatever of the following is asked for (every pointer is optional, NULL = not
+ * produced; d_u_in / d_u_out go together).  Versioned like bpg_rollout_args: struct_size = sizeof(bpg_step_args) as the
+ * caller compiled it (BPG_STEP_ARGS_INIT sets it), fields are only appended, unknown trailing bytes must be zero. */
+typedef struct {
+    uint32_t struct_size;
+    uint32_t reserved_;        /* 0 */
+    const uint32_t *d_masks;   /* (n_envs) packed pair masks of the step; NULL = the synthetic source */
+    float *d_reward;           /* (n_envs) float32 step reward, -1.0f / -0.0f */
+    uint8_t *d_flags;          /* (n_envs) flags byte */
+    float *d_success_f32;      /* (n_envs) info['is_success'] as float32 (rollout.py:127-131) */
+    float *d_ag;               /* obs['achieved_goal'] as float32 rows at d_ag + e * ld_ag (fetch_env.py:219-228): a dense
+                                  (n_envs, dimg) array or the time slot of an episode buffer */
+    int64_t ld_ag;             /* row stride of d_ag in elements (>= dimg) */
+    const float *d_u_in;       /* (n_envs, 4) float32 actions of the step ... */
+    float *d_u_out;            /* ... stored into the episode's action slot (`acts.append(u.copy())`, rollout.py:147) */
+    unsigned long long *d_success_count; /* += the number of envs whose has_succeeded latch is set after this step --
+                                  `successful = successes[-1]` (rollout.py:163-167) inside the LAST step's launch of a
+                                  rollout instead of a bpg_success_count launch of its own.  8-byte aligned */
+    float *d_return_acc;       /* (n_envs) float32, d_return_acc[e] += the step reward: the per-env undiscounted episode
+                                  return of a rollout that runs one launch per step (a policy between the steps), the
+                                  per-step counterpart of bpg_rollout_args.d_episode_return.  Initialise it to -0.0f
+                                  before the first step for the same r[0] + r[1] + ... convention (-0.0f when every
+                                  step succeeded) */
+} bpg_step_args;
+#define BPG_STEP_ARGS_MIN_SIZE 88u
+static inline bpg_step_args bpgh_step_args_init(void)
+{
+    bpg_step_args a;
+    memset(&a, 0, sizeof(a));
+    a.struct_size = (uint32_t)sizeof(a);
+    return a;
+}
+#define BPG_STEP_ARGS_INIT bpgh_step_args_init()
+int bpg_step_record(bpg_batch *b, const bpg_step_args *args, void *stream);
 
 /* One step whose contacts come from the build-defined counter-based synthetic
  * source keyed (seed, global env id, elapsed step) -- physics stand-in for
@@ -376,15 +400,15 @@ typedef struct {
 } bpg_rollout_args;
 #define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma */
 /* `bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT;` -- struct_size set, every other field zero (C and C++, no warnings under
- * -Wall -Wextra -pedantic) */
-static inline bpg_rollout_args bpg_rollout_args_init(void)
+ * -Wall -Wextra -pedantic).  bpgh_* are header-only helpers, not symbols of the library. */
+static inline bpg_rollout_args bpgh_rollout_args_init(void)
 {
     bpg_rollout_args a;
     memset(&a, 0, sizeof(a));
     a.struct_size = (uint32_t)sizeof(a);
     return a;
 }
-#define BPG_ROLLOUT_ARGS_INIT bpg_rollout_args_init()
+#define BPG_ROLLOUT_ARGS_INIT bpgh_rollout_args_init()
 int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 
 /* rollout.py:163-167 `successful = successes[-1]`: number of envs whose

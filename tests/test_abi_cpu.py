@@ -212,8 +212,8 @@ def test_header_is_plain_c_and_its_structs_have_the_layout_ctypes_assumes(tmp_pa
     """The boundary is a C ABI: include/bpgym.h must compile as C99 on its own (no C++, no HIP, no torch types), and
     the structs a C compiler lays out must be what blockpuzzle-gym_amd/_lib.py mirrors, field by field."""
     import subprocess
-    pairs = [('bpg_rollout_args', _lib.RolloutArgs), ('bpg_variant_info', _lib.VariantInfo), ('bpg_phys_state', _lib.PhysState),
-             ('bpg_placement_args', _lib.PlacementArgs)]
+    pairs = [('bpg_rollout_args', _lib.RolloutArgs), ('bpg_step_args', _lib.StepArgs), ('bpg_variant_info', _lib.VariantInfo),
+             ('bpg_phys_state', _lib.PhysState), ('bpg_placement_args', _lib.PlacementArgs)]
     body = ''
     for cname, ct in pairs:
         body += '  printf("%s.size %%zu\\n", sizeof(%s));\n' % (cname, cname)

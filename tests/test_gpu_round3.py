@@ -750,6 +750,16 @@ def test_graphed_pg_rollout_equals_eager():
         np.random.rand(T)
         assert np.random.rand() == after_graphed                       # = T draws of the reference's loop
         assert set(epg) == set(epe) and 'G' in epg and 'sigma' in epg
+        if r == 3:                                   # ... and with the per-env episode return the step launches accumulate
+            src_e.t = 0
+            epr = we.generate_rollouts(exploit=exploit, num_grey=ng, episode_return=True)
+            assert torch.equal(epr['G'], epe['G'])
+            wf = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None, dims_of(env_id), None,
+                                    T, rollout_batch_size=B, output='torch')
+            epf = wf.generate_rollouts_fused(masks=masks, num_grey=ng, episode_return=True)
+            assert torch.equal(epr['episode_return'].view(torch.int32), epf['episode_return'].view(torch.int32))
+            epgr = wg.generate_rollouts_graphed(exploit=exploit, num_grey=ng, episode_return=True)
+            assert torch.equal(epgr['episode_return'].view(torch.int32), epf['episode_return'].view(torch.int32))
         for k in epe:
             assert epg[k].dtype == epe[k].dtype and epg[k].shape == epe[k].shape, k
             assert torch.equal(epg[k], epe[k]), k

@@ -87,8 +87,11 @@ def child(which):
             _lib.check(L.bpg_rollout(env._h, C.byref(a2), None))
         res['rollout + G from step-ok words %d' % B] = timed(pg, 12)
         sf = torch.empty(B, dtype=torch.float32, device=dev)
-        res['step_record (nontemporal in both) %d' % B] = timed(
-            lambda: _lib.check(L.bpg_step_record(env._h, P(m[3]), P(r[3]), None, P(sf), P(rot(ag)), 36, None, None, None, None)), 30)
+        def record():
+            sa = _lib.StepArgs(d_masks=m[3].data_ptr(), d_reward=r[3].data_ptr(), d_success_f32=sf.data_ptr(),
+                               d_ag=rot(ag).data_ptr(), ld_ag=36)
+            _lib.check(L.bpg_step_record(env._h, C.byref(sa), None))
+        res['step_record (nontemporal in both) %d' % B] = timed(record, 30)
         fl = torch.empty(B, dtype=torch.uint8, device=dev)
         res['step_masks, same batch (state cache-resident) %d' % B] = timed(
             lambda: _lib.check(L.bpg_step_masks(env._h, P(m[5]), P(r[5]), P(fl), None)), 100)

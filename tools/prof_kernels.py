@@ -151,7 +151,9 @@ def main():
                 ag = torch.empty((B, 36), dtype=torch.float32, device=DEV)
                 sf = torch.empty(B, dtype=torch.float32, device=DEV)
                 for i in range(20):
-                    _lib.check(L.bpg_step_record(env._h, P(m[i]), P(r[i]), P(f[i]), P(sf), P(ag), 36, None, None, None, None))
+                    sa = _lib.StepArgs(d_masks=m[i].data_ptr(), d_reward=r[i].data_ptr(), d_flags=f[i].data_ptr(),
+                                       d_success_f32=sf.data_ptr(), d_ag=ag.data_ptr(), ld_ag=36)
+                    _lib.check(L.bpg_step_record(env._h, C.byref(sa), None))
             elif w in ('return', 'scan'):
                 # three (reward, G) pairs round-robin: nothing of the previous launch is left in the 256 MiB cache
                 rs = [r] + [TM(B, torch.float32) for _ in range(2)]

@@ -68,7 +68,7 @@ static void launch_step(const Train &t, int step, int grid, hipStream_t st, bool
     hipLaunchKernelGGL((k_step_record<6, SRC, true, WPB, NT>), dim3(grid), dim3(64 * WPB), 0, st, t.now, t.ever,
                        SRC == SRC_MASKS ? t.masks + (int64_t)step * t.B : nullptr, reinterpret_cast<uint32_t *>(t.reward), t.flags,
                        t.succ + (int64_t)step * t.B, t.ag + (int64_t)(step + 1) * slot, (int64_t)36, t.B, mk_c(), mk_s(), mk_tab(),
-                       reinterpret_cast<const float4 *>(t.u_in), reinterpret_cast<float4 *>(t.u_out) + (int64_t)step * t.B, ca);
+                       reinterpret_cast<const float4 *>(t.u_in), reinterpret_cast<float4 *>(t.u_out) + (int64_t)step * t.B, ca, (float *)nullptr);
 }
 
 struct NodeStats { double ramp, dur, gap; };
