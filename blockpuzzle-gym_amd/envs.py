@@ -424,6 +424,7 @@ class BatchedBlocksEnv:
                 else:
                     contacts = (nxt[1], nxt[2])
         st = _stream(self.device)
+        m = self._masks_of(contact_masks, contacts, st)
         # fresh output tensors every call (the reference returns copies, fetch_env.py:225-227);
         # the kernels write straight into them, so this costs an allocation, not a copy
         if reward_out is not None:
@@ -437,6 +438,10 @@ class BatchedBlocksEnv:
         else:
             ag = ag_out
             assert ag.shape == (self.num_envs, self.dimg) and ag.dtype == torch.float32 and ag.stride(1) == 1
+        return self._launch_step_record(m, reward, flags, succ_out, ag, u_out, a, count_out, return_acc, st)
+
+    def _masks_of(self, contact_masks, contacts, st):
+        """The step's contacts as (B,) packed pair masks on the device, or None for the synthetic source."""
         m = None
         if contacts is not None:
             # geom-id contact lists as the reference reads them (fetch_env.py:158-166): one launch maps
@@ -458,6 +463,9 @@ class BatchedBlocksEnv:
                 torch.is_tensor(contact_masks) and contact_masks.dtype in (torch.int32, torch.uint32)
             ) else self._to_dev(contact_masks, torch.int32)
             assert m.numel() == self.num_envs
+        return m
+
+    def _launch_step_record(self, m, reward, flags, succ_out, ag, u_out, a, count_out, return_acc, st):
         if succ_out is not None:
             assert succ_out.numel() == self.num_envs and succ_out.is_contiguous() and succ_out.dtype == torch.float32
         u_in = None
@@ -476,6 +484,20 @@ class BatchedBlocksEnv:
                           d_return_acc=dp(return_acc))
         _lib.check(self._L.bpg_step_record(self._h, C.byref(a), st))
         return reward, flags, ag
+
+    def _step_with_args(self, action, sa):
+        """The rollout worker's step: `sa` is a bpg_step_args the worker filled with the addresses of the episode's time
+        slots (plain integers: no tensor views are made per step); this adds the step's contacts from the contact
+        source and the action pointer, and launches.  `action`: (B, 4) float32 contiguous device tensor."""
+        self.last_action = action
+        nxt = self.contact_source.next(self, action)
+        st = _stream(self.device)
+        m = None
+        if nxt is not None:
+            m = self._masks_of(nxt[1], None, st) if nxt[0] == 'masks' else self._masks_of(None, (nxt[1], nxt[2]), st)
+        sa.d_masks = None if m is None else m.data_ptr()
+        sa.d_u_in = action.data_ptr() if sa.d_u_out else None
+        _lib.check(self._L.bpg_step_record(self._h, C.byref(sa), st))
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):
         """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info).

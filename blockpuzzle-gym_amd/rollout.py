@@ -384,8 +384,18 @@ class RolloutStudent:
         ep = self._alloc_episode(time_major=True, g=False, o=False, zero_u=False)
         ep['o'] = self._reset_into_episode(test, num_grey, ag_out=ep['ag'][0])   # slot 0 = initial_ag (rollout.py:82-83)
         Qs = []
+        # Without a backend that writes observations the step launch gets the ADDRESSES of the episode's time slots (one
+        # bpg_step_args per rollout, integer arithmetic per step) instead of a tensor view per slot and step: the eager
+        # loop is bound by the host (17 us of Python per step at 65 536 envs before, about half of it view objects)
+        fast = not self._watch_o
+        if fast:
+            sa = _lib.StepArgs(ld_ag=self.dims['g'], d_return_acc=None if acc is None else acc.data_ptr())
+            ag0, succ0, u0 = ep['ag'].data_ptr(), ep['info_is_success'].data_ptr(), ep['u'].data_ptr()
+            ag_sz, succ_sz, u_sz = 4 * B * self.dims['g'], 4 * B, 4 * B * self.dims['u']
+            o_const = ep['o'][0]                      # nothing rewrites the observation between resets: one view
+            assert ep['ag'].is_contiguous() and ep['u'].is_contiguous() and self.dims['u'] == 4
         for t in range(T):
-            o, ag = ep['o'][t], ep['ag'][t]
+            o, ag = (o_const if fast else ep['o'][t]), ep['ag'][t]
             policy_output = self.policy.get_actions(
                 *self._policy_in(o, ag, self.g),
                 compute_Q=self.compute_Q,
@@ -397,10 +407,17 @@ class RolloutStudent:
                 Qs.append(Q)
             else:
                 u = policy_output[0] if (compute_Attention and isinstance(policy_output, tuple)) else policy_output
-            u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1)
+            if not (torch.is_tensor(u) and u.dtype == torch.float32 and u.device == self.device and u.dim() == 2
+                    and u.shape[0] == B and u.is_contiguous()):
+                u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1).contiguous()
             # reward ignored: recomputed for HER (rollout.py:123-125); the step launch also stores the
             # actions into the episode's slot (acts.append(u.copy()), rollout.py:147)
-            self._step_into(u, ep, t, u_store=ep['u'][t], return_acc=acc)
+            if fast:
+                sa.d_ag, sa.d_success_f32, sa.d_u_out = ag0 + (t + 1) * ag_sz, succ0 + t * succ_sz, u0 + t * u_sz
+                sa.d_success_count = self._succ_total.data_ptr() if t == T - 1 else None
+                env._step_with_args(u, sa)
+            else:
+                self._step_into(u, ep, t, u_store=ep['u'][t], return_acc=acc)
         if self._watch_o:
             self.initial_o = ep['o'][T]                            # rollout.py:153 `self.initial_o[:] = o`
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
@@ -716,8 +733,15 @@ class PGRolloutStudent(RolloutStudent):
         defer = self.expert is not None and self.output == 'torch'
         if defer:
             self._trim_bad.zero_()
+        fast = not self._watch_o                     # addresses of the time slots instead of views (see _rollout_body)
+        if fast:
+            sa = _lib.StepArgs(ld_ag=self.dims['g'], d_return_acc=None if acc is None else acc.data_ptr())
+            ag0, succ0, rew0 = ep['ag'].data_ptr(), ep['info_is_success'].data_ptr(), reward.data_ptr()
+            ag_sz, succ_sz, rew_sz = 4 * B * self.dims['g'], 4 * B, 4 * int(reward.stride(0))
+            o_const = ep['o'][0]
+            assert ep['ag'].is_contiguous()
         for t in range(T):
-            o, ag = ep['o'][t], ep['ag'][t]
+            o, ag = (o_const if fast else ep['o'][t]), ep['ag'][t]
             if np.random.rand() < beta:            # the expert is in charge (:196-200)
                 # device-resident experts: no host read of the bad-row flag per step, one at the end of the rollout
                 o_, g_, ag_ = self.trim(o, self.g, ag, self.expert.dimo, self.expert.dimg, _defer_check=defer)
@@ -731,7 +755,12 @@ class PGRolloutStudent(RolloutStudent):
             ep['u'][t] = torch.as_tensor(raw, dtype=torch.float32).to(self.device).reshape(B, -1)
             if sigma is not None:
                 ep['sigma'][t] = torch.as_tensor(sigma, dtype=torch.float32).to(self.device).reshape(B, -1)
-            self._step_into(u, ep, t, reward_out=reward[t], return_acc=acc)
+            if fast:
+                sa.d_ag, sa.d_success_f32, sa.d_reward = ag0 + (t + 1) * ag_sz, succ0 + t * succ_sz, rew0 + t * rew_sz
+                sa.d_success_count = self._succ_total.data_ptr() if t == T - 1 else None
+                env._step_with_args(u.contiguous(), sa)
+            else:
+                self._step_into(u, ep, t, reward_out=reward[t], return_acc=acc)
         if defer and int(self._trim_bad.item()):
             raise ValueError('trim: an observation row did not hold exactly 2 GREEN / BLUE blocks at some step of the '
                              'rollout (policy_gradient/rollout.py:166)')
