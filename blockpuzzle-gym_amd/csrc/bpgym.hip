@@ -1077,6 +1077,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
                     one_step(t0 + u, mt, 1u << u);
                 }
                 flush_ok(t0);
+                if (t0 == 0 && tl_pass < 2) BPG_TL(1 + 4 * tl_pass);
             };
             // Two batches per trip with ping-pong register buffers (a register copy cur = nxt would
             // have to wait for the prefetch it copies), and the tail peeled so that every batch in

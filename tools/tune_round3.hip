@@ -367,6 +367,56 @@ static int run_timeline(int64_t B)
     return 0;
 }
 
+// mode S: the same stamps for the SMALL-batch shape (1 env per lane, 256-lane blocks, pipelined requests, 10 rows in
+// flight, one block per 256 envs): where a 65 536-env launch spends its 9-10 us.
+static int run_timeline_small(int64_t B)
+{
+    Bufs b;
+    const int T = 50;
+    if (setup(b, B, T, false)) return 1;
+    const StepConst c = mk_c();
+    const SynthConst s = mk_s();
+    const ResetConst rc = mk_rc(b);
+    CountArgs ca{b.cnt, nullptr, b.shards};
+    const int grid = (int)((B + 255) / 256);
+    unsigned long long *tl;
+    CK(hipMalloc(&tl, (size_t)grid * 16 * 8));
+    std::vector<unsigned long long> h((size_t)grid * 16);
+    unsigned long long *null_tl = nullptr;
+    printf("== mode S  B = %lld envs, grid %d x 256, epl1 pipelined unr10: per-block times in us relative to the earliest entry\n", (long long)B, grid);
+    for (int rep = 0; rep < 9; rep++) {
+        const bool count = rep < 6;
+        const bool stamps = rep % 3 != 2;           // every third launch runs without stamps: what the stamps cost
+        ca.count = count ? b.cnt : nullptr;
+        CK(hipMemset(tl, 0, (size_t)grid * 16 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(bpgk::bpg_timeline), stamps ? &tl : &null_tl, sizeof(tl)));
+        rot++;
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(b.e0, 0));
+        hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 1, 3, true, 10, true, true, 256, false, false, false>), dim3(grid), dim3(256), 0, 0,
+                           b.now, b.ever, M, R, F, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
+        CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));
+        float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));
+        CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+        printf("launch %d (%s, %s): %.2f us by events (a lone launch between two events: + the events' own ~3 us)\n", rep,
+               count ? "with the success count" : "no count", stamps ? "stamped" : "NOT stamped", ms * 1e3);
+        if (!stamps || rep < 3) continue;
+        unsigned long long t0 = ~0ull;
+        for (int g = 0; g < grid; g++) t0 = std::min(t0, h[(size_t)g * 16]);
+        const char *names[14] = {"entry", "first 10 steps done", "last step done", "state stored", "", "", "", "", "", "", "", "before count", "after count", "stores drained"};
+        for (int slot : {0, 1, 2, 3, 11, 12, 13}) {
+            std::vector<double> v;
+            for (int g = 0; g < grid; g++) v.push_back((double)(h[(size_t)g * 16 + slot] - t0) / 100.0);   // 100 MHz
+            std::sort(v.begin(), v.end());
+            printf("  %-20s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f\n", names[slot], v.front(), v[grid / 10], v[grid / 2],
+                   v[grid * 9 / 10], v.back());
+        }
+    }
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(bpgk::bpg_timeline), &null_tl, sizeof(null_tl)));
+    teardown(b);
+    return 0;
+}
+
 // mode P: the policy-gradient call (rollout with flags + step-ok words, then the expansion of the words into G rows) as
 // two launches one after the other, against the same work split into env halves on two streams: rollout A, then
 // rollout B and the expansion of A side by side (a read-heavy and a write-only kernel share the chip), then the
@@ -447,6 +497,7 @@ int main(int argc, char **argv)
 {
     if (argc >= 3 && argv[1][0] == 'P') return run_pg_split(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'T') return run_timeline(atoll(argv[2]));
+    if (argc >= 3 && argv[1][0] == 'S') return run_timeline_small(atoll(argv[2]));
     if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F|T envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
