@@ -390,7 +390,7 @@ static int run_timeline_small(int64_t B)
         ca.count = count ? b.cnt : nullptr;
         CK(hipMemset(tl, 0, (size_t)grid * 16 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(bpgk::bpg_timeline), stamps ? &tl : &null_tl, sizeof(tl)));
-        rot++;
+        if (!getenv("NOROT")) rot++;                // NOROT=1: every launch on the same buffers (Infinity-Cache-resident inputs)
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(b.e0, 0));
         hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 1, 3, true, 10, true, true, 256, false, false, false>), dim3(grid), dim3(256), 0, 0,
