@@ -676,7 +676,10 @@ def compute_reward(achieved_goal, goal, device=None):
     g = torch.as_tensor(np.asarray(goal) if not torch.is_tensor(goal) else goal)
     # the precision of `achieved_goal * goal` by NumPy's promotion rules (float32 x int8 / int16 / bool / float16 stays
     # float32; float32 x int32 / int64 / float64 is float64; integer x integer stays integer -- exact, run in float64)
-    rt = np.result_type(*(np.dtype(str(t.dtype).replace('torch.', '')) for t in (ag, g)))
+    try:
+        rt = np.result_type(*(np.dtype(str(t.dtype).replace('torch.', '')) for t in (ag, g)))
+    except TypeError:
+        raise TypeError('compute_reward: %s x %s arrays have no NumPy counterpart' % (ag.dtype, g.dtype)) from None
     if rt == np.float16:
         raise NotImplementedError('compute_reward on float16 x float16 rows (NumPy would sum in float16)')
     wide = rt != np.float32
