@@ -37,7 +37,7 @@ static int setup(Bufs &b, int64_t B, int T, bool withG)
     b.B = B; b.T = T;
     b.LD = bpg_row_stride(B) + (getenv("LDPAD") ? atoll(getenv("LDPAD")) : 0);
     const size_t set_bytes = (size_t)b.LD * T * 9 + (withG ? (size_t)B * T * 8 : 0);
-    b.NB = (int)((size_t)640 * 1024 * 1024 / set_bytes) + 1;
+    b.NB = (int)((size_t)(getenv("NBMB") ? atoll(getenv("NBMB")) : 640) * 1024 * 1024 / set_bytes) + 1;
     if (b.NB < 3) b.NB = 3;
     if (b.NB > 48) b.NB = 48;
     CK(hipMalloc(&b.now, B * 4)); CK(hipMalloc(&b.ever, B * 4)); CK(hipMalloc(&b.okbits, B * 8));
@@ -417,6 +417,53 @@ static int run_timeline_small(int64_t B)
     return 0;
 }
 
+// mode N: nontemporal against plain mask LOADS (and reward / flag STORES) on the SAME buffer sets of one process -- the
+// placement of the read stream moves a launch by up to 10 % (profiles/r04_stream_placement.log), so variants are only
+// comparable on the same arrays.
+static int run_nt_on_same_sets(int64_t B)
+{
+    Bufs b;
+    const int T = 50;
+    if (setup(b, B, T, false)) return 1;
+    const StepConst c = mk_c();
+    const SynthConst s = mk_s();
+    const ResetConst rc = mk_rc(b);
+    CountArgs ca{b.cnt, b.cnt + 1, b.shards};
+    const int grid = 256;
+    printf("== mode N  B = %lld envs, grid %d x 1024, epl2 plain unr5, %d buffer sets: us per launch on ONE set (re-launched; 472 MB per set)\n",
+           (long long)B, grid, b.NB);
+    printf("%-6s %12s %12s %12s %12s\n", "set", "nt ld + nt st", "plain ld", "plain st", "plain both");
+    for (int k = -1; k < b.NB && k < 6; k++) {      // k = -1: all sets round-robin (nothing comes from the Infinity Cache)
+        float us[4];
+        for (int v = 0; v < 4; v++) {
+            int it = 0;
+            auto launch = [&]() {
+                const int kk = k < 0 ? (it++ % b.NB) : k;
+                uint32_t *m = b.masks[kk], *r = b.reward[kk];
+                uint8_t *f = b.flags[kk];
+                if (v == 0) hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false, false, false>), dim3(grid), dim3(1024), 0, 0,
+                                               b.now, b.ever, m, r, f, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
+                if (v == 1) hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, false, 1024, false, false, false>), dim3(grid), dim3(1024), 0, 0,
+                                               b.now, b.ever, m, r, f, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
+                if (v == 2) hipLaunchKernelGGL((k_rollout<SRC_MASKS, false, 2, 3, true, 5, false, true, 1024, false, false, false>), dim3(grid), dim3(1024), 0, 0,
+                                               b.now, b.ever, m, r, f, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
+                if (v == 3) hipLaunchKernelGGL((k_rollout<SRC_MASKS, false, 2, 3, true, 5, false, false, 1024, false, false, false>), dim3(grid), dim3(1024), 0, 0,
+                                               b.now, b.ever, m, r, f, B, T, b.LD, b.LD, c, s, rc, ca, (uint64_t *)nullptr, 1, (uint32_t *)nullptr);
+            };
+            for (int i = 0; i < 9; i++) launch();
+            CK(hipEventRecord(b.e0, 0));
+            for (int i = 0; i < 30; i++) launch();
+            CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));
+            float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));
+            us[v] = ms * 1e3f / 30;
+        }
+        if (k < 0) printf("%-6s %12.2f %12.2f %12.2f %12.2f\n", "all", us[0], us[1], us[2], us[3]);
+        else printf("%-6d %12.2f %12.2f %12.2f %12.2f\n", k, us[0], us[1], us[2], us[3]);
+    }
+    teardown(b);
+    return 0;
+}
+
 // mode P: the policy-gradient call (rollout with flags + step-ok words, then the expansion of the words into G rows) as
 // two launches one after the other, against the same work split into env halves on two streams: rollout A, then
 // rollout B and the expansion of A side by side (a read-heavy and a write-only kernel share the chip), then the
@@ -498,6 +545,7 @@ int main(int argc, char **argv)
     if (argc >= 3 && argv[1][0] == 'P') return run_pg_split(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'T') return run_timeline(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'S') return run_timeline_small(atoll(argv[2]));
+    if (argc >= 3 && argv[1][0] == 'N') return run_nt_on_same_sets(atoll(argv[2]));
     if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F|T envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
