@@ -1006,9 +1006,19 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             stk[k] = (SRC == SRC_SYNTH) ? 0u : sticky_of(c, ee[k]);
             okb[k] = 0ull;
         }
+#ifdef BPG_TILED_EXPERIMENT
+        // tools/tune_round3 mode L only: block-tiled streams [n / tile][T][tile] with tile = ld_masks = ld_out envs -- element
+        // (t, e) at (e / tile) * T * tile + t * tile + e % tile -- instead of time-major rows (a row stride >= n selects rows)
+        const bool tiled = ld_masks < n;
+        const int64_t vt = tiled ? v / ldm : 0, vi = tiled ? v % ldm : v;
+        const Vec *mrow = reinterpret_cast<const Vec *>(masks) + vt * T * ldm + vi;
+        Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + vt * T * ldo + vi;
+        Fl *frow = reinterpret_cast<Fl *>(flags_tb) + vt * T * ldo + vi;
+#else
         const Vec *mrow = reinterpret_cast<const Vec *>(masks) + v;
         Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + v;
         Fl *frow = reinterpret_cast<Fl *>(flags_tb) + v;
+#endif
         // ubit = 1 << (step within its batch of UNROLL): the step-ok bits of a batch collect in a 32-bit word with
         // compile-time masks and join the 64-bit word once per batch (OKB)
         uint32_t okpart[EPL] = {};

@@ -9,6 +9,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -o tools/tune_round3 tools/tune_round3.hip
 //   ./tools/tune_round3 A 131072 262144 | B 65536 | C 1048576 | D 1048576
 #define BPG_TIMELINE 1       // lane 0 of every block timestamps a few points of k_rollout (mode T)
+#define BPG_TILED_EXPERIMENT 1   // mode L: block-tiled streams when the row stride passed is smaller than the batch
 #include "../blockpuzzle-gym_amd/csrc/bpgym.hip"
 
 #include <algorithm>
@@ -464,6 +465,46 @@ static int run_nt_on_same_sets(int64_t B)
     return 0;
 }
 
+// mode L: time-major rows against block-tiled streams [B / 2048][T][2048] on the SAME buffers (the bytes are the same;
+// what differs is how many pages a CU touches: 50 rows 4 MiB apart per stream, or one 400 KB piece).
+static int run_layout(int64_t B)
+{
+    Bufs b;
+    const int T = 50;
+    if (setup(b, B, T, false)) return 1;
+    const StepConst c = mk_c();
+    const SynthConst s = mk_s();
+    const ResetConst rc = mk_rc(b);
+    CountArgs ca{b.cnt, b.cnt + 1, b.shards};
+    const int grid = 256;
+    printf("== mode L  B = %lld envs, grid %d x 1024, epl2 plain unr5, %d buffer sets, all sets round-robin and each set on its own (re-launched)\n",
+           (long long)B, grid, b.NB);
+    printf("%-6s %16s %16s %16s\n", "set", "rows ld=B+256", "tiled 2048", "tiled 4096");
+    for (int k = -1; k < b.NB && k < 6; k++) {
+        float us[3];
+        for (int v = 0; v < 3; v++) {
+            const int64_t ld = v == 0 ? b.LD : (v == 1 ? 2048 : 4096);
+            int it = 0;
+            auto launch = [&]() {
+                const int kk = k < 0 ? (it++ % b.NB) : k;
+                hipLaunchKernelGGL((k_rollout<SRC_MASKS, true, 2, 3, true, 5, false, true, 1024, false, false, false>), dim3(grid), dim3(1024), 0, 0,
+                                   b.now, b.ever, b.masks[kk], b.reward[kk], b.flags[kk], B, T, ld, ld, c, s, rc, ca, (uint64_t *)nullptr, 1,
+                                   (uint32_t *)nullptr);
+            };
+            for (int i = 0; i < 9; i++) launch();
+            CK(hipEventRecord(b.e0, 0));
+            for (int i = 0; i < 30; i++) launch();
+            CK(hipEventRecord(b.e1, 0)); CK(hipEventSynchronize(b.e1));
+            float ms; CK(hipEventElapsedTime(&ms, b.e0, b.e1));
+            us[v] = ms * 1e3f / 30;
+        }
+        if (k < 0) printf("%-6s %16.2f %16.2f %16.2f\n", "all", us[0], us[1], us[2]);
+        else printf("%-6d %16.2f %16.2f %16.2f\n", k, us[0], us[1], us[2]);
+    }
+    teardown(b);
+    return 0;
+}
+
 // mode P: the policy-gradient call (rollout with flags + step-ok words, then the expansion of the words into G rows) as
 // two launches one after the other, against the same work split into env halves on two streams: rollout A, then
 // rollout B and the expansion of A side by side (a read-heavy and a write-only kernel share the chip), then the
@@ -546,6 +587,7 @@ int main(int argc, char **argv)
     if (argc >= 3 && argv[1][0] == 'T') return run_timeline(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'S') return run_timeline_small(atoll(argv[2]));
     if (argc >= 3 && argv[1][0] == 'N') return run_nt_on_same_sets(atoll(argv[2]));
+    if (argc >= 3 && argv[1][0] == 'L') return run_layout(atoll(argv[2]));
     if (argc < 3) { printf("usage: tune_round3 A|B|C|D|E|F|T envs...\n"); return 1; }
     if (argv[1][0] == 'E') return run_skew(atoll(argv[2]));
     for (int i = 2; i < argc; i++)
