@@ -707,7 +707,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
             res['rollout_masks_%d_envs' % Bx] = {'error': repr(e)[:200]}
     # ... configs[3]'s per-GPU shard with the per-env episode return the 8 GPUs all-gather (4 B/env more), and the headline
     # batch with it
-    for Bx in (524288, B):
+    for Bx in (524288, B, 4 * B):                     # 4 * B = configs[3]'s whole job on ONE GPU at the default batch
         try:
             res['rollout_masks_%d_envs_with_episode_return' % Bx] = rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line,
                                                                                episode_return=True)
