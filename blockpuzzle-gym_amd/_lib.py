@@ -101,6 +101,8 @@ SIGNATURES = {
     'bpg_step_contacts': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     'bpg_contacts_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'bpg_contacts_to_masks_tb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p]),
     'bpg_contacts_csr_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'bpg_step_record': (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
     'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

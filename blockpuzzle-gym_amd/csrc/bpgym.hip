@@ -1374,18 +1374,23 @@ k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
 // Geom-id contact lists -> packed pair masks (fetch_env.py:158-167 up to the matrix write), so
 // a backend that produces contact lists can feed the mask-based fused kernels.
 __global__ void __launch_bounds__(256)
+// T = 1, ld = n: one step's lists.  T > 1: the lists of a whole recorded rollout, time-major (T, n, maxcon, 2) / (T, n), into the
+// (T, ld) mask stream of the fused rollout; num_grey (optional): the model of env e is the one of the episode that is ABOUT
+// to be drawn (Variation picks its sim by num_objs = 4 + num_grey, fetch_env.py:647-651), not the one in the state.
 k_contacts_to_masks(const uint32_t *__restrict__ ever, const int16_t *__restrict__ contacts,
                     const int32_t *__restrict__ ncon, int maxcon, const int8_t *__restrict__ id2obj,
-                    int is_variation, uint32_t valid, uint32_t *__restrict__ out, int64_t n)
+                    int is_variation, uint32_t valid, uint32_t *__restrict__ out, int64_t n, int T, int64_t ld,
+                    const int32_t *__restrict__ num_grey)
 {
     __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
     for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, total = n * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t t = T == 1 ? 0 : i / n, e = i - t * n;
         int model = 0;
         if (is_variation) {
-            model = (int)nobj_of(ever[i]) - 4;
+            model = num_grey ? num_grey[e] : (int)nobj_of(ever[e]) - 4;
             model = model < 0 ? 0 : (model > 2 ? 2 : model);
         }
         const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
@@ -1394,7 +1399,7 @@ k_contacts_to_masks(const uint32_t *__restrict__ ever, const int16_t *__restrict
         const uint32_t *row = reinterpret_cast<const uint32_t *>(contacts) + i * maxcon;
         uint32_t m = 0;
         for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
-        out[i] = m & valid;
+        out[t * ld + e] = m & valid;
     }
 }
 
@@ -3038,7 +3043,26 @@ int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t
     DeviceGuard guard(b->device);
     hipLaunchKernelGGL(k_contacts_to_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
-                       b->n);
+                       b->n, 1, b->n, (const int32_t *)nullptr);
+    return check_launch("k_contacts_to_masks");
+}
+
+int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int T, int maxcon,
+                             const int32_t *d_num_grey, uint32_t *d_masks, int64_t ld_masks, void *stream)
+{
+    if (!b || !d_contacts || !d_ncon || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
+    if (T < 1 || T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
+    if (maxcon < 1 || maxcon > 4096) return fail(BPG_ERR_ARG, "maxcon must be in 1..4096");
+    if (!aligned4(d_contacts) || !aligned4(d_masks)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    const int64_t ld = ld_masks ? ld_masks : b->n;
+    if (ld < b->n) return fail(BPG_ERR_ARG, "ld_masks must be 0 or >= n_envs");
+    const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
+    for (int m = 0; m < models; m++)
+        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+    DeviceGuard guard(b->device);
+    hipLaunchKernelGGL(k_contacts_to_masks, dim3(grid_for(b->n * T, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
+                       d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
+                       b->n, T, ld, d_num_grey);
     return check_launch("k_contacts_to_masks");
 }
 

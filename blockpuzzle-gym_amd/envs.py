@@ -588,6 +588,27 @@ class BatchedBlocksEnv:
         _lib.check(fn(self._h, C.byref(ph), _ptr(out), int(out.stride(0)), _stream(self.device)))
         return out
 
+    def contacts_to_masks(self, pairs, ncon, num_grey=None, out=None):
+        """The contact lists of a whole recorded rollout -> the (T, B) mask stream the fused rollout reads
+        (generate_rollouts_fused(masks=...)): `pairs` (T, B, maxcon, 2) int16 geom-id pairs and `ncon` (T, B) int32, as
+        a physics trace stores sim.data.contact of every step (fetch_env.py:158-166), mapped through id2obj on the
+        device in one launch.  num_grey: the (B,) draws of the episode the trace belongs to (Variation picks the sim and
+        its id2obj table by num_objs = 4 + num_grey, fetch_env.py:647-651) when the rollout's reset has not happened
+        yet; None = the model of the env's current state.  Returns a (T, B) int32 device tensor with the row stride
+        bpg_row_stride(B)."""
+        p = self._to_dev(pairs, torch.int16)
+        nc = self._to_dev(ncon, torch.int32)
+        assert p.dim() == 4 and p.shape[1] == self.num_envs and p.shape[3] == 2 and nc.shape == p.shape[:2]
+        T, maxcon = int(p.shape[0]), int(p.shape[2])
+        ng = self._to_dev(num_grey, torch.int32)
+        if out is None:
+            ld = int(self._L.bpg_row_stride(self.num_envs))
+            out = torch.empty((T, ld), dtype=torch.int32, device=self.device)[:, :self.num_envs]
+        assert out.shape == (T, self.num_envs) and out.stride(1) == 1 and out.element_size() == 4
+        _lib.check(self._L.bpg_contacts_to_masks_tb(self._h, _ptr(p), _ptr(nc), T, maxcon, _ptr(ng), _ptr(out),
+                                                    int(out.stride(0)) if T > 1 else self.num_envs, _stream(self.device)))
+        return out
+
     def randomize_objects(self, test=False, grip_xy=(1.3419, 0.7491), variates=None, out=None, status=None,
                           env_mask=None):
         """_randomize_objects for the whole batch (fetch_env.py:328-336, 370-399, 448-517,

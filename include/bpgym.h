@@ -176,6 +176,14 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
 int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
                           uint32_t *d_masks, void *stream);
 
+/* The lists of a whole recorded rollout at once -- d_contacts (T, n_envs, maxcon, 2) int16 and d_ncon (T, n_envs), time-major,
+ * as a physics trace stores sim.data.contact of every step -- into the (T, ld_masks) mask stream bpg_rollout reads
+ * (ld_masks = 0: contiguous rows).  d_num_grey (n_envs, optional): Variation picks the sim, and with it the id2obj table,
+ * of an episode by num_objs = 4 + num_grey (fetch_env.py:647-651); pass the draws of the episode the trace belongs to when
+ * the conversion runs BEFORE that episode's reset (bpg_rollout with reset_first), NULL = the model of the current state. */
+int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int T, int maxcon,
+                             const int32_t *d_num_grey, uint32_t *d_masks, int64_t ld_masks, void *stream);
+
 /* The same from RAGGED contact lists (CSR): env e owns contacts d_offsets[e] .. d_offsets[e+1]-1
  * (int64, n_envs+1 entries, non-decreasing) of one packed d_pairs[total][2] int16 geom-id array --
  * sim.data.contact of every env compacted instead of padded to the longest list.  Offsets are

@@ -108,9 +108,17 @@ def test_golden_rollout_fused(env_id):
     worker = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
                                 dims_of(env_id), None, T, rollout_batch_size=B)
     for r, test in enumerate(d['modes']):
+        # the reference's contact lists (geom-id pairs of every step) -> the mask stream, on the device, in one launch
+        # (env.contacts_to_masks: the model of each env is the one of the episode about to be drawn); the oracle's
+        # host-side conversion is only the cross-check
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        num_grey = d['r%d_num_objs' % r] - 4
+        dmasks = worker.env.contacts_to_masks(np.ascontiguousarray(con.transpose(1, 0, 2, 3)),
+                                              np.ascontiguousarray(d['r%d_ncon' % r].T), num_grey=num_grey)
         masks = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
-        ep = worker.generate_rollouts_fused(test=bool(test), masks=i32(masks),
-                                            num_grey=d['r%d_num_objs' % r] - 4)
+        np.testing.assert_array_equal(dmasks.cpu().numpy().view(np.uint32), masks)
+        ep = worker.generate_rollouts_fused(test=bool(test), masks=dmasks, num_grey=num_grey)
         for k in ('ag', 'g', 'info_is_success'):
             np.testing.assert_array_equal(ep[k], d['r%d_%s' % (r, k)], err_msg=k)
         assert worker.success_history[-1] == pytest.approx(float(d['r%d_success_rate' % r]), abs=1e-7)

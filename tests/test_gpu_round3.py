@@ -192,8 +192,14 @@ def test_golden_pg_return_from_the_fused_call(name):
     worker = bpg.PGRolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None, None,
                                   dims_of(env_id), None, T, rollout_batch_size=B, gamma=1. - 1. / T)
     for r in range(len(d['modes'])):
+        # the recorded contact lists -> masks on the device (env.contacts_to_masks); the oracle's conversion cross-checks it
+        con = d['r%d_contacts' % r].copy()
+        con[con < 0] = 0
+        dmasks = worker.env.contacts_to_masks(np.ascontiguousarray(con.transpose(1, 0, 2, 3)),
+                                              np.ascontiguousarray(d['r%d_ncon' % r].T), num_grey=d['r%d_num_objs' % r] - 4)
         masks = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
-        ep = worker.generate_rollouts_fused(masks=i32(masks), num_grey=d['r%d_num_objs' % r] - 4)
+        np.testing.assert_array_equal(dmasks.cpu().numpy().view(np.uint32), masks)
+        ep = worker.generate_rollouts_fused(masks=dmasks, num_grey=d['r%d_num_objs' % r] - 4)
         assert ep['G'].dtype == np.float64
         same_bits(ep['G'], d['r%d_G' % r])
         np.testing.assert_array_equal(ep['ag'], d['r%d_ag' % r])
