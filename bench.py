@@ -949,6 +949,17 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     except Exception as e:  # noqa: BLE001
         res['episode_writer_f32'] = {'error': repr(e)[:200]}
 
+    # (4b) the batch as S env shards on S streams of the one GPU (distributed.StreamShards): the same partition that spreads a
+    # job over GPUs, once more inside one -- independent launches that the hardware runs side by side, so that one shard's
+    # ramp-up and drain are covered by the others' streaming.  K rollouts per shard back to back, nothing joins the shards
+    # in between; ms = wall time per rollout of ALL shards (the same env-steps and bytes as the headline launch).
+    try:
+        from blockpuzzle_gym_amd import distributed as D
+        for tot, S in ((B, 4), (524288, 2)):
+            res['rollout_masks_%d_envs_as_%d_shards_on_%d_streams' % (tot, S, S)] = shards_on_streams(torch, _lib, D, tot, S, T, dev, line)
+    except Exception as e:  # noqa: BLE001
+        res['rollout_masks_as_shards_on_streams'] = {'error': repr(e)[:300]}
+
     # (5) BASELINE configs[4]: the rollout worker with a policy in the loop
     for Bx in (65536, B):
         try:
@@ -956,6 +967,49 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         except Exception as e:  # noqa: BLE001
             res['rollout_policy_in_loop_%d_envs' % Bx] = {'error': repr(e)[:300]}
     return res
+
+
+def shards_on_streams(torch, _lib, D, total, S, T, dev, line, reps=120):
+    L = _lib.lib()
+    sh = D.StreamShards(ENV_ID, total, S, device=dev, seed=7)
+    nset = max(4, int(2.5 * 256 * 2**20 // (total * T * 9)) + 1)
+    per = []
+    for i, (env, st) in enumerate(sh.shards):
+        with torch.cuda.stream(st):
+            cs = C.c_void_p(st.cuda_stream)
+            n = env.num_envs
+            ng = ((torch.arange(n, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
+            ld = int(L.bpg_row_stride(n))
+            sets = []
+            for k in range(nset):
+                env.seed(7 + k)
+                m = torch.empty((T, ld), dtype=torch.int32, device=dev)[:, :n]
+                _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(m.data_ptr()), ld, cs))
+                sets.append((m, torch.empty((T, ld), dtype=torch.float32, device=dev)[:, :n],
+                             torch.empty((T, ld), dtype=torch.uint8, device=dev)[:, :n]))
+            cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+            args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(),
+                                     d_flags_tb=f.data_ptr(), ld_masks=ld, ld_out=ld, d_success_count=cnt.data_ptr()) for m, r, f in sets]
+            per.append((env, cs, args, (ng, sets, cnt)))
+    torch.cuda.synchronize(dev)
+
+    def run(n):
+        for i in range(n):
+            for env, cs, args, _ in per:
+                _lib.check(L.bpg_rollout(env._h, C.byref(args[i % nset]), cs))
+    run(40)
+    torch.cuda.synchronize(dev)
+    best = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(reps)
+        torch.cuda.synchronize(dev)
+        best.append((time.perf_counter() - t0) / reps * 1e3)
+    out = line(min(best), total * (T * 9 + 12), total * T)
+    out.update(shards=S, envs_per_shard=[e.num_envs for e, _ in sh.shards], runs_ms=best, buffer_sets_per_shard=nset,
+               note='wall time per rollout of all shards over %d rollouts per shard back to back (min of 3 runs); launches of '
+                    'different shards overlap, so no per-launch duration is quoted' % reps)
+    return out
 
 
 def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1, episode_return=False):

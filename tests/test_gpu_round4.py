@@ -470,3 +470,53 @@ def test_per_step_rollouts_accumulate_the_same_episode_return(env_id):
     big.future_field = 5
     assert L.bpg_step_record(env._h, ptr, None) == bpg._lib.ERR_UNSUPPORTED
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('total,S', [(1048576, 4), (524288 + 6, 2), (1003, 3)])
+def test_stream_shards_of_one_gpu_equal_one_batch(total, S):
+    """distributed.StreamShards: S env shards on one GPU, each on its own stream, keyed by global env index -- their
+    rollouts (launched side by side, nothing synchronises them between rollouts) write the slices of ONE set of arrays
+    that a single `total`-env handle writes: reward, flags, episode return, success counts, final state."""
+    from blockpuzzle_gym_amd import distributed as D
+    T = 50
+    one = bpg.make(ENV_ID, num_envs=total, device=DEV, seed=21)
+    sh = D.StreamShards(ENV_ID, total, S, device=DEV, seed=21)
+    assert len(sh) == S and sum(e.num_envs for e, _ in sh.shards) == total
+    ld = int(L.bpg_row_stride(total))
+    masks = torch.empty((T, ld), dtype=torch.int32, device=DEV)[:, :total]
+    ng = (torch.arange(total, device=DEV, dtype=torch.int32) * 5) % 3
+    outs = []
+    for who in ('one', 'shards'):
+        rew = torch.empty((T, ld), dtype=torch.float32, device=DEV)[:, :total]
+        flg = torch.empty((T, ld), dtype=torch.uint8, device=DEV)[:, :total]
+        ret = torch.empty(total, dtype=torch.float32, device=DEV)
+        cnt = torch.zeros(3 * max(S, 1), dtype=torch.int64, device=DEV)
+        for it in range(3):                          # three rollouts back to back: the shards never wait for each other
+            one.seed(21 + it)
+            bpg._lib.check(L.bpg_synth_masks_ld(one._h, 0, T, P(masks), ld, None))
+            torch.cuda.synchronize()
+            if who == 'one':
+                a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld,
+                                         d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(), d_episode_return=ret.data_ptr(),
+                                         d_success_count=cnt[it:].data_ptr())
+                bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+            else:
+                def go(i, env, st):
+                    lo = sh.first[i]
+                    a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng[lo:].data_ptr(), d_masks=masks[:, lo:].data_ptr(),
+                                             ld_masks=ld, ld_out=ld, d_reward_tb=rew[:, lo:].data_ptr(), d_flags_tb=flg[:, lo:].data_ptr(),
+                                             d_episode_return=ret[lo:].data_ptr(), d_success_count=cnt[it * S + i:].data_ptr())
+                    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), C.c_void_p(st.cuda_stream)))
+                sh.fork()                            # the masks were written on the current stream
+                sh.for_each(go)
+                sh.join()
+            torch.cuda.synchronize()
+        if who == 'one':
+            outs.append((rew.clone(), flg.clone(), ret.clone(), cnt[:3].clone(), one.state_now.clone(), one.state_ever.clone()))
+        else:
+            now = torch.cat([e.state_now for e, _ in sh.shards])
+            ever = torch.cat([e.state_ever for e, _ in sh.shards])
+            outs.append((rew.clone(), flg.clone(), ret.clone(), cnt[:3 * S].reshape(3, S).sum(1), now, ever))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.uint8) if a.dtype == torch.float32 else a, b.view(torch.uint8) if b.dtype == torch.float32 else b)
+    assert int(outs[0][3][0]) > 0 and bool(torch.signbit(outs[0][2]).all())
