@@ -777,24 +777,49 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
     del agrec, succ_f
 
     # (1b) one env.step launch with the contacts as the reference reads them: geom-id pair lists
-    # (B, maxcon=16, 2) int16 + ncon; bytes = 8 state + 4 ncon + 64 list in, 13 out = 89 B/env-step
+    # (B, maxcon=16, 2) int16 + ncon; bytes = 8 state + 4 ncon + 64 list in, 13 out = 89 B/env-step; eight list sets in
+    # rotation, so the lists come from HBM (the 8 MB of state stay cache-resident)
     try:
         maxcon = 16
         names = bpg.default_geom_names(ENV_ID)[2]
         objs = [i for i, n in enumerate(names) if n and (n == 'table' or n.startswith('object') or 'finger' in n)]
         gsel = torch.tensor(objs, dtype=torch.int16, device=dev)
-        idx = torch.randint(0, len(objs), (B, maxcon, 2), device=dev)
-        pairs = gsel[idx].contiguous()
-        ncon = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev)
+        csets = [(gsel[torch.randint(0, len(objs), (B, maxcon, 2), device=dev)].contiguous(),
+                  torch.randint(0, 9, (B,), dtype=torch.int32, device=dev)) for _ in range(8)]
+        c_it = [0]
 
         def step_contacts():
+            pairs, ncon = csets[c_it[0] % len(csets)]
+            c_it[0] += 1
             _lib.check(L.bpg_step_contacts(env._h, C.c_void_p(pairs.data_ptr()), C.c_void_p(ncon.data_ptr()),
                                            maxcon, C.c_void_p(reward.data_ptr()), C.c_void_p(flags.data_ptr()),
                                            stream))
-        res['step_contacts_single_launch'] = line(timed(step_contacts, 100), 89 * B, B, cache_resident=True)
-        del pairs, ncon, idx
+        res['step_contacts_single_launch'] = line(timed(step_contacts, 96), 89 * B, B)
+        del csets
     except Exception as e:  # noqa: BLE001
         res['step_contacts_single_launch'] = {'error': repr(e)[:200]}
+
+    # (1c) the contact lists of a whole recorded rollout -> the fused rollout's mask stream (bpg_contacts_to_masks_tb):
+    # (T, n, 16, 2) int16 + (T, n) int32 in, (T, LD) masks out; 262 144 envs = 0.94 GB of lists per set, two sets
+    try:
+        nrec, maxcon = 262144, 16
+        erec = bpg.make(ENV_ID, num_envs=nrec, device=dev, seed=7)
+        ngr = (torch.arange(nrec, device=dev, dtype=torch.int32) * 7) % 3
+        tb = [(gsel[torch.randint(0, len(objs), (T, nrec, maxcon, 2), device=dev)].contiguous(),
+               torch.randint(0, 9, (T, nrec), dtype=torch.int32, device=dev), bpg.time_major_empty(T, nrec, torch.int32, dev))
+              for _ in range(2)]
+        t_it = [0]
+
+        def lists_to_masks():
+            p_, c_, m_ = tb[t_it[0] % 2]
+            t_it[0] += 1
+            _lib.check(L.bpg_contacts_to_masks_tb(erec._h, C.c_void_p(p_.data_ptr()), C.c_void_p(c_.data_ptr()), T, maxcon,
+                                                  C.c_void_p(ngr.data_ptr()), C.c_void_p(m_.data_ptr()), int(m_.stride(0)), stream))
+        res['contacts_to_masks_recorded_rollout_262144_envs'] = line(timed(lists_to_masks, 8), T * nrec * (4 * maxcon + 8) + 4 * nrec, nrec * T)
+        del tb, erec
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        res['contacts_to_masks_recorded_rollout_262144_envs'] = {'error': repr(e)[:200]}
 
     # (2) the same T steps as T launches replayed from a hipGraph (25 B/env-step, streams from HBM,
     # the 8 MB of state cache-resident between the launches)

@@ -636,73 +636,58 @@ __device__ __forceinline__ uint32_t pair_bit_of(const int8_t *tab, uint32_t pr)
     return 0u;
 }
 
-// STAGED: the block's 256 contact rows are one contiguous tile; it is brought into LDS
-// with 16-byte-per-lane coalesced loads (row stride padded to maxcon+1 dwords, so the
-// per-lane row walk that follows is bank-conflict free) instead of 64 lanes each
-// striding through their own row.  Needs maxcon % 4 == 0 and a 16-byte aligned list.
-template <bool STAGED>
+// The pair mask of one padded list row.  VW = 4: the row is walked in 16-byte steps -- every lane strides through a row
+// of its own, so a wave's load touches 64 cache lines whatever its width, and it is the number of such loads, not the
+// bytes, that bounds the walk (dword steps: 0.40 of the HBM peak at maxcon = 16; 16-byte steps:
+// profiles/r04_contacts_to_masks.log).  Needs maxcon % 4 == 0 and a 16-byte aligned list.
+template <int VW>
+__device__ __forceinline__ uint32_t row_pair_mask(const int8_t *tab, const uint32_t *row, int nc)
+{
+    uint32_t m = 0;
+    if (VW == 4) {
+        const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+        for (int k = 0; k < nc; k += 4) {
+            const uint4 v = row4[k >> 2];
+            m |= pair_bit_of(tab, v.x);
+            if (k + 1 < nc) m |= pair_bit_of(tab, v.y);
+            if (k + 2 < nc) m |= pair_bit_of(tab, v.z);
+            if (k + 3 < nc) m |= pair_bit_of(tab, v.w);
+        }
+    } else {
+        for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
+    }
+    return m;
+}
+
+// One env per lane; the id2obj tables live in LDS.  (Round 2 staged the block's 256 rows through LDS with coalesced
+// 16-byte loads; the 16-byte row walk of row_pair_mask<4> is as fast or faster at every list length -- 1 M envs,
+// maxcon 8 / 16 / 32: 14.6 / 19.6 / 28.4 us against 16.2 / 19.9 / 33.9 staged and 20.1 / 29.1 / 50.0 with dword steps,
+// profiles/r04_contacts_to_masks.log -- and needs no tile.)
+template <int VW>
 __global__ void __launch_bounds__(256)
 k_step_contacts(uint32_t *__restrict__ now, uint32_t *__restrict__ ever,
                 const int16_t *__restrict__ contacts, const int32_t *__restrict__ ncon, int maxcon,
                 const int8_t *__restrict__ id2obj, int is_variation,
                 uint32_t *__restrict__ reward, uint8_t *__restrict__ flags, int64_t n, StepConst c)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int8_t *s_tab = reinterpret_cast<int8_t *>(smem);                        // [MODELS][GEOMS]
-    uint32_t *s_con = reinterpret_cast<uint32_t *>(smem + BPG_MAX_MODELS * BPG_MAX_GEOMS);
+    __shared__ int8_t s_tab[BPG_MAX_MODELS * BPG_MAX_GEOMS];
     for (int k = threadIdx.x; k < BPG_MAX_MODELS * BPG_MAX_GEOMS; k += blockDim.x) s_tab[k] = id2obj[k];
-    const int ldc = maxcon + 1;
-    const int64_t nblocks = (n + 255) / 256;
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int64_t base = blk * 256;
-        const int rows = (int)((n - base) < 256 ? (n - base) : 256);
-        const uint32_t *tile = reinterpret_cast<const uint32_t *>(contacts) + base * maxcon;
-        if (STAGED) {
-            __syncthreads();                                   // previous tile fully consumed
-            const int nq = rows * maxcon / 4;
-            const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);
-            constexpr int SC_U = 4;                              // requests in flight per lane
-            for (int q0 = threadIdx.x; q0 < nq; q0 += 256 * SC_U) {
-                uint4 v[SC_U];
-#pragma unroll
-                for (int u = 0; u < SC_U; u++)
-                    if (q0 + u * 256 < nq) v[u] = t4[q0 + u * 256];
-#pragma unroll
-                for (int u = 0; u < SC_U; u++) {
-                    const int q = q0 + u * 256;
-                    if (q < nq) {
-                        const int d = 4 * q, r = d / maxcon, col = d - r * maxcon;
-                        uint32_t *dst = s_con + r * ldc + col;
-                        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
-                    }
-                }
-            }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t a = now[i], e = ever[i], rb, fl;
+        int model = 0;
+        if (is_variation) {
+            model = (int)nobj_of(e) - 4;                   // fetch_env.py:650-651
+            model = model < 0 ? 0 : (model > 2 ? 2 : model);
         }
-        __syncthreads();
-        if ((int)threadIdx.x < rows) {
-            const int64_t i = base + threadIdx.x;
-            uint32_t a = now[i], e = ever[i], rb, fl;
-            int model = 0;
-            if (is_variation) {
-                model = (int)nobj_of(e) - 4;                   // fetch_env.py:650-651
-                model = model < 0 ? 0 : (model > 2 ? 2 : model);
-            }
-            const int8_t *tab = s_tab + model * BPG_MAX_GEOMS;
-            int nc = ncon[i];
-            nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
-            uint32_t m = 0;
-            if (STAGED) {
-                const uint32_t *row = s_con + threadIdx.x * ldc;
-                for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
-            } else {
-                const uint32_t *row = tile + (int64_t)threadIdx.x * maxcon;
-                for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
-            }
-            step_core(a, e, m, c, rb, fl);
-            now[i] = a; ever[i] = e;
-            if (reward) reward[i] = rb;
-            if (flags) flags[i] = (uint8_t)fl;
-        }
+        int nc = ncon[i];
+        nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
+        const uint32_t m = row_pair_mask<VW>(s_tab + model * BPG_MAX_GEOMS, reinterpret_cast<const uint32_t *>(contacts) + i * maxcon, nc);
+        step_core(a, e, m, c, rb, fl);
+        now[i] = a; ever[i] = e;
+        if (reward) reward[i] = rb;
+        if (flags) flags[i] = (uint8_t)fl;
     }
 }
 
@@ -1373,6 +1358,7 @@ k_step_record(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uin
 
 // Geom-id contact lists -> packed pair masks (fetch_env.py:158-167 up to the matrix write), so
 // a backend that produces contact lists can feed the mask-based fused kernels.
+template <int VW>
 __global__ void __launch_bounds__(256)
 // T = 1, ld = n: one step's lists.  T > 1: the lists of a whole recorded rollout, time-major (T, n, maxcon, 2) / (T, n), into the
 // (T, ld) mask stream of the fused rollout; num_grey (optional): the model of env e is the one of the episode that is ABOUT
@@ -1397,9 +1383,7 @@ k_contacts_to_masks(const uint32_t *__restrict__ ever, const int16_t *__restrict
         int nc = ncon[i];
         nc = nc < 0 ? 0 : (nc > maxcon ? maxcon : nc);
         const uint32_t *row = reinterpret_cast<const uint32_t *>(contacts) + i * maxcon;
-        uint32_t m = 0;
-        for (int k = 0; k < nc; k++) m |= pair_bit_of(tab, row[k]);
-        out[t * ld + e] = m & valid;
+        out[t * ld + e] = row_pair_mask<VW>(tab, row, nc) & valid;
     }
 }
 
@@ -3015,20 +2999,27 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
     for (int m = 0; m < models; m++)
         if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
-    const int64_t nblocks = (b->n + 255) / 256;
-    const dim3 grid((unsigned)(nblocks < 4096 ? nblocks : 4096)), block(256);
-    const size_t tab_bytes = BPG_MAX_MODELS * BPG_MAX_GEOMS;
-    const size_t staged_lds = tab_bytes + (size_t)256 * (maxcon + 1) * sizeof(uint32_t);
-    const bool staged = (maxcon % 4 == 0) && staged_lds <= 64 * 1024 && aligned16(d_contacts);
-    if (staged)
-        hipLaunchKernelGGL(k_step_contacts<true>, grid, block, staged_lds, (hipStream_t)stream, b->now, b->ever,
-                           d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
-                           reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
+    const dim3 grid(grid_for(b->n, 256, 4096)), block(256);
+    if (maxcon % 4 == 0 && aligned16(d_contacts))
+        hipLaunchKernelGGL(k_step_contacts<4>, grid, block, 0, (hipStream_t)stream, b->now, b->ever, d_contacts, d_ncon, maxcon,
+                           b->d_id2obj, b->info.is_variation, reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
     else
-        hipLaunchKernelGGL(k_step_contacts<false>, grid, block, tab_bytes, (hipStream_t)stream, b->now, b->ever,
-                           d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation,
-                           reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
+        hipLaunchKernelGGL(k_step_contacts<1>, grid, block, 0, (hipStream_t)stream, b->now, b->ever, d_contacts, d_ncon, maxcon,
+                           b->d_id2obj, b->info.is_variation, reinterpret_cast<uint32_t *>(d_reward), d_flags, b->n, step_const(b));
     return check_launch("k_step_contacts");
+}
+
+static int launch_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
+                                    uint32_t *d_masks, int T, int64_t ld, const int32_t *d_num_grey, hipStream_t st)
+{
+    const dim3 grid(grid_for(b->n * T, 256)), block(256);
+    if (maxcon % 4 == 0 && aligned16(d_contacts))
+        hipLaunchKernelGGL(k_contacts_to_masks<4>, grid, block, 0, st, b->ever, d_contacts, d_ncon, maxcon, b->d_id2obj,
+                           b->info.is_variation, b->info.valid_pairs, d_masks, b->n, T, ld, d_num_grey);
+    else
+        hipLaunchKernelGGL(k_contacts_to_masks<1>, grid, block, 0, st, b->ever, d_contacts, d_ncon, maxcon, b->d_id2obj,
+                           b->info.is_variation, b->info.valid_pairs, d_masks, b->n, T, ld, d_num_grey);
+    return check_launch("k_contacts_to_masks");
 }
 
 int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int maxcon,
@@ -3041,10 +3032,7 @@ int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t
     for (int m = 0; m < models; m++)
         if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_contacts_to_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
-                       d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
-                       b->n, 1, b->n, (const int32_t *)nullptr);
-    return check_launch("k_contacts_to_masks");
+    return launch_contacts_to_masks(b, d_contacts, d_ncon, maxcon, d_masks, 1, b->n, nullptr, (hipStream_t)stream);
 }
 
 int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_ncon, int T, int maxcon,
@@ -3060,10 +3048,7 @@ int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int3
     for (int m = 0; m < models; m++)
         if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
-    hipLaunchKernelGGL(k_contacts_to_masks, dim3(grid_for(b->n * T, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
-                       d_contacts, d_ncon, maxcon, b->d_id2obj, b->info.is_variation, b->info.valid_pairs, d_masks,
-                       b->n, T, ld, d_num_grey);
-    return check_launch("k_contacts_to_masks");
+    return launch_contacts_to_masks(b, d_contacts, d_ncon, maxcon, d_masks, T, ld, d_num_grey, (hipStream_t)stream);
 }
 
 int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_t *d_offsets, int64_t total,

@@ -520,3 +520,54 @@ def test_stream_shards_of_one_gpu_equal_one_batch(total, S):
     for a, b in zip(*outs):
         assert torch.equal(a.view(torch.uint8) if a.dtype == torch.float32 else a, b.view(torch.uint8) if b.dtype == torch.float32 else b)
     assert int(outs[0][3][0]) > 0 and bool(torch.signbit(outs[0][2]).all())
+
+
+@pytest.mark.parametrize('maxcon', [1, 3, 4, 6, 8, 12, 16, 20])
+@pytest.mark.parametrize('shift', [0, 2])
+def test_contact_list_walk_at_every_length_and_alignment(maxcon, shift):
+    """The per-lane walk of a padded contact list row (row_pair_mask: 16-byte steps when maxcon % 4 == 0 and the list is
+    16-byte aligned, dword steps otherwise) against the oracle's list -> mask conversion: every ncon from 0 to maxcon
+    (lengths that end inside a 16-byte step), entries past ncon filled with pairs that WOULD set bits if they were read,
+    list base 16-byte aligned and 4 bytes off -- through bpg_contacts_to_masks, bpg_contacts_to_masks_tb and
+    bpg_step_contacts."""
+    v = VARIANTS[ENV_ID]
+    T, n = 3, 2 * 64 * (maxcon + 1) + 5
+    rng = np.random.RandomState(maxcon * 7 + shift)
+    num_grey = rng.randint(3, size=n).astype(np.int32)
+    ngeom = np.array([len(v['models'][m]['id2obj']) for m in num_grey])
+    ncon = ((np.arange(T * n) * 5 + rng.randint(2)) % (maxcon + 1)).astype(np.int32).reshape(T, n)
+    ncon[0, :4] = [-3, maxcon + 7, 0, maxcon]                    # clamped to 0 .. maxcon (sanitised input)
+    pairs = (rng.randint(0, 1 << 30, size=(T, n, maxcon, 2)) % ngeom[None, :, None, None]).astype(np.int16)
+    flat = torch.zeros(pairs.size + 8 + shift, dtype=torch.int16, device=DEV)
+    off = (-(flat.data_ptr() // 2) % 8 + shift) % 8 if shift else (-(flat.data_ptr() // 2)) % 8
+    dp = flat[off:off + pairs.size].view(T, n, maxcon, 2)
+    assert dp.data_ptr() % 16 == (4 if shift else 0)
+    dp.copy_(torch.as_tensor(pairs))
+    dn = torch.as_tensor(ncon, device=DEV)
+    ng = torch.as_tensor(num_grey, device=DEV)
+    nc_eff = np.clip(ncon, 0, maxcon)
+    exp = np.zeros((T, n), np.uint32)
+    for t in range(T):
+        for e in range(n):
+            exp[t, e] = O.contacts_to_mask(v['models'][int(num_grey[e])]['id2obj'], pairs[t, e, :nc_eff[t, e]])
+    env = bpg.make(ENV_ID, num_envs=n, device=DEV, seed=2)
+    # whole recorded rollout: the model of env e is the one of the episode about to be drawn (num_grey)
+    tb = bpg.time_major_empty(T, n, torch.int32, DEV)
+    tb.fill_(-1)
+    bpg._lib.check(L.bpg_contacts_to_masks_tb(env._h, P(dp), P(dn), T, maxcon, P(ng), P(tb), int(tb.stride(0)), None))
+    np.testing.assert_array_equal(tb.cpu().numpy().view(np.uint32), exp)
+    # one step's lists, model from the state
+    env.reset(num_grey=ng)
+    one = torch.empty(n, dtype=torch.int32, device=DEV)
+    bpg._lib.check(L.bpg_contacts_to_masks(env._h, P(dp[1]), P(dn[1]), maxcon, P(one), None))
+    np.testing.assert_array_equal(one.cpu().numpy().view(np.uint32), exp[1])
+    # the step from lists == the step from the masks just checked
+    ref = bpg.make(ENV_ID, num_envs=n, device=DEV, seed=2)
+    ref.reset(num_grey=ng)
+    r = [torch.empty(n, dtype=torch.float32, device=DEV) for _ in range(2)]
+    f = [torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(2)]
+    for t in range(T):
+        bpg._lib.check(L.bpg_step_contacts(env._h, P(dp[t]), P(dn[t]), maxcon, P(r[0]), P(f[0]), None))
+        bpg._lib.check(L.bpg_step_masks(ref._h, P(tb[t]), P(r[1]), P(f[1]), None))
+        assert torch.equal(r[0].view(torch.int32), r[1].view(torch.int32)) and torch.equal(f[0], f[1])
+    assert torch.equal(env.state_now, ref.state_now) and torch.equal(env.state_ever, ref.state_ever)

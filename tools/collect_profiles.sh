@@ -7,7 +7,7 @@ set -o pipefail
 OUT=gpurun_out/${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-KERN="rollout rollout64k rollout128k rollout256k synth pg step record return scan episode reward assemble nan reset trim multi64k rolloutret"
+KERN="rollout rollout64k rollout128k rollout256k synth pg step record return scan episode reward assemble nan reset trim multi64k rolloutret contacts"
 KERN2="rollout512k rollout4m multi1m rolloutret512k"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bench" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace_bench.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_headline" -- python3 bench.py --no-extras --no-cpu-baseline --no-stride-probe > "$OUT/bench_headline_under_rocprof.json" 2> "$OUT/trace_headline.err" || exit 1

@@ -202,6 +202,32 @@ def main():
             for i in range(13):
                 env.reset(num_grey=ng, observation_out=obs[i % 3])
             torch.cuda.synchronize()
+        elif w == 'contacts':
+            # geom-id pair lists (maxcon 16): one step at 1 M envs over 8 list sets (HBM-cold), and the lists of a recorded
+            # rollout (T = 50, 262 144 envs, 0.94 GB per set, 2 sets) into the fused rollout's mask stream
+            maxcon = 16
+            names = bpg.default_geom_names(ENV_ID)[2]
+            objs = [i for i, nm in enumerate(names) if nm and (nm == 'table' or nm.startswith('object') or 'finger' in nm)]
+            gsel = torch.tensor(objs, dtype=torch.int16, device=DEV)
+            env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
+            env.reset()
+            sets = [(gsel[torch.randint(0, len(objs), (B, maxcon, 2), device=DEV)].contiguous(),
+                     torch.randint(0, 9, (B,), dtype=torch.int32, device=DEV)) for _ in range(8)]
+            r, f = torch.empty(B, dtype=torch.float32, device=DEV), torch.empty(B, dtype=torch.uint8, device=DEV)
+            for i in range(24):
+                p_, c_ = sets[i % 8]
+                _lib.check(L.bpg_step_contacts(env._h, P(p_), P(c_), maxcon, P(r), P(f), None))
+            torch.cuda.synchronize()
+            del sets
+            n = 262144
+            e2 = bpg.make(ENV_ID, num_envs=n, device=DEV, seed=1)
+            ng = (torch.arange(n, device=DEV, dtype=torch.int32) * 7) % 3
+            tb = [(gsel[torch.randint(0, len(objs), (T, n, maxcon, 2), device=DEV)].contiguous(),
+                   torch.randint(0, 9, (T, n), dtype=torch.int32, device=DEV), TM(n, torch.int32)) for _ in range(2)]
+            for i in range(8):
+                p_, c_, m_ = tb[i % 2]
+                _lib.check(L.bpg_contacts_to_masks_tb(e2._h, P(p_), P(c_), T, maxcon, P(ng), P(m_), int(m_.stride(0)), None))
+            torch.cuda.synchronize()
         elif w == 'nan':
             x = torch.zeros(4, B, 87, dtype=torch.float32, device=DEV)
             flag = torch.zeros(1, dtype=torch.int32, device=DEV)

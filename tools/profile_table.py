@@ -28,6 +28,8 @@ ROWS = [
     ('k_step_record', '`k_step_record<6>`', 'step + f32 `achieved_goal` row + f32 `is_success`'),
     ('k_episode', '`k_episode<6>`', 'reset + 50 steps + float32 episode arrays'),
     ('k_trim_variation', '`k_trim<variation>`', "the expert's inputs of one pg step (87 → 40 f64, 2 × 36 → 16)"),
+    ('k_step_contacts', '`k_step_contacts<4>`', 'one step from geom-id pair lists (maxcon 16), lists HBM-cold'),
+    ('k_contacts_to_masks_tb', '`k_contacts_to_masks<4>`', 'a recorded rollout\'s lists (T = 50, 262 144 envs, maxcon 16) → mask stream'),
     ('k_compute_reward_f32', '`k_compute_reward_f32`', "4 M rows of 36 floats, NumPy's summation order"),
     ('k_assemble_obs_f32', '`k_assemble_obs<float, 4>`', '`_get_obs` rows of 1 M Variation envs'),
     ('k_nan_flag', '`k_nan_flag`', 'NaN check of 1 M × 87 floats'),

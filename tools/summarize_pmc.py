@@ -86,6 +86,8 @@ KERNELS = [
     ('k_set_action', None, 'k_set_action', 'read16', 16 * B, 72 * B, ''),
     ('k_nan_flag<true>', None, 'k_nan_flag', 'read16', B * 4 * 87, 0, ''),
     ('k_trim<true>', None, 'k_trim_variation', 'read16', B * 4 * (87 + 2 * 36), B * (8 * 40 + 2 * 4 * 16), ''),
+    ('k_step_contacts<4>', None, 'k_step_contacts', 'read16', B * (8 + 4 + 64), 13 * B, ''),
+    ('k_contacts_to_masks<4>', None, 'k_contacts_to_masks_tb', 'read16', T * 262144 * (64 + 4) + 4 * 262144, 4 * T * 262144, ''),
     ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, true, false>', 65536, 'k_rollout_masks_65536_x10', 'read4') + roll_k(65536) + ('',),
     ('k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, true, false>', 256 * 1024, 'k_rollout_masks_x10', 'read8') + roll_k(B) + ('2',),
 ]
