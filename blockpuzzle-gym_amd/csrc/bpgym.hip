@@ -2038,75 +2038,88 @@ k_trim(const float *__restrict__ o, const float *__restrict__ g, const float *__
 // sums achieved_goal * goal that way, in the arrays' own precision, so for rows that are not ternary the ORDER
 // decides whether d == c.  Products and sums are rounded separately (FP_CONTRACT off).
 template <typename F>
-__device__ __forceinline__ F cr_block_dot(const F *ra, const F *rg, int n)          // n <= 128
+__device__ __forceinline__ F cr_block_sum(const F *p, int n)          // n <= 128; p = the products, already rounded
 {
     if (n < 8) {
         F res = (F)0;
-        for (int i = 0; i < n; i++) res = res + ra[i] * rg[i];
+        for (int i = 0; i < n; i++) res = res + p[i];
         return res;
     }
     F r[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = ra[j] * rg[j];
+    for (int j = 0; j < 8; j++) r[j] = p[j];
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = r[j] + ra[i + j] * rg[i + j];
+        for (int j = 0; j < 8; j++) r[j] = r[j] + p[i + j];
     }
     F res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + ra[i] * rg[i];
+    for (; i < n; i++) res = res + p[i];
     return res;
 }
 
 template <typename F>
-__device__ __forceinline__ F cr_half_dot(const F *ra, const F *rg, int n)           // n <= 256: at most one more split
+__device__ __forceinline__ F cr_half_sum(const F *p, int n)           // n <= 256: at most one more split
 {
-    if (n <= 128) return cr_block_dot(ra, rg, n);
+    if (n <= 128) return cr_block_sum(p, n);
     int n2 = n / 2;
     n2 -= n2 % 8;
-    return cr_block_dot(ra, rg, n2) + cr_block_dot(ra + n2, rg + n2, n - n2);
+    return cr_block_sum(p, n2) + cr_block_sum(p + n2, n - n2);
 }
 
 template <typename F>
-__device__ __forceinline__ F cr_row_dot(const F *ra, const F *rg, int n)            // n <= 256
+__device__ __forceinline__ F cr_row_sum(const F *p, int n)            // n <= 256
 {
-    if (n <= 128) return cr_block_dot(ra, rg, n);
+    if (n <= 128) return cr_block_sum(p, n);
     int n2 = n / 2;
     n2 -= n2 % 8;
-    return cr_half_dot(ra, rg, n2) + cr_half_dot(ra + n2, rg + n2, n - n2);
+    return cr_half_sum(p, n2) + cr_half_sum(p + n2, n - n2);
 }
 
 constexpr int CR_ROWS_MAX = 128;
-// BCAST: one goal row for every row of ag (env.compute_reward(ag, env.goal), fetch_env.py:135-143 with
-// NumPy broadcasting): staged once per block, read by every lane at the same LDS address.
-template <bool VEC4, bool BCAST = false>
-__global__ void __launch_bounds__(CR_ROWS_MAX)
-k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
-                     uint32_t *__restrict__ out)
+template <typename F> struct CrVec;                     // the 16-byte vector of F and the number of requests in flight
+template <> struct CrVec<float> { using V = float4; static constexpr int N = 4, U = 9; };
+template <> struct CrVec<double> { using V = double2; static constexpr int N = 2, U = 8; };
+__device__ __forceinline__ float cr_elem(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+__device__ __forceinline__ double cr_elem(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
+
+// One block = blockDim.x rows, one row per lane in the end.  The tile that goes through LDS is the row-wise PRODUCT
+// achieved_goal * goal (rounded on its own, as NumPy's temporary is) -- not the two operand tiles: half the LDS bytes
+// and writes, twice the resident blocks -- plus per row the count of non-zero goal entries (an LDS atomic per vector).
+// VEC: 16-byte loads (float4 / double2; len a multiple of their length, 16-byte aligned arrays), U vectors of each
+// operand requested per lane before the first is consumed.  BCAST: one goal row for every row of ag
+// (env.compute_reward(ag, env.goal), fetch_env.py:135-143 with NumPy broadcasting), staged once per block.
+template <typename F, bool VEC, bool BCAST>
+__device__ __forceinline__ void compute_reward_body(const F *__restrict__ ag, const F *__restrict__ g, int64_t n, int len, int ldp,
+                                                    uint32_t *__restrict__ out)
 {
+    using V = typename CrVec<F>::V;
+    constexpr int N = CrVec<F>::N, U = CrVec<F>::U;
     const int CR_ROWS = blockDim.x;               // 128 rows per block, 64 when the rows are long (LDS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *s_ag = reinterpret_cast<float *>(smem);
-    float *s_g = s_ag + CR_ROWS * ldp;
+    F *s_p = reinterpret_cast<F *>(smem);
+    F *s_g = s_p + (size_t)CR_ROWS * ldp;                                       // BCAST: the goal row
+    int *s_cnt = reinterpret_cast<int *>(s_p + (size_t)CR_ROWS * ldp);          // !BCAST: non-zero goal entries per row
     const int64_t row0 = (int64_t)blockIdx.x * CR_ROWS;
     const int rows = (int)((n - row0) < CR_ROWS ? (n - row0) : CR_ROWS);
-    const float *pa = ag + row0 * len, *pg = BCAST ? g : g + row0 * len;
+    const F *pa = ag + row0 * len, *pg = BCAST ? g : g + row0 * len;
     if (BCAST) {
         for (int k = threadIdx.x; k < len; k += CR_ROWS) s_g[k] = pg[k];
+    } else {
+        s_cnt[threadIdx.x] = 0;
     }
-    if (VEC4) {
-        // len % 4 == 0: a float4 never straddles a row; (row, col) advance incrementally
-        const int qpr = len >> 2, total = rows * qpr;
+    __syncthreads();
+    if (VEC) {
+        // a vector never straddles a row; (row, col) advance incrementally
+        const int qpr = len / N, total = rows * qpr;
         int r = threadIdx.x / qpr, cq = threadIdx.x - r * qpr;
         const int r_inc = CR_ROWS / qpr, c_inc = CR_ROWS - r_inc * qpr;
-        const float4 *a4 = reinterpret_cast<const float4 *>(pa), *g4 = reinterpret_cast<const float4 *>(pg);
-        // CR_U float4 pairs requested per lane before the first one is consumed: with one pair per
-        // trip the tile took rows * len / (4 * CR_ROWS) serial memory round trips (0.59 of HBM peak)
-        constexpr int CR_U = 9;
-        for (int q0 = threadIdx.x; q0 < total; q0 += CR_ROWS * CR_U) {
-            float4 va[CR_U], vg[BCAST ? 1 : CR_U];
+        const V *a4 = reinterpret_cast<const V *>(pa), *g4 = reinterpret_cast<const V *>(pg);
+        // with one pair of vectors per trip the tile took rows * len / (N * CR_ROWS) serial memory round trips
+        for (int q0 = threadIdx.x; q0 < total; q0 += CR_ROWS * U) {
+            V va[U], vg[BCAST ? 1 : U];
 #pragma unroll
-            for (int u = 0; u < CR_U; u++) {
+            for (int u = 0; u < U; u++) {
                 const int q = q0 + u * CR_ROWS;
                 if (q < total) {
                     va[u] = a4[q];
@@ -2114,14 +2127,17 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
                 }
             }
 #pragma unroll
-            for (int u = 0; u < CR_U; u++) {
+            for (int u = 0; u < U; u++) {
                 if (q0 + u * CR_ROWS < total) {
-                    float *da = s_ag + r * ldp + 4 * cq;
-                    da[0] = va[u].x; da[1] = va[u].y; da[2] = va[u].z; da[3] = va[u].w;
-                    if constexpr (!BCAST) {
-                        float *dg = s_g + r * ldp + 4 * cq;
-                        dg[0] = vg[u].x; dg[1] = vg[u].y; dg[2] = vg[u].z; dg[3] = vg[u].w;
+                    F *dp = s_p + r * ldp + N * cq;
+                    int nz = 0;
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        const F gj = BCAST ? s_g[N * cq + j] : cr_elem(vg[BCAST ? 0 : u], j);
+                        dp[j] = cr_elem(va[u], j) * gj;
+                        nz += (gj != (F)0) ? 1 : 0;
                     }
+                    if (!BCAST && nz) atomicAdd(&s_cnt[r], nz);
                 }
                 r += r_inc; cq += c_inc;
                 if (cq >= qpr) { cq -= qpr; r++; }
@@ -2131,18 +2147,40 @@ k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, 
         const int total = rows * len;
         for (int f = threadIdx.x; f < total; f += CR_ROWS) {
             const int r = f / len, k = f - r * len;
-            s_ag[r * ldp + k] = pa[f];
-            if (!BCAST) s_g[r * ldp + k] = pg[f];
+            const F gk = BCAST ? s_g[k] : pg[f];
+            s_p[r * ldp + k] = pa[f] * gk;
+            if (!BCAST && gk != (F)0) atomicAdd(&s_cnt[r], 1);
         }
     }
     __syncthreads();
     if ((int)threadIdx.x < rows) {
-        const float *ra = s_ag + threadIdx.x * ldp, *rg = BCAST ? s_g : s_g + threadIdx.x * ldp;
         int cnt = 0;
-        for (int k = 0; k < len; k++) cnt += (rg[k] != 0.0f) ? 1 : 0;
-        const float d = cr_row_dot<float>(ra, rg, len);    // NumPy's float32 summation order
-        out[row0 + threadIdx.x] = (d != (float)cnt) ? RBITS_FAIL : RBITS_OK;
+        if (BCAST) {
+            for (int k = 0; k < len; k++) cnt += (s_g[k] != (F)0) ? 1 : 0;
+        } else {
+            cnt = s_cnt[threadIdx.x];
+        }
+        const F d = cr_row_sum<F>(s_p + threadIdx.x * ldp, len);    // NumPy's summation order for this precision
+        out[row0 + threadIdx.x] = (d != (F)cnt) ? RBITS_FAIL : RBITS_OK;
     }
+}
+
+template <bool VEC4, bool BCAST = false>
+__global__ void __launch_bounds__(CR_ROWS_MAX)
+k_compute_reward_f32(const float *__restrict__ ag, const float *__restrict__ g, int64_t n, int len, int ldp,
+                     uint32_t *__restrict__ out)
+{
+    compute_reward_body<float, VEC4, BCAST>(ag, g, n, len, ldp, out);
+}
+
+// The same on float64 rows (env.step's own call: achieved_goal float64, goal int64 / float64 -> a float64 sum,
+// fetch_env.py:141-143).
+template <bool VEC2, bool BCAST = false>
+__global__ void __launch_bounds__(CR_ROWS_MAX)
+k_compute_reward_f64(const double *__restrict__ ag, const double *__restrict__ g, int64_t n, int len, int ldp,
+                     uint32_t *__restrict__ out)
+{
+    compute_reward_body<double, VEC2, BCAST>(ag, g, n, len, ldp, out);
 }
 
 __global__ void __launch_bounds__(256)
@@ -2153,38 +2191,6 @@ k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__rest
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t bad = (want_touch & ~now[i]) | (want_never & ever[i]);
         out[i] = bad ? RBITS_FAIL : RBITS_OK;
-    }
-}
-
-// The same on float64 rows (env.step's own call: achieved_goal float64, goal int64 / float64 -> a float64 sum,
-// fetch_env.py:141-143).  64 rows per block staged through LDS with coalesced loads, one row per lane.
-template <bool BCAST>
-__global__ void __launch_bounds__(64)
-k_compute_reward_f64(const double *__restrict__ ag, const double *__restrict__ g, int64_t n, int len, int ldp,
-                     uint32_t *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *s_ag = reinterpret_cast<double *>(smem);
-    double *s_g = s_ag + 64 * ldp;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
-    const double *pa = ag + row0 * len, *pg = BCAST ? g : g + row0 * len;
-    if (BCAST) {
-        for (int k = threadIdx.x; k < len; k += 64) s_g[k] = pg[k];
-    }
-    const int total = rows * len;
-    for (int f = threadIdx.x; f < total; f += 64) {
-        const int r = f / len, k = f - r * len;
-        s_ag[r * ldp + k] = pa[f];
-        if (!BCAST) s_g[r * ldp + k] = pg[f];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < rows) {
-        const double *ra = s_ag + threadIdx.x * ldp, *rg = BCAST ? s_g : s_g + threadIdx.x * ldp;
-        int cnt = 0;
-        for (int k = 0; k < len; k++) cnt += (rg[k] != 0.0) ? 1 : 0;
-        const double d = cr_row_dot<double>(ra, rg, len);
-        out[row0 + threadIdx.x] = (d != (double)cnt) ? RBITS_FAIL : RBITS_OK;
     }
 }
 
@@ -2735,6 +2741,36 @@ int check_launch(const char *what)
 
 }  // namespace bpgk
 using namespace bpgk;
+
+// LDS of a block: the product tile + either the goal row (bcast) or the per-row counts
+template <typename F>
+static size_t compute_reward_lds(int rows, int ldp, bool bcast)
+{
+    return (size_t)rows * ldp * sizeof(F) + (bcast ? (size_t)ldp * sizeof(F) : (size_t)rows * sizeof(int));
+}
+
+template <typename F, typename K>
+static int compute_reward_launch(K kern_vec_b, K kern_vec, K kern_b, K kern, const F *d_ag, const F *d_g, bool bcast, int64_t n,
+                                 int len, float *d_out, int device_id, void *stream, const char *what)
+{
+    if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
+    if (((uintptr_t)d_ag % sizeof(F)) || ((uintptr_t)d_g % sizeof(F))) return fail(BPG_ERR_ARG, "rows must be aligned to their element size");
+    if (n == 0) return BPG_OK;
+    DeviceGuard guard(device_id);
+    const int ldp = len | 1;
+    // 128 rows per block while two blocks fit a CU's 160 KB of LDS, 64 rows beyond (float64 rows longer than 79)
+    const int CR_ROWS = compute_reward_lds<F>(CR_ROWS_MAX, ldp, bcast) <= 80 * 1024 ? CR_ROWS_MAX : 64;
+    const size_t lds = compute_reward_lds<F>(CR_ROWS, ldp, bcast);
+    constexpr int N = (int)(16 / sizeof(F));
+    const bool vec = (len % N == 0) && (len / N <= CR_ROWS) && aligned16(d_ag) && (bcast || aligned16(d_g));
+    K fn = vec ? (bcast ? kern_vec_b : kern_vec) : (bcast ? kern_b : kern);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), block(CR_ROWS);
+    hipLaunchKernelGGL(fn, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp, reinterpret_cast<uint32_t *>(d_out));
+    return check_launch(what);
+}
 
 // versioned argument structs (include/bpgym.h): copies what the caller passed into a zeroed struct of this library's
 // layout; bytes this library does not know must be zero
@@ -3322,49 +3358,19 @@ int bpg_compute_reward_f32_goal(const float *d_ag, const float *d_goal_row, int6
 static int compute_reward_f32(const float *d_ag, const float *d_g, bool bcast, int64_t n, int len, float *d_out,
                               int device_id, void *stream)
 {
-    if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
-    if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
-    if (n == 0) return BPG_OK;
-    DeviceGuard guard(device_id);
-    const int ldp = len | 1;
-    // two row tiles of CR_ROWS x ldp floats in LDS: 128 rows up to 159 floats per row, 64 rows beyond
-    const int CR_ROWS = ((size_t)2 * CR_ROWS_MAX * ldp * sizeof(float) <= 160 * 1024) ? CR_ROWS_MAX : 64;
-    const size_t lds = (size_t)2 * CR_ROWS * ldp * sizeof(float);
-    const bool vec = (len % 4 == 0) && (len / 4 <= CR_ROWS) && aligned16(d_ag) && (bcast || aligned16(d_g));
-    const void *fn = vec ? (bcast ? reinterpret_cast<const void *>(k_compute_reward_f32<true, true>)
-                                  : reinterpret_cast<const void *>(k_compute_reward_f32<true, false>))
-                         : (bcast ? reinterpret_cast<const void *>(k_compute_reward_f32<false, true>)
-                                  : reinterpret_cast<const void *>(k_compute_reward_f32<false, false>));
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((unsigned)((n + CR_ROWS - 1) / CR_ROWS)), block(CR_ROWS);
-    uint32_t *o = reinterpret_cast<uint32_t *>(d_out);
-    hipStream_t st = (hipStream_t)stream;
-    if (vec && bcast) hipLaunchKernelGGL((k_compute_reward_f32<true, true>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
-    else if (vec) hipLaunchKernelGGL((k_compute_reward_f32<true, false>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
-    else if (bcast) hipLaunchKernelGGL((k_compute_reward_f32<false, true>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
-    else hipLaunchKernelGGL((k_compute_reward_f32<false, false>), grid, block, lds, st, d_ag, d_g, n, len, ldp, o);
-    return check_launch("k_compute_reward_f32");
+    using K = void (*)(const float *, const float *, int64_t, int, int, uint32_t *);
+    return compute_reward_launch<float, K>(k_compute_reward_f32<true, true>, k_compute_reward_f32<true, false>,
+                                           k_compute_reward_f32<false, true>, k_compute_reward_f32<false, false>, d_ag, d_g, bcast, n,
+                                           len, d_out, device_id, stream, "k_compute_reward_f32");
 }
 
 static int compute_reward_f64(const double *d_ag, const double *d_g, bool bcast, int64_t n, int len, float *d_out,
                               int device_id, void *stream)
 {
-    if (!d_ag || !d_g || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
-    if (n < 0 || len < 1 || len > 256) return fail(BPG_ERR_ARG, "len must be in 1..256");
-    if (((uintptr_t)d_ag & 7u) || ((uintptr_t)d_g & 7u)) return fail(BPG_ERR_ARG, "float64 rows must be 8-byte aligned");
-    if (n == 0) return BPG_OK;
-    DeviceGuard guard(device_id);
-    const int ldp = len | 1;
-    const size_t lds = (size_t)2 * 64 * ldp * sizeof(double);          // two 64-row tiles: 160 KB of LDS hold rows of <= 159
-    if (lds > 160 * 1024) return fail(BPG_ERR_ARG, "float64 rows: len must be <= 159");
-    const void *fn = bcast ? reinterpret_cast<const void *>(k_compute_reward_f64<true>)
-                           : reinterpret_cast<const void *>(k_compute_reward_f64<false>);
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    uint32_t *o = reinterpret_cast<uint32_t *>(d_out);
-    if (bcast) hipLaunchKernelGGL(k_compute_reward_f64<true>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp, o);
-    else hipLaunchKernelGGL(k_compute_reward_f64<false>, grid, block, lds, (hipStream_t)stream, d_ag, d_g, n, len, ldp, o);
-    return check_launch("k_compute_reward_f64");
+    using K = void (*)(const double *, const double *, int64_t, int, int, uint32_t *);
+    return compute_reward_launch<double, K>(k_compute_reward_f64<true, true>, k_compute_reward_f64<true, false>,
+                                            k_compute_reward_f64<false, true>, k_compute_reward_f64<false, false>, d_ag, d_g, bcast, n,
+                                            len, d_out, device_id, stream, "k_compute_reward_f64");
 }
 
 int bpg_compute_reward_f64(const double *d_ag, const double *d_g, int64_t n, int len, float *d_out, int device_id,

@@ -688,8 +688,7 @@ def compute_reward(achieved_goal, goal, device=None):
     torch in -> torch float32 out (on `device`).  The products and their sum are taken in the precision NumPy
     would use for `achieved_goal * goal` (fetch_env.py:141) -- np.result_type of the two arrays: float64 for the
     reference's own call (a float64 matrix, robot_env.py:66), float32 for HER's float32 replay arrays -- and in
-    NumPy's summation order; for the ternary rows of the env any order is exact.  float64 rows longer than 159
-    entries raise ValueError."""
+    NumPy's summation order; for the ternary rows of the env any order is exact.  Rows of up to 256 entries."""
     L = _lib.lib()
     np_in = not torch.is_tensor(achieved_goal)
     dev = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
@@ -704,9 +703,6 @@ def compute_reward(achieved_goal, goal, device=None):
     if rt == np.float16:
         raise NotImplementedError('compute_reward on float16 x float16 rows (NumPy would sum in float16)')
     wide = rt != np.float32
-    if wide and ag.shape[-1] > 159:
-        raise ValueError('compute_reward: float64 rows are limited to 159 entries (bpg_compute_reward_f64); got %d -- '
-                         'pass float32 arrays if float32 arithmetic is what is wanted' % ag.shape[-1])
     ft = torch.float64 if wide else torch.float32
     ag = ag.to(dev, ft).contiguous()
     g = g.to(dev, ft)

@@ -320,7 +320,7 @@ int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters);
  * Every row the env or a replay buffer can hold is ternary ({-1, 0, 1}: any summation order is exact); for
  * arbitrary rows the sum is taken in NumPy's order for that precision -- products rounded on their own, then the
  * pairwise add-reduction (third-party NumPy; pinned by tests/golden/compute_reward_order.npz) -- so the result
- * is NumPy's for float32 arrays (_f32) and for float64 arrays (_f64, len <= 159), not that of a mixed call. */
+ * is NumPy's for float32 arrays (_f32) and for float64 arrays (_f64), not that of a mixed call. */
 int bpg_compute_reward_f32(const float *d_ag, const float *d_g, int64_t n, int len,
                            float *d_out, int device_id, void *stream);
 /* Same against ONE goal row of `len` floats shared by every row of d_ag -- env.compute_reward(ag,

@@ -355,10 +355,11 @@ def test_compute_reward_follows_numpys_summation_order_in_both_precisions():
     np.testing.assert_array_equal(bpg.compute_reward(ag, g).view(np.uint32), want)                       # float64 * int64
     np.testing.assert_array_equal(bpg.compute_reward(ag.astype(np.float32), g.astype(np.float32)).view(np.uint32), want)
     # argument checks of the float64 entry point
-    x = torch.zeros((4, 160), dtype=torch.float64, device=DEV)
+    x = torch.zeros((4, 257), dtype=torch.float64, device=DEV)
     o = torch.zeros(4, dtype=torch.float32, device=DEV)
-    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 160, P(o), 0, None) == bpg._lib.ERR_ARG
-    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 159, P(o), 0, None) == 0
+    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 257, P(o), 0, None) == bpg._lib.ERR_ARG
+    assert L.bpg_compute_reward_f64(P(x), P(x), 4, 256, P(o), 0, None) == 0
+    assert L.bpg_compute_reward_f64(C.c_void_p(x.data_ptr() + 4), P(x), 4, 16, P(o), 0, None) == bpg._lib.ERR_ARG    # 8-byte alignment
 
 
 def test_rollout_with_return_is_capturable_in_a_hip_graph():

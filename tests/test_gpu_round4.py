@@ -334,8 +334,7 @@ def test_step_ok_words_are_allocated_on_first_use_only():
 def test_compute_reward_precision_follows_numpys_promotion():
     """bpg.compute_reward picks the arithmetic NumPy would use for `achieved_goal * goal` (fetch_env.py:141):
     float32 x int8 / bool stays float32, float32 x int64 / float64 is float64 -- on rows built so that the two
-    precisions DISAGREE about `sum == count` -- and float64 rows longer than 159 entries raise instead of being
-    narrowed silently."""
+    precisions DISAGREE about `sum == count` (a float64 call is never narrowed to float32)."""
     rng = np.random.RandomState(5)
     rows = []
     g8 = np.array([3, 3, 3, 0, 0, 0, 0, 0], np.int8)       # three non-zero entries: count_nonzero(g) = 3
@@ -365,8 +364,8 @@ def test_compute_reward_precision_follows_numpys_promotion():
             np.testing.assert_array_equal(bits32(gt), want.view(np.uint32))
             seen.add(want.tobytes())
     assert len(seen) >= 2                                   # the two precisions really answered differently (bool goals: a third)
-    with pytest.raises(ValueError):
-        bpg.compute_reward(np.zeros((4, 160)), np.zeros((4, 160)))
+    with pytest.raises(bpg._lib.BpgError):                  # the header's range, len <= 256, in either precision
+        bpg.compute_reward(np.zeros((4, 257)), np.zeros((4, 257)))
     assert bpg.compute_reward(np.zeros((4, 160), np.float32), np.zeros((4, 160), np.int8)).shape == (4,)
     with pytest.raises(NotImplementedError):
         bpg.compute_reward(np.zeros((2, 8), np.float16), np.zeros((2, 8), np.float16))
@@ -571,3 +570,44 @@ def test_contact_list_walk_at_every_length_and_alignment(maxcon, shift):
         bpg._lib.check(L.bpg_step_masks(ref._h, P(tb[t]), P(r[1]), P(f[1]), None))
         assert torch.equal(r[0].view(torch.int32), r[1].view(torch.int32)) and torch.equal(f[0], f[1])
     assert torch.equal(env.state_now, ref.state_now) and torch.equal(env.state_ever, ref.state_ever)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_compute_reward_rows_of_every_length_in_numpys_order(dtype):
+    """bpg_compute_reward_f32 / _f64 (rows and one-goal-row forms) against NumPy itself -- np.sum(ag * g, axis=-1) !=
+    np.count_nonzero(g), fetch_env.py:141-143, in the arrays' own precision -- on NON-ternary rows whose verdict depends on
+    the summation order: every length class of NumPy's pairwise reduction (below 8, the 8-accumulator block up to 128,
+    one and two splits up to 256), lengths that are and are not multiples of the 16-byte vector, tiles with ragged tails,
+    16-byte aligned and 8-/4-byte offset arrays (the scalar staging path)."""
+    rng = np.random.RandomState(17)
+    for ln in (1, 2, 5, 7, 8, 9, 16, 25, 36, 37, 64, 100, 127, 128, 129, 130, 160, 200, 255, 256):
+        for n in (1, 127, 130, 389):
+            g = (rng.randint(1, 4, size=(n, ln)) * (rng.rand(n, ln) < 0.6)).astype(dtype)
+            c = np.count_nonzero(g, axis=-1)
+            ag = rng.rand(n, ln).astype(dtype)
+            # rows whose exact sum is close to the count: the rounding order decides `d != c`
+            with np.errstate(divide='ignore', invalid='ignore'):
+                scale = np.where(c > 0, c / np.maximum(np.sum(ag.astype(np.float64) * g, axis=-1), 1e-30), 1.0)
+            ag = (ag * scale[:, None]).astype(dtype)
+            ag[::5] = np.where(g[::5] != 0, 1.0 / np.maximum(g[::5], 1), ag[::5]).astype(dtype)
+            want = -(np.sum(ag * g, axis=-1) != c).astype(np.float32)
+            got = bpg.compute_reward(ag, g)
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg='len %d n %d' % (ln, n))
+            g1 = g[0]
+            want1 = -(np.sum(ag * g1, axis=-1) != np.count_nonzero(g1)).astype(np.float32)
+            np.testing.assert_array_equal(bpg.compute_reward(ag, g1).view(np.uint32), want1.view(np.uint32), err_msg='len %d n %d goal row' % (ln, n))
+    # arrays that are element-aligned only: one element past a 16-byte boundary
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    fn = L.bpg_compute_reward_f64 if dtype == np.float64 else L.bpg_compute_reward_f32
+    n, ln = 300, 36
+    g = (rng.randint(1, 4, size=(n, ln)) * (rng.rand(n, ln) < 0.6)).astype(dtype)
+    ag = rng.rand(n, ln).astype(dtype)
+    want = -(np.sum(ag * g, axis=-1) != np.count_nonzero(g, axis=-1)).astype(np.float32)
+    fa = torch.zeros(n * ln + 1, dtype=tdt, device=DEV)
+    fg = torch.zeros(n * ln + 1, dtype=tdt, device=DEV)
+    fa[1:].copy_(torch.as_tensor(ag.ravel()))
+    fg[1:].copy_(torch.as_tensor(g.ravel()))
+    o = torch.empty(n, dtype=torch.float32, device=DEV)
+    assert fa[1:].data_ptr() % 16 != 0
+    bpg._lib.check(fn(P(fa[1:]), P(fg[1:]), n, ln, P(o), 0, None))
+    np.testing.assert_array_equal(bits32(o), want.view(np.uint32))
