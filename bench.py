@@ -872,6 +872,26 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         _lib.check(L.bpg_compute_reward_f32(C.c_void_p(cr_ag.data_ptr()), C.c_void_p(cr_g.data_ptr()), nrow,
                                             env.dimg, C.c_void_p(cr_out.data_ptr()), dev.index, stream))
     res['compute_reward_f32_rows'] = line(timed(cr, 20), nrow * (8 * env.dimg + 4), nrow)
+
+    def cr_goal():      # env.compute_reward(ag, env.goal): one goal row for all rows (fetch_env.py:135-143 with broadcasting)
+        _lib.check(L.bpg_compute_reward_f32_goal(C.c_void_p(cr_ag.data_ptr()), C.c_void_p(cr_g.data_ptr()), nrow,
+                                                 env.dimg, C.c_void_p(cr_out.data_ptr()), dev.index, stream))
+    res['compute_reward_f32_one_goal_row'] = line(timed(cr_goal, 20), nrow * (4 * env.dimg + 4), nrow)
+    del cr_ag, cr_g
+    # float64 rows: the precision of env.step's own call (a float64 matrix against an int64 goal, robot_env.py:66): 2 B rows
+    nrow = 2 * B
+    cr_ag = torch.randint(-1, 2, (nrow, env.dimg), device=dev).to(torch.float64)
+    cr_g = env._g[:1].to(torch.float64).expand(nrow, env.dimg).contiguous()
+
+    def cr64():
+        _lib.check(L.bpg_compute_reward_f64(C.c_void_p(cr_ag.data_ptr()), C.c_void_p(cr_g.data_ptr()), nrow,
+                                            env.dimg, C.c_void_p(cr_out.data_ptr()), dev.index, stream))
+
+    def cr64_goal():
+        _lib.check(L.bpg_compute_reward_f64_goal(C.c_void_p(cr_ag.data_ptr()), C.c_void_p(cr_g.data_ptr()), nrow,
+                                                 env.dimg, C.c_void_p(cr_out.data_ptr()), dev.index, stream))
+    res['compute_reward_f64_rows'] = line(timed(cr64, 20), nrow * (16 * env.dimg + 4), nrow)
+    res['compute_reward_f64_one_goal_row'] = line(timed(cr64_goal, 20), nrow * (8 * env.dimg + 4), nrow)
     del cr_ag, cr_g, cr_out
 
     # (3d') the expert's inputs of one step (policy_gradient/rollout.py:105-171, :198): 87 -> 40 (float64) observation

@@ -178,6 +178,16 @@ def main():
                 co = torch.empty(n, dtype=torch.float32, device=DEV)
                 for i in range(10):
                     _lib.check(L.bpg_compute_reward_f32(P(cag), P(cg), n, 36, P(co), 0, None))
+                for i in range(10):
+                    _lib.check(L.bpg_compute_reward_f32_goal(P(cag), P(cg), n, 36, P(co), 0, None))
+                del cag, cg
+                n = 2 * B
+                dag = torch.randint(-1, 2, (n, 36), device=DEV).to(torch.float64)
+                dg = env._g[:1].to(torch.float64).expand(n, 36).contiguous()
+                for i in range(10):
+                    _lib.check(L.bpg_compute_reward_f64(P(dag), P(dg), n, 36, P(co), 0, None))
+                for i in range(10):
+                    _lib.check(L.bpg_compute_reward_f64_goal(P(dag), P(dg), n, 36, P(co), 0, None))
             torch.cuda.synchronize()
         elif w == 'assemble':
             env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)

@@ -31,6 +31,9 @@ ROWS = [
     ('k_step_contacts', '`k_step_contacts<4>`', 'one step from geom-id pair lists (maxcon 16), lists HBM-cold'),
     ('k_contacts_to_masks_tb', '`k_contacts_to_masks<4>`', 'a recorded rollout\'s lists (T = 50, 262 144 envs, maxcon 16) → mask stream'),
     ('k_compute_reward_f32', '`k_compute_reward_f32`', "4 M rows of 36 floats, NumPy's summation order"),
+    ('k_compute_reward_f32_goal', '`k_compute_reward_f32<one goal row>`', '4 M rows of 36 floats against one goal row'),
+    ('k_compute_reward_f64', '`k_compute_reward_f64`', "2 M rows of 36 doubles (the precision of `env.step`'s own call)"),
+    ('k_compute_reward_f64_goal', '`k_compute_reward_f64<one goal row>`', '2 M rows of 36 doubles against one goal row'),
     ('k_assemble_obs_f32', '`k_assemble_obs<float, 4>`', '`_get_obs` rows of 1 M Variation envs'),
     ('k_nan_flag', '`k_nan_flag`', 'NaN check of 1 M × 87 floats'),
     ('k_set_action', '`k_set_action`', 'clip + 9-vector, 1 M envs'),

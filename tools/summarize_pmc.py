@@ -80,7 +80,10 @@ KERNELS = [
     ('k_discounted_return_lane<50, 0', None, 'k_discounted_return_lane50_exact', 'read4', 4 * T * B, 8 * T * B, ''),
     ('k_discounted_return_lane<50, 1', None, 'k_discounted_return_lane50_scan', 'read4', 4 * T * B, 8 * T * B, ''),
     ('k_episode<6, 0', None, 'k_episode', 'read4', B * (4 * T + 8), B * (8 + 4 * (36 * (2 * T + 1) + T)), ''),
-    ('k_compute_reward_f32<true', None, 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4, ''),
+    ('k_compute_reward_f32<true, false>', None, 'k_compute_reward_f32', 'read16', 4 * B * 288, 4 * B * 4, ''),
+    ('k_compute_reward_f32<true, true>', None, 'k_compute_reward_f32_goal', 'read16', 4 * B * 144, 4 * B * 4, ''),
+    ('k_compute_reward_f64<true, false>', None, 'k_compute_reward_f64', 'read16', 2 * B * 576, 2 * B * 4, ''),
+    ('k_compute_reward_f64<true, true>', None, 'k_compute_reward_f64_goal', 'read16', 2 * B * 288, 2 * B * 4, ''),
     ('k_reset<true>', None, 'k_reset_obs', 'read4', 8 * B, None, ''),
     ('k_assemble_obs<float, 4>', None, 'k_assemble_obs_f32', 'read8', B * (4 + 8 * 58), B * 4 * 87, ''),
     ('k_set_action', None, 'k_set_action', 'read16', 16 * B, 72 * B, ''),
