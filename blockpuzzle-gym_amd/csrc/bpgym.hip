@@ -2094,7 +2094,9 @@ __device__ __forceinline__ void compute_reward_body(const F *__restrict__ ag, co
                                                     uint32_t *__restrict__ out)
 {
     using V = typename CrVec<F>::V;
-    constexpr int N = CrVec<F>::N, U = CrVec<F>::U;
+    // one goal row for all: only one operand stream -- float64: twice the vectors of it in flight (the same bytes per lane;
+    // 124-132 -> 116 us for 2 M rows of 36); float32 measured no better with 18 than with 9
+    constexpr int N = CrVec<F>::N, U = (BCAST && sizeof(F) == 8) ? 2 * CrVec<F>::U : CrVec<F>::U;
     const int CR_ROWS = blockDim.x;               // 128 rows per block, 64 when the rows are long (LDS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     F *s_p = reinterpret_cast<F *>(smem);
@@ -2131,9 +2133,11 @@ __device__ __forceinline__ void compute_reward_body(const F *__restrict__ ag, co
                 if (q0 + u * CR_ROWS < total) {
                     F *dp = s_p + r * ldp + N * cq;
                     int nz = 0;
+                    // the goal row sits 16-byte aligned in LDS (its offset is a multiple of 64 elements): one vector read
+                    const V gv = BCAST ? *reinterpret_cast<const V *>(s_g + N * cq) : vg[BCAST ? 0 : u];
 #pragma unroll
                     for (int j = 0; j < N; j++) {
-                        const F gj = BCAST ? s_g[N * cq + j] : cr_elem(vg[BCAST ? 0 : u], j);
+                        const F gj = cr_elem(gv, j);
                         dp[j] = cr_elem(va[u], j) * gj;
                         nz += (gj != (F)0) ? 1 : 0;
                     }
