@@ -82,6 +82,7 @@ def parse():
     p.add_argument('--no-stride-probe', action='store_true',
                    help='skip the set-up probe of the headline launch at row strides B, B + 256, B + 768')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-box-state', action='store_true', help='skip the rocm-smi reading under load after the measurement')
     p.add_argument('--cpu-seconds', type=float, default=12.0)
     p.add_argument('--launch-timeout', type=float, default=900.0,
                    help='self-launched N>1 runs: seconds before the parent ends the rank processes it started')
@@ -139,6 +140,48 @@ def cpu_baseline(T, seconds):
         except ValueError as e:
             out['reference_python'] = {'error': repr(e)[:200]}
     return out
+
+
+def box_state_under_load(cx, h, seconds=0.6):
+    """Untimed, after the measurement: the clocks and the power of the card WHILE the headline launch runs back to back (a train
+    of launches is enqueued, `rocm-smi` is read once while it drains).  The headline launch takes 82-91 us depending on the box
+    (DESIGN.md 4): this records what the box the bench ran on looked like.  Best effort -- {'error': ...} if rocm-smi is missing."""
+    torch, _lib, L = cx.torch, cx._lib, cx.L
+    try:
+        env, T, LD, NBUF = h['env'], cx.T, h['LD'], h['NBUF']
+        ng = ((torch.arange(h['B'], device=cx.dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
+        cnt = torch.zeros(2, dtype=torch.int64, device=cx.dev)
+        args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=h['masks'][k].data_ptr(),
+                                 d_reward_tb=h['reward'][k].data_ptr(), d_flags_tb=h['flags'][k].data_ptr(), ld_masks=LD, ld_out=LD,
+                                 d_success_count=cnt.data_ptr()) for k in range(NBUF)]
+        n = int(seconds / (h['kernel_ms'] * 1e-3))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            _lib.check(L.bpg_rollout(env._h, C.byref(args[i % NBUF]), cx.stream))
+        e1.record()
+        t0 = time.perf_counter()
+        smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showmemorypartition', '--showcomputepartition', '--json'],
+                             capture_output=True, text=True, timeout=20)
+        read_after_s = time.perf_counter() - t0
+        still_running = not e1.query()
+        torch.cuda.synchronize(cx.dev)
+        card = {}
+        try:
+            js = json.loads(smi.stdout)
+            card = js.get('card0') or next(iter(js.values()))
+        except (ValueError, StopIteration):
+            card = {'raw': smi.stdout[:400]}
+        keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ('clk', 'clock', 'power', 'partition'))}
+        return {'rocm_smi': keep, 'launches_in_the_train': n, 'train_ms_per_launch': e0.elapsed_time(e1) / n,
+                'smi_read_took_s': read_after_s, 'train_still_running_when_read': bool(still_running),
+                'how': 'a train of headline launches enqueued, rocm-smi read once while it drains; untimed, after the measurement'}
+    except Exception as e:  # noqa: BLE001
+        try:
+            torch.cuda.synchronize(cx.dev)
+        except Exception:  # noqa: BLE001
+            pass
+        return {'error': repr(e)[:300]}
 
 
 METRIC = 'env_steps_per_sec'
@@ -603,6 +646,10 @@ def run(a):
     }
     if h['probe'] is not None:
         out['row_stride_probe'] = h['probe']
+    # (not under a profiler: its preloaded library would ride along into the child process)
+    profiled = any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
+    if rank == 0 and world == 1 and not a.no_box_state and not profiled:
+        out['box_state_under_load'] = box_state_under_load(cx, h)
 
     if rank == 0 and world == 1 and not a.no_extras:
         out['extra'] = extras(torch, bpg, _lib, h['env'], h['masks'][0], h['reward'][0], h['flags'][0], B, T, dev, stream)
