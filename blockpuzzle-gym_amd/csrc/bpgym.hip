@@ -902,6 +902,51 @@ __device__ __forceinline__ void wave_store_returns(const double (&acc)[TT], doub
     }
 }
 
+// The same for rows of which only the first T <= TT entries exist (k_returns_from_okbits_lane_rt): the tile keeps rows of
+// TT doubles, the output rows are T doubles long, 16-byte stores when T is even.
+template <int TT, int TR = G_TILE_ROWS>
+__device__ __forceinline__ void wave_store_returns_rt(const double (&acc)[TT], double *tile, double *__restrict__ G,
+                                                      int64_t e0, int64_t n, int lane, int T)
+{
+    static_assert(TT % 2 == 0, "rows are whole 16-byte pieces");
+    const bool pairs = (T % 2 == 0) && ((reinterpret_cast<uintptr_t>(G) & 15u) == 0);
+#pragma unroll
+    for (int c = 0; c < 64 / TR; c++) {
+        if (c) wave_lds_sync();
+        if ((lane / TR) == c) {
+            double *row = tile + (lane % TR) * TT;
+            static_for<0, TT / 2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (2 * i < T) reinterpret_cast<double2 *>(row)[i] = make_double2(acc[2 * i], acc[2 * i + 1]);
+            });
+        }
+        wave_lds_sync();
+        const int64_t first = e0 + c * TR;
+        const int64_t left = n - first;
+        const int rows = left >= TR ? TR : (left > 0 ? (int)left : 0);
+        double *o = G + first * T;
+        if (pairs) {                                   // first is a multiple of 16: the piece starts 16-byte aligned
+            const int hp = T / 2;
+            int r = 0, col = lane;
+            while (col >= hp) { col -= hp; r++; }
+            double2 *o2 = reinterpret_cast<double2 *>(o);
+            for (int f = lane; f < rows * hp; f += 64) {
+                st_d2<OUT_NT>(&o2[f], reinterpret_cast<const double2 *>(tile + r * TT)[col]);
+                col += 64;
+                while (col >= hp) { col -= hp; r++; }
+            }
+        } else {
+            int r = 0, col = lane;
+            while (col >= T) { col -= T; r++; }
+            for (int f = lane; f < rows * T; f += 64) {
+                st_1<OUT_NT>(&o[f], tile[r * TT + col]);
+                col += 64;
+                while (col >= T) { col -= T; r++; }
+            }
+        }
+    }
+}
+
 
 // PIPE: software-pipelined mask requests (see the loop); used for the latency-bound batch sizes.
 // The plain loop (PIPE = false: UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound
@@ -2428,33 +2473,26 @@ k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__re
     }
 }
 
-// any T <= 64: the rows accumulate in an LDS tile, one env per lane
-__global__ void __launch_bounds__(64)
-k_returns_from_okbits(const uint64_t *__restrict__ okbits, double *__restrict__ G, int64_t n, int T, int R, PowTable pw)
+// Any horizon T <= TT through the register-resident form: steps t >= T count as "ok" (nothing is subtracted for them, so
+// the first T accumulators are bit for bit those of a T-step rollout -- only steps t < T ever contribute to them), the
+// lag passes of steps that no lane needs are skipped wave-uniformly, and only the first T entries of a row leave.
+// (The reference's tasks all use T = 50, which has its own instantiation; this one takes the cliff out of every other
+// horizon: T = 40 at 1 M envs 346 us through the LDS-tile kernel below, profiles/r04_survey_secondary.log.)
+template <int TT, int WPB, int TR = G_TILE_ROWS>
+__global__ void __launch_bounds__(64 * WPB)
+k_returns_from_okbits_lane_rt(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
+                              int64_t n, int T)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *tile = reinterpret_cast<double *>(smem);   // [64][R]
-    const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * 64;
-    const int nvalid = (int)((n - base) < 64 ? (n - base) : 64);
-    if (lane < nvalid) {
-        const uint64_t ok = okbits[base + lane];
-        double *my = tile + lane * R;
-        for (int t = 0; t < T; t++) my[t] = ((ok >> t) & 1ull) ? -0.0 : -1.0;
-        for (int t = 1; t < T; t++) {
-            if (!((ok >> t) & 1ull))
-                for (int t_ = 0; t_ < t; t_++) my[t_] = my[t_] - pw.v[t - t_];
-        }
-    }
-    __syncthreads();
-    double *o = G + base * (int64_t)T;
-    const int total = nvalid * T;
-    int e = 0, rem = lane;
-    while (rem >= T) { rem -= T; e++; }
-    for (int f = lane; f < total; f += 64) {
-        o[f] = tile[e * R + rem];
-        rem += 64;
-        while (rem >= T) { rem -= T; e++; }
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t beyond = T < 64 ? ~0ull << T : 0ull;
+    for (int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64; base < n; base += (int64_t)gridDim.x * WPB * 64) {
+        const int64_t e = base + lane < n ? base + lane : n - 1;
+        const uint64_t ok = okbits[e] | beyond;
+        double acc[TT];
+        returns_from_okbits<TT>(ok, acc);
+        wave_store_returns_rt<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane, T);
+        wave_lds_sync();                               // the tile is written again by the next trip
     }
 }
 
@@ -3412,11 +3450,10 @@ static int launch_returns_from_okbits(const uint64_t *d_okbits, double *d_G, int
         hipLaunchKernelGGL((k_returns_from_okbits_lane<25, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n);
     else if (T == 10 && aligned16(d_G))
         hipLaunchKernelGGL((k_returns_from_okbits_lane<10, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n);
-    else {
-        const int R = T | 1;
-        hipLaunchKernelGGL(k_returns_from_okbits, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)64 * R * sizeof(double), st,
-                           d_okbits, d_G, n, T, R, tab);
-    }
+    else if (T <= 32)                                  // every other horizon: the smallest register-resident form that holds it
+        hipLaunchKernelGGL((k_returns_from_okbits_lane_rt<32, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n, T);
+    else
+        hipLaunchKernelGGL((k_returns_from_okbits_lane_rt<64, WPB>), pgrid, pblock, 0, st, tab, d_okbits, d_G, n, T);
     return check_launch("k_returns_from_okbits");
 }
 

@@ -611,3 +611,33 @@ def test_compute_reward_rows_of_every_length_in_numpys_order(dtype):
     assert fa[1:].data_ptr() % 16 != 0
     bpg._lib.check(fn(P(fa[1:]), P(fg[1:]), n, ln, P(o), 0, None))
     np.testing.assert_array_equal(bits32(o), want.view(np.uint32))
+
+
+@pytest.mark.parametrize('T', [1, 2, 7, 16, 31, 32, 33, 40, 49, 51, 63, 64])
+def test_return_from_step_ok_words_at_any_horizon(T):
+    """bpg_rollout(d_G) at horizons without an instantiation of their own (every T <= 64 except 50 / 25 / 10): the
+    register-resident form for 32 or 64 accumulators with the steps t >= T counted as ok and only the first T entries of a
+    row stored -- G bit for bit the oracle's float64 accumulation (policy_gradient/rollout.py:255-258) of the rewards the same
+    launch wrote, ragged batch (partial wave, partial 16-row tile), G 16-byte aligned and 8 bytes off."""
+    B, gamma = 64 * 5 + 37, 1.0 - 1.0 / max(T, 2)
+    rng = np.random.RandomState(T)
+    env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=4, max_episode_steps=T)
+    ng = torch.as_tensor(rng.randint(3, size=B).astype(np.int32), device=DEV)
+    masks = torch.as_tensor(legal_masks(rng, T, B, 6, density=4).astype(np.int32), device=DEV)
+    rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
+    flat = torch.full((B * T + 2,), 7.0, dtype=torch.float64, device=DEV)
+    for off in (0, 1):
+        base = flat[off:]
+        shift = 0 if (base.data_ptr() % 16 == 0) == (off == 0) else 1         # off 0: aligned, off 1: 8 bytes off
+        G = flat[off + shift:off + shift + B * T].view(B, T)
+        assert (G.data_ptr() % 16 == 0) == (off == 0)
+        a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), d_reward_tb=rew.data_ptr(),
+                                 d_G=G.data_ptr(), gamma=gamma)
+        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        torch.cuda.synchronize()
+        same_bits64(G.cpu().numpy(), oracle_G(rew.cpu().numpy(), gamma))
+        tail = flat[off + shift + B * T:]
+        assert tail.numel() == 0 or float(tail.min()) == 7.0                   # nothing written past the last row
+        flat.fill_(7.0)
+    if T >= 16:
+        assert (rew.cpu().numpy() == -1.0).any() and (rew.cpu().numpy() == 0.0).any()
