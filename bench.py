@@ -161,18 +161,21 @@ def box_state_under_load(cx, h, seconds=0.6):
             _lib.check(L.bpg_rollout(env._h, C.byref(args[i % NBUF]), cx.stream))
         e1.record()
         t0 = time.perf_counter()
-        smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showmemorypartition', '--showcomputepartition', '--json'],
+        smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showmemorypartition', '--showcomputepartition', '--showvbios',
+                              '--showdriverversion', '--json'],
                              capture_output=True, text=True, timeout=20)
         read_after_s = time.perf_counter() - t0
         still_running = not e1.query()
         torch.cuda.synchronize(cx.dev)
-        card = {}
+        card, js = {}, None
         try:
             js = json.loads(smi.stdout)
             card = js.get('card0') or next(iter(js.values()))
         except (ValueError, StopIteration):
             card = {'raw': smi.stdout[:400]}
-        keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ('clk', 'clock', 'power', 'partition'))}
+        keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ('clk', 'clock', 'power', 'partition', 'vbios'))}
+        if isinstance(js, dict) and isinstance(js.get('system'), dict):
+            keep.update({k: v for k, v in js['system'].items() if 'driver' in k.lower()})
         return {'rocm_smi': keep, 'launches_in_the_train': n, 'train_ms_per_launch': e0.elapsed_time(e1) / n,
                 'smi_read_took_s': read_after_s, 'train_still_running_when_read': bool(still_running),
                 'how': 'a train of headline launches enqueued, rocm-smi read once while it drains; untimed, after the measurement'}
