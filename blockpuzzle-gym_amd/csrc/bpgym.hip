@@ -2337,11 +2337,15 @@ k_discounted_return(const float *__restrict__ reward_tb, int64_t n, int64_t ld, 
 enum { DRM_EXACT = 0, DRM_SCAN = 1 };
 constexpr int DR_LANE_WPB = 4;              // waves per block (each wave: 64 envs, a private 16-row LDS tile)
 
-template <int TT, int MODE, int WPB, int TR = G_TILE_ROWS>
+// RT: any horizon T_rt <= TT through the TT-accumulator form -- rows t >= T_rt are neither read nor do they contribute
+// (every guard below is wave-uniform and compiled out when !RT), only the first T_rt entries of a row leave.
+template <int TT, int MODE, int WPB, int TR = G_TILE_ROWS, bool RT = false>
 __global__ void __launch_bounds__(64 * WPB)
 k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64_t n, int64_t ld, double gamma,
-                         double *__restrict__ G, int allow_plain)
+                         double *__restrict__ G, int allow_plain, int T_rt)
 {
+    const int T = RT ? T_rt : TT;
+    auto row = [&](int t) { return !RT || t < T; };      // row t of the stream exists
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WPB][TR * TT * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * WPB + wave) * 64;
@@ -2353,9 +2357,10 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
     uint32_t r[TT];
     static_for<0, TT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        r[t] = __builtin_nontemporal_load(rp + (int64_t)t * ld);          // read once
+        r[t] = row(t) ? __builtin_nontemporal_load(rp + (int64_t)t * ld) : RBITS_OK;          // read once
     });
     double acc[TT];
+    static_assert(!(RT && MODE == DRM_SCAN), "the scan keeps its LDS-tile form at other horizons");
     if constexpr (MODE == DRM_SCAN) {
         acc[TT - 1] = (double)__uint_as_float(r[TT - 1]);
         static_for<1, TT>([&](auto tc) {
@@ -2393,16 +2398,21 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
                 asm volatile("" : "+v"(rq));
                 float ahead[AHEAD];
                 static_for<0, AHEAD>([&](auto uc) {
-                    ahead[decltype(uc)::value] = __uint_as_float(*rq);
-                    if constexpr (decltype(uc)::value + 1 < TT) rq += ld;
+                    if (row(decltype(uc)::value)) {
+                        ahead[decltype(uc)::value] = __uint_as_float(*rq);
+                        if constexpr (decltype(uc)::value + 1 < TT) { if (row(decltype(uc)::value + 1)) rq += ld; }
+                    }
                     asm volatile("" : "+v"(rq));
                 });
                 static_for<0, TT>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
+                    if (!row(t)) return;
                     const double rt = (double)ahead[t % AHEAD];
                     if constexpr (t + AHEAD < TT) {
-                        ahead[t % AHEAD] = __uint_as_float(*rq);
-                        if constexpr (t + AHEAD + 1 < TT) rq += ld;
+                        if (row(t + AHEAD)) {
+                            ahead[t % AHEAD] = __uint_as_float(*rq);
+                            if constexpr (t + AHEAD + 1 < TT) { if (row(t + AHEAD + 1)) rq += ld; }
+                        }
                         asm volatile("" : "+v"(rq));
                     }
                     acc[t] = rt;                                            // G[t] starts as r[t]
@@ -2426,16 +2436,21 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
                 asm volatile("" : "+v"(rq));
                 float ahead[AHEAD];
                 static_for<0, AHEAD>([&](auto uc) {
-                    ahead[decltype(uc)::value] = __uint_as_float(*rq);
-                    if constexpr (KA + 1 + decltype(uc)::value + 1 < TT) rq += ld;
+                    if (row(KA + 1 + decltype(uc)::value)) {
+                        ahead[decltype(uc)::value] = __uint_as_float(*rq);
+                        if constexpr (KA + 1 + decltype(uc)::value + 1 < TT) { if (row(KA + 1 + decltype(uc)::value + 1)) rq += ld; }
+                    }
                     asm volatile("" : "+v"(rq));
                 });
                 static_for<KA + 1, TT>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
+                    if (!row(t)) return;
                     const double rt = (double)ahead[(t - KA - 1) % AHEAD];
                     if constexpr (t + AHEAD < TT) {
-                        ahead[(t - KA - 1) % AHEAD] = __uint_as_float(*rq);
-                        if constexpr (t + AHEAD + 1 < TT) rq += ld;
+                        if (row(t + AHEAD)) {
+                            ahead[(t - KA - 1) % AHEAD] = __uint_as_float(*rq);
+                            if constexpr (t + AHEAD + 1 < TT) { if (row(t + AHEAD + 1)) rq += ld; }
+                        }
                         asm volatile("" : "+v"(rq));
                     }
                     static_for<0, (t - KA + GW - 1) / GW>([&](auto gc) {
@@ -2450,7 +2465,8 @@ k_discounted_return_lane(PowTable pw, const float *__restrict__ reward_tb, int64
             }
         }
     }
-    wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
+    if constexpr (RT) wave_store_returns_rt<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane, T);
+    else wave_store_returns<TT, TR>(acc, reinterpret_cast<double *>(lds_raw[wave]), G, base, n, lane);
 }
 
 // G rows from the step-ok words of a rollout launch (k_rollout<..., OKB>, k_episode): same arithmetic as above,
@@ -3653,12 +3669,24 @@ int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, in
         const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
         hipStream_t st = (hipStream_t)stream;
         if (T == 50)
-            hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
+            hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok, T);
         else if (T == 25)
-            hipLaunchKernelGGL((k_discounted_return_lane<25, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
+            hipLaunchKernelGGL((k_discounted_return_lane<25, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok, T);
         else
-            hipLaunchKernelGGL((k_discounted_return_lane<10, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok);
+            hipLaunchKernelGGL((k_discounted_return_lane<10, DRM_EXACT, DR_LANE_WPB>), pgrid, pblock, 0, st, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok, T);
         return check_launch("k_discounted_return_lane");
+    }
+    if (T <= 64 && ld < ((int64_t)1 << 28)) {              // every other horizon up to 64: the same form with 32 or 64 accumulators
+        const PowTable tab = pow_table(gamma, T);
+        const int plain_ok = gamma_is_subtractable(gamma, T) ? 1 : 0;
+        const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
+        if (T <= 32)
+            hipLaunchKernelGGL((k_discounted_return_lane<32, DRM_EXACT, DR_LANE_WPB, G_TILE_ROWS, true>), pgrid, pblock, 0,
+                               (hipStream_t)stream, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok, T);
+        else
+            hipLaunchKernelGGL((k_discounted_return_lane<64, DRM_EXACT, DR_LANE_WPB, G_TILE_ROWS, true>), pgrid, pblock, 0,
+                               (hipStream_t)stream, tab, d_reward_tb, n, ld, gamma, d_G, plain_ok, T);
+        return check_launch("k_discounted_return_lane<rt>");
     }
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
     PowTableBig big;
@@ -3686,9 +3714,11 @@ int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, 
         std::memset(&none, 0, sizeof(none));
         const dim3 pgrid((unsigned)((n + 64 * DR_LANE_WPB - 1) / (64 * DR_LANE_WPB))), pblock(64 * DR_LANE_WPB);
         hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, DR_LANE_WPB>), pgrid, pblock, 0, (hipStream_t)stream,
-                           none, d_reward_tb, n, ld, gamma, d_G, 0);
+                           none, d_reward_tb, n, ld, gamma, d_G, 0, T);
         return check_launch("k_discounted_return_lane<scan>");
     }
+    // (other horizons: the LDS-tile scan below -- the 32 / 64-accumulator register form measured SLOWER for the scan, 178 against
+    // 132 us at T = 40 and 1 M envs: an O(T) scan has no arithmetic to hide behind its registers' cost in occupancy)
     const int R = T | 1;
     const size_t lds = (size_t)64 * R * sizeof(double);
     if (lds > 64 * 1024)

@@ -641,3 +641,41 @@ def test_return_from_step_ok_words_at_any_horizon(T):
         flat.fill_(7.0)
     if T >= 16:
         assert (rew.cpu().numpy() == -1.0).any() and (rew.cpu().numpy() == 0.0).any()
+
+
+@pytest.mark.parametrize('T', [1, 2, 3, 9, 24, 26, 31, 32, 33, 40, 49, 51, 63, 64])
+def test_returns_from_a_reward_stream_at_any_horizon(T):
+    """bpg_discounted_return / bpg_discounted_return_scan at horizons without an instantiation of their own, T <= 64: the
+    register-resident form with 32 or 64 accumulators in which rows t >= T are neither read nor contribute and only the first
+    T entries of a row leave.  Exact form bit for bit the oracle's float64 accumulation -- env rewards (the conditional
+    subtraction), arbitrary floats (the general product + sum), batches in which only some waves are plain, a negative gamma
+    -- on padded rows and with G 8 bytes off a 16-byte boundary; scan form inside its stated bound.  Nothing is written
+    past the last row."""
+    rng = np.random.RandomState(100 + T)
+    B = 64 * 3 + 21
+    gamma = 1.0 - 1.0 / max(T, 2)
+    env_r = np.where(rng.rand(T, B) < 0.6, -1.0, -0.0).astype(np.float32)
+    gen_r = rng.normal(size=(T, B)).astype(np.float32)
+    mixed = env_r.copy()
+    mixed[:, 64:128] = gen_r[:, 64:128]                       # the second wave runs the general path, the others the plain one
+    mixed[T // 2, -1] = np.float32(0.0)                        # +0.0f is not an env reward either
+    for name, r, g in (('env', env_r, gamma), ('general', gen_r, gamma), ('mixed', mixed, gamma), ('negative gamma', env_r, -0.5)):
+        want = oracle_G(r, g)
+        src = bpg.time_major_empty(T, B, torch.float32, DEV)
+        src.copy_(torch.as_tensor(r))
+        flat = torch.full((B * T + 3,), 7.0, dtype=torch.float64, device=DEV)
+        for off in (0, 1):
+            k = off if flat.data_ptr() % 16 == 0 else 1 - off
+            G = flat[k:k + B * T].view(B, T)
+            assert (G.data_ptr() % 16 == 0) == (off == 0)
+            bpg.discounted_return(src, g, out=G)
+            torch.cuda.synchronize()
+            same_bits64(G.cpu().numpy(), want)
+            assert float(flat[k + B * T:].min()) == 7.0 and (k == 0 or float(flat[0]) == 7.0)
+            flat.fill_(7.0)
+        if g > 0:
+            got = bpg.discounted_return_scan(src, g).cpu().numpy()
+            pw = g ** np.arange(T)
+            bound = np.stack([[4 * T * 2.0 ** -53 * float(np.sum(pw[:T - t] * np.abs(r[t:, b].astype(np.float64))))
+                               for t in range(T)] for b in range(B)])
+            assert np.all(np.abs(got - want) <= bound), (name, float(np.max(np.abs(got - want) - bound)))

@@ -120,9 +120,9 @@ rw = [bpg.time_major_empty(T2, B, torch.float32, dev) for _ in range(2)]
 for r in rw:
     r.copy_(-(torch.rand(T2, B, device=dev) < 0.5).float())
 Gs = [torch.empty(B, T2, dtype=torch.float64, device=dev) for _ in range(2)]
-timed('discounted_return, T = 40 (LDS-tile kernel)', B * 12 * T2,
+timed('discounted_return, T = 40 (64-accumulator register form)', B * 12 * T2,
       [lambda r=r, g=g: _lib.check(L.bpg_discounted_return_ld(P(r), B, int(r.stride(0)), T2, 0.98, P(g), 0, None)) for r, g in zip(rw, Gs)])
-timed('discounted_return_scan, T = 40', B * 12 * T2,
+timed('discounted_return_scan, T = 40 (LDS-tile kernel)', B * 12 * T2,
       [lambda r=r, g=g: _lib.check(L.bpg_discounted_return_scan(P(r), B, int(r.stride(0)), T2, 0.98, P(g), 0, None)) for r, g in zip(rw, Gs)])
 m40 = bpg.time_major_empty(T2, B, torch.int32, dev)
 _lib.check(L.bpg_synth_masks_ld(env._h, 0, T2, P(m40), int(m40.stride(0)), None))

@@ -179,7 +179,7 @@ static int run(char mode, int64_t B)
         for (int rep = 0; rep < 2; rep++) {
             ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024);                       // round 2: reward + flags streams ...
             TIME("  + k_discounted_return_lane<50, exact>", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50));
             ROLL(2, 1024, 5, false, 2, 2, 1, 1, 1024);                       // flags + step-ok words ...
             ROLL(2, 1024, 5, false, 0, 2, 1, 1, 1024);                       // (G alone: no per-step stream at all)
             TIME("  + k_returns_from_okbits_lane<50>", gbytes,
@@ -193,11 +193,11 @@ static int run(char mode, int64_t B)
         for (int k = 0; k < b.NB; k++) { rot = k; ROLL(2, 1024, 5, false, 3, 2, 1, 0, 1024); }
         for (int rep = 0; rep < 3; rep++) {
             TIME("k_discounted_return_lane<50, exact> (plain rewards)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50));
             TIME("k_discounted_return_lane<50, scan>", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, WPB>), lg, lb, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50));
             TIME("k_discounted_return_lane<50, exact> (masks as floats: general path)", rbytes,
-                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG, 1));
+                 hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, WPB>), lg, lb, 0, 0, pw, (const float *)M, B, b.LD, 0.98, GG, 1, 50));
             TIME("k_returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),
                  hipLaunchKernelGGL((k_returns_from_okbits_lane<50, WPB>), lg, lb, 0, 0, pw, (const uint64_t *)b.okbits, GG, B));
             {   // the same bytes with no transposition (rows of the padded reward stream are read as one linear array)
@@ -211,9 +211,9 @@ static int run(char mode, int64_t B)
             do {                                                                                                                   \
                 const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
                 TIME("  waves/block " #W ": lane<50, exact>", rbytes,                                                              \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1)); \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50)); \
                 TIME("  waves/block " #W ": lane<50, scan>", rbytes,                                                               \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));  \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50));  \
                 TIME("  waves/block " #W ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),                                 \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
@@ -221,9 +221,9 @@ static int run(char mode, int64_t B)
             do {                                                                                                                   \
                 const dim3 g_((unsigned)((B + 64 * W - 1) / (64 * W))), b_(64 * W);                                                \
                 TIME("  waves/block " #W " tile rows " #TRR ": lane<50, exact>", rbytes,                                            \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1)); \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_EXACT, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50)); \
                 TIME("  waves/block " #W " tile rows " #TRR ": lane<50, scan>", rbytes,                                             \
-                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1));  \
+                     hipLaunchKernelGGL((k_discounted_return_lane<50, DRM_SCAN, W, TRR>), g_, b_, 0, 0, pw, (const float *)R, B, b.LD, 0.98, GG, 1, 50));  \
                 TIME("  waves/block " #W " tile rows " #TRR ": returns_from_okbits_lane<50>", (double)B * (8 + 8 * T),               \
                      hipLaunchKernelGGL((k_returns_from_okbits_lane<50, W, TRR>), g_, b_, 0, 0, pw, (const uint64_t *)b.okbits, GG, B)); \
             } while (0)
