@@ -431,9 +431,11 @@ int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream);
 int bpg_discounted_return(const float *d_reward_tb, int64_t n, int T, double gamma,
                           double *d_G, int device_id, void *stream);
 /* Same for a reward stream with row stride ld >= n (the padded rows bpg_rollout writes).
- * T = 50 / 25 / 10: one env per lane; a wave whose rewards are all -1.0f / -0.0f (the only values
+ * T <= 64: one env per lane, the T returns in registers (T = 50 / 25 / 10 have instantiations of their own, every other
+ * horizon runs the 32- or 64-accumulator form); a wave whose rewards are all -1.0f / -0.0f (the only values
  * compute_reward produces, fetch_env.py:141-143) replaces product + sum by a conditional subtraction of
- * gamma**k -- exact for those rewards, same bits --, any other wave runs the general product + sum. */
+ * gamma**k -- exact for those rewards, same bits --, any other wave runs the general product + sum.
+ * 64 < T <= 319: the returns accumulate in an LDS tile. */
 int bpg_discounted_return_ld(const float *d_reward_tb, int64_t n, int64_t ld, int T, double gamma,
                              double *d_G, int device_id, void *stream);
 /* the same return as an O(T) reverse scan G[t] = fma(gamma, G[t+1], r[t]) instead of the
