@@ -2493,7 +2493,7 @@ k_returns_from_okbits_lane(PowTable pw_at_kernarg_offset_0, const uint64_t *__re
 // the first T accumulators are bit for bit those of a T-step rollout -- only steps t < T ever contribute to them), the
 // lag passes of steps that no lane needs are skipped wave-uniformly, and only the first T entries of a row leave.
 // (The reference's tasks all use T = 50, which has its own instantiation; this one takes the cliff out of every other
-// horizon: T = 40 at 1 M envs 346 us through the LDS-tile kernel below, profiles/r04_survey_secondary.log.)
+// horizon: T = 40 at 1 M envs took 346 us through the LDS-tile kernel this one replaces, 71 us now, profiles/r04_survey_secondary.log.)
 template <int TT, int WPB, int TR = G_TILE_ROWS>
 __global__ void __launch_bounds__(64 * WPB)
 k_returns_from_okbits_lane_rt(PowTable pw_at_kernarg_offset_0, const uint64_t *__restrict__ okbits, double *__restrict__ G,
