@@ -19,8 +19,17 @@ L = _lib.lib()
 env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=dev, seed=0)
 ng = (torch.arange(B, device=dev, dtype=torch.int32) * 7) % 3
 LD = int(L.bpg_row_stride(B))
-r = [torch.empty((T, LD), dtype=torch.float32, device=dev) for _ in range(2)]
-f = [torch.empty((T, LD), dtype=torch.uint8, device=dev) for _ in range(2)]
+WHERE = sys.argv[3] if len(sys.argv) > 3 else 'first'          # reward / flag arrays allocated before ('first'), after ('last') or in the
+                                                               # middle of ('mid') the mask arrays
+
+
+def out_arrays():
+    return ([torch.empty((T, LD), dtype=torch.float32, device=dev) for _ in range(2)],
+            [torch.empty((T, LD), dtype=torch.uint8, device=dev) for _ in range(2)])
+
+
+if WHERE == 'first':
+    r, f = out_arrays()
 src = torch.empty((T, LD), dtype=torch.int32, device=dev)
 _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, C.c_void_p(src.data_ptr()), LD, None))
 cnt = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -38,6 +47,10 @@ for k in range(N):
         m.copy_(src)
         keep.append(m)
         ptrs.append(m.data_ptr())
+    if WHERE == 'mid' and k == N // 2:
+        r, f = out_arrays()
+if WHERE == 'last':
+    r, f = out_arrays()
 torch.cuda.synchronize()
 
 
@@ -56,6 +69,6 @@ def timed(pp, n=16):
 
 
 us = [timed([ptrs[k], ptrs[k + 1]]) for k in range(0, N - 1, 2)]
-print(json.dumps({'mode': MODE, 'us_per_launch_on_pairs': us, 'addresses_GiB': [round(p / 2**30, 3) for p in ptrs]}))
+print(json.dumps({'mode': MODE, 'reward_flag_arrays': WHERE, 'reward_GiB': [round(x.data_ptr() / 2**30, 3) for x in r], 'us_per_launch_on_pairs': us, 'addresses_GiB': [round(p / 2**30, 3) for p in ptrs]}))
 again = [timed([ptrs[k], ptrs[k + 1]]) for k in range(0, N - 1, 2)]
 print(json.dumps({'again': again}))
