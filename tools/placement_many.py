@@ -28,6 +28,8 @@ def out_arrays():
             [torch.empty((T, LD), dtype=torch.uint8, device=dev) for _ in range(2)])
 
 
+BALLAST_MB = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # held allocation made before everything else
+ballast = torch.empty(BALLAST_MB << 20, dtype=torch.uint8, device=dev) if BALLAST_MB else None
 if WHERE == 'first':
     r, f = out_arrays()
 src = torch.empty((T, LD), dtype=torch.int32, device=dev)
@@ -69,6 +71,6 @@ def timed(pp, n=16):
 
 
 us = [timed([ptrs[k], ptrs[k + 1]]) for k in range(0, N - 1, 2)]
-print(json.dumps({'mode': MODE, 'reward_flag_arrays': WHERE, 'reward_GiB': [round(x.data_ptr() / 2**30, 3) for x in r], 'us_per_launch_on_pairs': us, 'addresses_GiB': [round(p / 2**30, 3) for p in ptrs]}))
+print(json.dumps({'mode': MODE, 'ballast_MB': BALLAST_MB, 'reward_flag_arrays': WHERE, 'reward_GiB': [round(x.data_ptr() / 2**30, 3) for x in r], 'us_per_launch_on_pairs': us, 'addresses_GiB': [round(p / 2**30, 3) for p in ptrs]}))
 again = [timed([ptrs[k], ptrs[k + 1]]) for k in range(0, N - 1, 2)]
 print(json.dumps({'again': again}))
