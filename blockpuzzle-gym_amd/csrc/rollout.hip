@@ -1,0 +1,442 @@
+// rollout.hip -- RolloutStudent.generate_rollouts' inner loop (rollout.py:100-153) for T steps in ONE launch: the
+// packed state stays in registers, masks / rewards / flags are time-major coalesced streams.
+#include "state.hip.h"
+
+namespace bpgk {
+
+// PIPE: software-pipelined mask requests (see the loop); used for the latency-bound batch sizes.
+// The plain loop (PIPE = false: UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound
+// fat shape runs: with >= 16 waves per CU other waves cover the round trips.
+// RESET: the launch starts with reset_all_rollouts (rollout.py:79).  Compile-time because the
+// elapsed counter is then the same for every lane (step t of the launch), so the time-limit
+// test, the saturation and the generator's Weyl term run on the scalar unit.
+// LB: the largest block the instantiation is ever launched with (the register budget follows from it:
+// 128 VGPRs at 1024 lanes, 512 / waves-per-SIMD below).
+// OKB: the launch also stores every env's step-ok word (bit t = the success condition held at step t, i.e. the
+// step reward was -0.0f; T <= 64) into okbits[n] -- 8 bytes per env instead of a 4 T-byte reward stream -- from
+// which k_returns_from_okbits computes the policy-gradient return.  (Computing G inside this launch, right
+// after a wave's steps, was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs,
+// profiles/r03_tune_pg_path.log -- the memory-bound step phase and the VALU-bound return phase of the same
+// waves do not overlap -- and removed.)
+// MULTI: `rollouts` consecutive rollouts in this ONE launch (each: reset, T steps, success count into its own counter
+// word), rollout r on rows r*T .. r*T+T-1 of the streams -- exactly what `rollouts` launches in a row would do, without
+// their fixed cost (5-6 us per launch, which is all a 65 536-env rollout has left to lose).  Envs are independent and a
+// lane only ever touches its own, so nothing has to be synchronised between the rollouts of a launch; the counts go out
+// as plain atomics that drain behind the next rollout's steps.
+// BPG_TL(slot) / BPG_ROLLOUT_MINB: hooks.hip.h (empty / 1 in the library build).
+template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
+          bool MULTI = false, bool RET = false>
+__global__ void __launch_bounds__(LB, BPG_ROLLOUT_MINB)
+k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks_all,
+          uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
+          int64_t ld_masks, int64_t ld_out,
+          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts,
+          uint32_t *__restrict__ ep_return_all)
+{
+    static_assert(!MULTI || (RESET && !OKB), "several rollouts per launch: each starts with its reset; no step-ok words");
+    using Vec = typename LaneVec<EPL>::vec;
+    using Fl = typename LaneVec<EPL>::fl;
+    const int64_t nvec = n / EPL;               // the host guarantees n, ld_masks, ld_out % EPL == 0
+    const int64_t ldm = ld_masks / EPL, ldo = ld_out / EPL;      // row strides of the (T, ld) streams
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (ca.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *ca.zero_next = 0ull;
+    BPG_TL(0);
+    int tl_pass = 0;
+    (void)tl_pass;
+    for (int ro = 0; ro < (MULTI ? rollouts : 1); ro++) {
+    const uint32_t *__restrict__ masks = masks_all + (MULTI ? (int64_t)ro * T * ld_masks : 0);
+    uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
+    uint8_t *__restrict__ flags_tb = flags_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
+    uint32_t *__restrict__ ep_return = ep_return_all ? ep_return_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
+    uint32_t nsucc = 0;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        uint32_t an[EPL] = {}, ee[EPL] = {};
+        // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
+        // no wave starts its episode behind a memory round trip
+        if (!(RESET && rc.is_variation)) {
+            unpack<EPL>(reinterpret_cast<const Vec *>(now)[v], an);
+            unpack<EPL>(reinterpret_cast<const Vec *>(ever)[v], ee);
+        }
+        SynthLane sl[EPL];
+        // step_core() with the state unpacked for the duration of the launch: the touching set,
+        // the ever set (+ num_objs bits, untouched), the elapsed counter and the success latch (as
+        // an all-ones / zero mask) each in a register of their own, and the two comparisons of
+        // step_core turned into sign-bit arithmetic -- 11 instead of ~20 instructions per env-step.
+        uint32_t cm[EPL], ev[EPL], el[EPL], lat[EPL], stk[EPL];
+        uint64_t okb[EPL];                          // OKB: bit t = the success condition held at step t
+        // RET: steps of this launch whose success condition held, counted for every env (one subtraction per
+        // env-step): the undiscounted episode return is -(T - nok), bpg_rollout_args.d_episode_return.  Compile-time,
+        // because the contacts-in-kernel form lives on occupancy and loses a wave per SIMD to the two extra registers.
+        // With OKB the count is the population of the step-ok word and costs nothing per step.
+        constexpr bool COUNT = RET && !OKB;
+        uint32_t nok[EPL] = {};
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
+            if (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
+            cm[k] = an[k] & PAIR_BITS;
+            el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
+            ev[k] = ee[k] & ~SUCC_BIT;
+            lat[k] = (uint32_t)((int32_t)ee[k] >> 31);
+            // pairs that are never demoted (StepConst); the synthetic source only emits pairs of present objects
+            stk[k] = (SRC == SRC_SYNTH) ? 0u : sticky_of(c, ee[k]);
+            okb[k] = 0ull;
+        }
+        const Vec *mrow = reinterpret_cast<const Vec *>(masks) + v;
+        Vec *rrow = reinterpret_cast<Vec *>(reward_tb) + v;
+        Fl *frow = reinterpret_cast<Fl *>(flags_tb) + v;
+        // ubit = 1 << (step within its batch of UNROLL): the step-ok bits of a batch collect in a 32-bit word with
+        // compile-time masks and join the 64-bit word once per batch (OKB)
+        uint32_t okpart[EPL] = {};
+        auto one_step = [&](int t, const uint32_t *mt, uint32_t ubit) {
+            uint32_t rb[EPL], fl[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+                if (RESET) el[k] = (uint32_t)t;            // uniform: elapsed == step of the launch (T <= 1023)
+                if (SRC == SRC_SYNTH) cm[k] = synth_mask(sl[k], el[k]) & c.valid;
+                else cm[k] = (mt[k] & c.valid) | (cm[k] & stk[k]);
+                ev[k] |= cm[k];
+                const uint32_t bad = (c.want_touch & ~cm[k]) | (c.want_never & ev[k]);    // < 2^21
+                const uint32_t okm = (uint32_t)((int32_t)(bad - 1u) >> 31);               // ~0 iff bad == 0
+                lat[k] |= okm;
+                if (COUNT) nok[k] -= okm;                                                 // okm is 0 or -1
+                if (OKB) okpart[k] |= okm & ubit;
+                el[k] = min(el[k] + 1u, ELAPSED_MAX);
+                const uint32_t dn = ((c.max_steps - 1u - el[k]) >> 30) & (uint32_t)BPG_FLAG_DONE;   // el >= max_steps
+                rb[k] = RBITS_FAIL ^ (okm & (RBITS_FAIL ^ RBITS_OK));
+                fl[k] = (lat[k] & (uint32_t)BPG_FLAG_SUCCESS) | (okm & (uint32_t)BPG_FLAG_STEP_OK) | dn;
+            }
+            if (OUT & OUT_REWARD) st_vec<NT, EPL>(&rrow[(int64_t)t * ldo], rb);
+            if (OUT & OUT_FLAGS) {
+                uint32_t f = fl[0];
+#pragma unroll
+                for (int k = 1; k < EPL; k++) f |= fl[k] << (8 * k);
+                st_1<NT>(&frow[(int64_t)t * ldo], (Fl)f);
+            }
+            // The contacts-in-kernel form is arithmetic-co-limited and lives on occupancy.  Left alone, the
+            // scheduler interleaves the generators of all UNROLL steps (47 VGPRs in one build, 107-140 in the next,
+            // depending on which side of the SGPR limit a few unrelated kernel arguments push it); a scheduling
+            // fence per step keeps every step's ~70 instructions together: 50 VGPRs, 7-8 waves per SIMD.
+            if (SRC == SRC_SYNTH) __builtin_amdgcn_sched_barrier(0);
+        };
+        auto flush_ok = [&](int t0) {
+            if (OKB) {
+#pragma unroll
+                for (int k = 0; k < EPL; k++) {
+                    okb[k] |= (uint64_t)okpart[k] << t0;
+                    okpart[k] = 0u;
+                }
+            }
+        };
+        // Steps run in batches of UNROLL.  The masks of batch b+1 are requested BEFORE the rewards /
+        // flags of batch b are stored: vector-memory operations retire in issue order (one vmcnt
+        // counter for loads and stores), so a load issued behind a store cannot be consumed until
+        // that store has been acknowledged by the memory side -- with the loads in front, a batch
+        // waits for one memory latency instead of a store round trip plus a load round trip.
+        const int nb = T / UNROLL;
+        if constexpr (PIPE && SRC == SRC_MASKS) {
+            Vec bufA[UNROLL], bufB[UNROLL];
+            if (nb > 0) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) bufA[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)u * ldm]);
+            }
+            auto batch = [&](int t0, const Vec *cur, Vec *nxt, bool prefetch) {
+                if (prefetch) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) nxt[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(t0 + UNROLL + u) * ldm]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of this batch's stores
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    uint32_t mt[EPL];
+                    unpack<EPL>(cur[u], mt);
+                    one_step(t0 + u, mt, 1u << u);
+                }
+                flush_ok(t0);
+                if (t0 == 0 && tl_pass < 2) BPG_TL(1 + 4 * tl_pass);
+            };
+            // Two batches per trip with ping-pong register buffers (a register copy cur = nxt would
+            // have to wait for the prefetch it copies), and the tail peeled so that every batch in
+            // the loop prefetches unconditionally (a conditional prefetch makes the compiler place
+            // the wait for the merged worst case at the loop head).
+            int b = 0;
+            for (; b + 2 < nb; b += 2) {
+                batch(b * UNROLL, bufA, bufB, true);
+                batch((b + 1) * UNROLL, bufB, bufA, true);
+            }
+            if (nb - b == 2) {
+                batch(b * UNROLL, bufA, bufB, true);
+                batch((b + 1) * UNROLL, bufB, bufA, false);
+            } else if (nb - b == 1) {
+                batch(b * UNROLL, bufA, bufB, false);
+            }
+        } else {
+            for (int b = 0; b < nb; b++) {
+                Vec cur[UNROLL];
+                if (SRC == SRC_MASKS) {
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) cur[u] = ld_vec<NTL, EPL>(&mrow[(int64_t)(b * UNROLL + u) * ldm]);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    uint32_t mt[EPL] = {};
+                    if (SRC == SRC_MASKS) unpack<EPL>(cur[u], mt);
+                    one_step(b * UNROLL + u, mt, 1u << u);
+                }
+                flush_ok(b * UNROLL);
+                if (b == 0 && tl_pass < 2) BPG_TL(1 + 4 * tl_pass);
+            }
+        }
+        if (tl_pass < 2) BPG_TL(2 + 4 * tl_pass);
+        for (int t = nb * UNROLL; t < T; t++) {          // T % UNROLL leftover steps
+            uint32_t mt[EPL] = {};
+            if (SRC == SRC_MASKS) unpack<EPL>(mrow[(int64_t)t * ldm], mt);
+            one_step(t, mt, 1u << (t - nb * UNROLL));
+        }
+        flush_ok(nb * UNROLL);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            an[k] = cm[k] | (el[k] << ELAPSED_SHIFT);
+            ee[k] = ev[k] | (lat[k] & SUCC_BIT);
+            nsucc += lat[k] & 1u;
+        }
+        // (plain stores: nontemporal state stores were measured 0.8 us SLOWER per 1 M-env launch, 84.8 against 84.0 us
+        // on one box, profiles/r04_ab_state_stores.log -- the 8 MB a launch leaves dirty are not what the boundary costs)
+        reinterpret_cast<Vec *>(now)[v] = pack<EPL>(an);
+        reinterpret_cast<Vec *>(ever)[v] = pack<EPL>(ee);
+        if constexpr (OKB) {
+#pragma unroll
+            for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
+        }
+        if constexpr (RET || OKB) {
+            if (ep_return) {                        // uniform (an OKB launch may or may not be asked for the return)
+                // r[0] + r[1] + ... of T float32 rewards in {-1.0f, -0.0f}: -(number of -1.0f), -0.0f if there is none
+                uint32_t rt[EPL];
+#pragma unroll
+                for (int k = 0; k < EPL; k++) {
+                    const uint32_t held = OKB ? (uint32_t)__popcll(okb[k]) : nok[k];
+                    rt[k] = __float_as_uint(-(float)((uint32_t)T - held));
+                }
+                reinterpret_cast<Vec *>(ep_return)[v] = pack<EPL>(rt);
+            }
+        }
+        if (tl_pass < 2) BPG_TL(3 + 4 * tl_pass);
+        tl_pass++;
+    }
+    BPG_TL(11);
+    if (ca.count) {
+        if (MULTI) {
+            block_count_add(nsucc, CountArgs{ca.count + ro, nullptr, nullptr});
+            __syncthreads();                       // the partial sums are written again by the next rollout
+        } else {
+            block_count_add(nsucc, ca);
+        }
+    }
+    BPG_TL(12);
+    }
+    BPG_TL(13);
+}
+
+// Launch shape of the fused rollout, chosen from the batch size (tools/tune_round3.hip mode A,
+// profiles/r03_tune_mid_shapes.log; round 2: profiles/r02_tune_geometry.log; MI355X, T = 50, masks read cold
+// from HBM).  The kernel is a pure stream with T independent requests per lane, so what matters is (a) enough
+// resident waves on every CU to cover the HBM latency and (b), when there are not, that no wave waits for a
+// store round trip before it can consume a load (the pipelined loop).  rocprofv3 means per launch
+// (profiles/r03_pmc/kernel_means.json), round 1's plain 4/lane x 1024 shape in parentheses:
+//     65 536      9.9 us  (49)   1/lane, 256-lane blocks, pipelined, 10 rows in flight
+//     131 072    14.5 us  (45)   1/lane, 256, pipelined, 5 rows in flight
+//     262 144    23.5 us  (52)   2/lane, 256, plain loop
+//     524 288    43.8 us  (58)   2/lane, 1024, plain
+//     1 048 576  82-91 us (89)   2/lane, 1024, plain (shifted rows, bpg_row_stride; box-dependent)
+//     4 194 304  351 us   (372)  2/lane, 256, plain, when the rows are a power of two apart (1024 lanes: 468 us)
+// 8-byte accesses (512 B per wave instruction) stream as fast as 16-byte ones here, so there is no
+// 4-per-lane instantiation.  One returning atomic per block on a sharded counter (block_count_add).
+constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
+struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
+
+RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
+                                 const void *flags, const void *ep_return = nullptr)
+{
+    // 2 envs per lane need an even batch, even row strides and 8-byte aligned mask / reward streams
+    // (2-byte flags)
+    const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
+                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0 && ((uintptr_t)ep_return & 7u) == 0;
+    RolloutGeometry g;
+    g.unroll = 5;
+    if (ok2 && n >= 131072 && !masks) {
+        // contacts generated in-kernel: write-only and co-limited by the generator's arithmetic.  One
+        // short-lived 256-lane block per 512 envs (no grid cap: blocks start in address order as
+        // earlier ones retire), 10 steps per trip: 51 vs 53-58 us at 1 M envs, 178 vs 190-220 us at
+        // 4 M (profiles/r02_tune_geometry_synth.log)
+        g.epl = 2;
+        g.block = 256;
+        g.pipe = false;
+        g.unroll = 10;
+        g.grid = (int)((n / 2 + 255) / 256);
+        return g;
+    }
+    if (ok2 && n >= ROLLOUT_EPL2_FROM) {
+        // 2 envs per lane, plain loop.  From 524 288 envs on in 1024-lane blocks (one per CU, 16 waves cover
+        // the round trips); below that -- and from 4 M envs on when the rows are a power of two apart -- in
+        // 256-lane blocks.  (Round 2 ran a software-pipelined 2-per-lane loop here whose ping-pong buffers
+        // spilled to scratch under the 1024-lane register bound it was compiled with; with an honest bound it
+        // needs 200 VGPRs and is no faster than the plain loop: profiles/r03_tune_mid_shapes.log.)
+        g.epl = 2;
+        const bool aliased = ld_masks % 4096 == 0 || ld_out % 4096 == 0;
+        const bool fat = n >= 524288 && (n < 4194304 || !aliased);
+        g.block = fat ? 1024 : 256;
+        g.pipe = false;
+    } else {
+        // 1 env per lane, software-pipelined requests (latency-bound sizes): 10 rows in flight per lane below
+        // ~100 K envs, 5 above (profiles/r03_tune_mid_shapes.log)
+        g.epl = 1;
+        g.block = 256;
+        g.pipe = true;
+        g.unroll = n < ROLLOUT_UNROLL5_FROM ? 10 : 5;
+    }
+    const int64_t lanes = n / g.epl;
+    int64_t grid = (lanes + g.block - 1) / g.block;
+    if (grid < 1) grid = 1;
+    const int64_t cap = 256 * (1024 / g.block);           // at most 1024 lanes' worth of blocks per CU
+    g.grid = (int)(grid > cap ? cap : grid);
+    return g;
+}
+
+
+}  // namespace bpgk
+
+extern "C" {
+
+int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
+{
+    if (!b || !args) return fail(BPG_ERR_ARG, "NULL argument");
+    // struct versioning (include/bpgym.h): fields the caller's header did not have are zero; bytes this library does
+    // not know must be zero
+    static_assert(offsetof(bpg_rollout_args, gamma) + sizeof(double) == BPG_ROLLOUT_ARGS_MIN_SIZE, "BPG_ROLLOUT_ARGS_MIN_SIZE");
+    bpg_rollout_args local;
+    if (int rc = take_args(local, args, BPG_ROLLOUT_ARGS_MIN_SIZE, "bpg_rollout_args")) return rc;
+    const bpg_rollout_args *a = &local;
+    if (a->T < 1 || a->T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
+    if ((a->d_success_count && ((uintptr_t)a->d_success_count & 7u)) ||
+        (a->d_zero_count && ((uintptr_t)a->d_zero_count & 7u)))
+        return fail(BPG_ERR_ARG, "counters must be 8-byte aligned");
+    if (a->d_success_count && a->d_success_count == a->d_zero_count)
+        return fail(BPG_ERR_ARG, "d_zero_count must differ from d_success_count");
+    DeviceGuard guard(b->device);
+    const StepConst c = step_const(b);
+    const SynthConst s = synth_const(b);
+    const ResetConst rc = reset_const(b, a->reset_first ? 1 : 0, a->d_num_grey);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *rw = reinterpret_cast<uint32_t *>(a->d_reward_tb);
+    const CountArgs ca = count_args(b, a->d_success_count, a->d_zero_count);
+    const bool episode = a->d_ep_ag || a->d_ep_g || a->d_ep_success;
+    const int64_t ldm = a->ld_masks ? a->ld_masks : b->n, ldo = a->ld_out ? a->ld_out : b->n;
+    if (ldm < b->n || ldo < b->n) return fail(BPG_ERR_ARG, "ld_masks / ld_out must be 0 or >= n_envs");
+    // The policy-gradient return (policy_gradient/rollout.py:255-258).  Up to 64 steps the step rewards of an
+    // env are one 64-bit word: the rollout launch stores it (8 bytes per env, handle-owned) and a second launch
+    // on the same stream expands the words into the G rows -- no reward stream is written or read.  Longer
+    // horizons go through the reward stream.
+    enum { G_NONE, G_OKBITS, G_FROM_REWARD } gmode = G_NONE;
+    if (a->d_G) {
+        if (!(a->gamma == a->gamma)) return fail(BPG_ERR_ARG, "gamma is NaN");
+        if (((uintptr_t)a->d_G & 7u) != 0) return fail(BPG_ERR_ARG, "d_G must be 8-byte aligned");
+        if (a->T <= 64 && gamma_is_subtractable(a->gamma, a->T)) gmode = G_OKBITS;
+        else if (a->T > DR_TMAX) return fail(BPG_ERR_ARG, "d_G needs T <= 319");
+        else if (!a->d_reward_tb)
+            return fail(BPG_ERR_ARG, "d_G with T > 64, a negative gamma or overflowing powers of gamma needs d_reward_tb "
+                                     "(the return is then computed from the reward stream)");
+        else gmode = G_FROM_REWARD;
+    }
+    if (a->d_episode_return && ((uintptr_t)a->d_episode_return & 3u) != 0)
+        return fail(BPG_ERR_ARG, "d_episode_return must be 4-byte aligned");
+    if (gmode == G_OKBITS && !b->d_okbits) {
+        // the step-ok words are handle-owned scratch, allocated by the first call that asks for d_G: a hipMalloc is not
+        // a stream operation, so that call must not sit inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(BPG_ERR_ARG, "the first bpg_rollout call with d_G allocates the handle's step-ok words: make it once "
+                                     "outside the stream capture (a warm-up call does)");
+        if (hipMalloc(&b->d_okbits, (size_t)((b->n + 1) & ~(int64_t)1) * sizeof(uint64_t)) != hipSuccess) {
+            b->d_okbits = nullptr;
+            return fail(BPG_ERR_HIP, "hipMalloc failed for the step-ok words");
+        }
+    }
+    uint64_t *okbits = gmode == G_OKBITS ? b->d_okbits : nullptr;
+    // several rollouts in one launch (stream path only): rollout r = reset + T steps + count on rows r*T .. of the streams
+    const int rollouts = a->rollouts > 1 ? a->rollouts : 1;
+    if (a->rollouts < 0 || a->rollouts > 4096) return fail(BPG_ERR_ARG, "rollouts must be in 0..4096");
+    if (rollouts > 1 && (!a->reset_first || episode || a->d_G))
+        return fail(BPG_ERR_ARG, "rollouts > 1 needs reset_first and takes neither episode arrays nor d_G");
+    int rcode = BPG_OK;
+    if (!episode) {
+        const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
+        const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb,
+                                                     a->d_episode_return);
+        const dim3 grid(geo.grid), block(geo.block);
+#define BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, RET)                               \
+        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, MULTI, RET>), grid, block, 0, st, \
+                           b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits,  \
+                           rollouts, reinterpret_cast<uint32_t *>(a->d_episode_return))
+        // the in-loop counter only where the return is asked for and there is no step-ok word to take it from
+#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI)                                    \
+        do {                                                                                                  \
+            if (a->d_episode_return && !(OKB)) BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, false, MULTI, true); \
+            else BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, false);                   \
+        } while (0)
+#define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
+        do {                                                                                                  \
+            if (rollouts > 1) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, false, true);           \
+            else if (a->reset_first) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, OKB, false);     \
+            else BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, false, UNR, PIPE, LB, OKB, false);                        \
+        } while (0)
+#define BPG_LAUNCH_ROLLOUT_1(SRC, EPL, OUT, UNR, PIPE, LB)                                                     \
+        do {                                                                                                  \
+            if (okbits) BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, true);                              \
+            else BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, false);                                    \
+        } while (0)
+#define BPG_LAUNCH_ROLLOUT(SRC, EPL, UNR, PIPE, LB)                                                            \
+        do {                                                                                                  \
+            switch (out) {                                                                                    \
+            case 0: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 0, UNR, PIPE, LB); break;                                  \
+            case 1: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 1, UNR, PIPE, LB); break;                                  \
+            case 2: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 2, UNR, PIPE, LB); break;                                  \
+            default: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 3, UNR, PIPE, LB); break;                                 \
+            }                                                                                                 \
+        } while (0)
+        // the instantiations below are the only ones: LB is the block size the shape is launched with
+        if (a->d_masks) {
+            if (geo.epl == 2 && geo.block == 1024) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 1024);
+            else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 256);
+            else if (geo.unroll == 5) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 5, true, 256);
+            else BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 10, true, 256);
+        } else {                                   // nothing to request: the plain loop
+            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 2, 10, false, 256);
+            else BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 1, 5, false, 256);
+        }
+#undef BPG_LAUNCH_ROLLOUT
+#undef BPG_LAUNCH_ROLLOUT_1
+#undef BPG_LAUNCH_ROLLOUT_2
+#undef BPG_LAUNCH_ROLLOUT_3
+#undef BPG_LAUNCH_ROLLOUT_4
+        rcode = check_launch("k_rollout");
+    } else {
+        if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
+            (a->d_ep_success && !aligned4(a->d_ep_success)))
+            return fail(BPG_ERR_ARG, "episode buffers must be 16-byte aligned");
+        EpisodeLaunch e;
+        e.d_masks = a->d_masks; e.reward_tb = rw; e.flags_tb = a->d_flags_tb;
+        e.ep_ag = a->d_ep_ag; e.ep_g = a->d_ep_g; e.ep_success = a->d_ep_success;
+        e.T = a->T; e.ldm = ldm; e.ldo = ldo; e.rc = rc; e.ca = ca; e.okbits = okbits; e.ep_return = a->d_episode_return;
+        rcode = launch_episode(b, e, st);
+    }
+    if (rcode == BPG_OK && gmode == G_OKBITS) rcode = launch_returns_from_okbits(b->d_okbits, a->d_G, b->n, a->T, a->gamma, st);
+    if (rcode == BPG_OK && gmode == G_FROM_REWARD)
+        rcode = bpg_discounted_return_ld(a->d_reward_tb, b->n, ldo, a->T, a->gamma, a->d_G, b->device, stream);
+    if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey) {
+        rcode = enqueue_bump_counter(b->d_reset_counter, (uint32_t)rollouts, st);
+    }
+    return rcode;
+}
+
+}  // extern "C"

@@ -2,7 +2,8 @@
 """A/B of the output stores of the one-shot kernels: the library as built (nontemporal, BPG_OUT_NT = 1) against the same
 source compiled with -DBPG_OUT_NT=0 (plain stores), same box, same process order, alternating.
 
-    hipcc ... -DBPG_OUT_NT=0 -o tools/libbpgym_plainout.so blockpuzzle-gym_amd/csrc/bpgym.hip     (build container)
+    python -c "import importlib.util as u; s = u.spec_from_file_location('b', 'blockpuzzle-gym_amd/build.py'); b = u.module_from_spec(s); \
+               s.loader.exec_module(b); b.build(force=True, extra_flags=['-DBPG_OUT_NT=0'], out='tools/libbpgym_plainout.so')"     (build container)
     python tools/ab_output_stores.py                      (GPU box; runs itself once per library, twice, alternating)
 
 Per kernel and batch size: HIP events around a train of back-to-back launches on rotating output buffers; us per launch.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel register / scratch / LDS / occupancy table of csrc/bpgym.hip for gfx950, from
-`hipcc -Rpass-analysis=kernel-resource-usage` (device-only compile, no GPU needed).
+"""Per-kernel register / scratch / LDS / occupancy table of every translation unit of csrc/ for gfx950, from
+`hipcc -Rpass-analysis=kernel-resource-usage` (device-only compiles in parallel, no GPU needed).
 
     python tools/kernel_resources.py [--scratch-only] [--filter k_rollout]
 """
@@ -11,7 +11,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'blockpuzzle-gym_amd', 'csrc', 'bpgym.hip')
+CSRC = os.path.join(ROOT, 'blockpuzzle-gym_amd', 'csrc')
+SOURCES = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 FIELDS = (('sgpr', r'SGPRs'), ('vgpr', r'VGPRs'), ('agpr', r'AGPRs'), ('scratch', r'ScratchSize \[bytes/lane\]'),
           ('occupancy', r'Occupancy \[waves/SIMD\]'), ('sgpr_spill', r'SGPRs Spill'), ('vgpr_spill', r'VGPRs Spill'),
           ('lds', r'LDS Size \[bytes/block\]'))
@@ -26,18 +27,28 @@ def demangle(names):
     return out if len(out) == len(names) else names
 
 
-def resources(src=SRC, hipcc='/opt/rocm/bin/hipcc'):
-    """[{name, sgpr, vgpr, agpr, scratch, occupancy, sgpr_spill, vgpr_spill, lds}] for every kernel."""
+def _remarks(src, hipcc, extra_flags=()):
     with tempfile.TemporaryDirectory() as d:
-        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-c', '-fPIC', '-ffp-contract=off',
+        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-c', '-fPIC', '-ffp-contract=off', *extra_flags,
                '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', '-o', os.path.join(d, 'dev.o'), src]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-4000:])
-    blocks = re.split(r'remark: [^\n]*Function Name: ', r.stderr)[1:]
+    return r.stderr
+
+
+def resources(sources=None, hipcc='/opt/rocm/bin/hipcc', extra_flags=()):
+    """[{name, unit, sgpr, vgpr, agpr, scratch, occupancy, sgpr_spill, vgpr_spill, lds}] for every kernel."""
+    from concurrent.futures import ThreadPoolExecutor
+    sources = list(sources or SOURCES)
+    with ThreadPoolExecutor(min(len(sources), os.cpu_count() or 4)) as ex:
+        texts = list(ex.map(lambda s: _remarks(s, hipcc, extra_flags), sources))
+    blocks = []
+    for src, text in zip(sources, texts):
+        blocks += [(os.path.basename(src), b) for b in re.split(r'remark: [^\n]*Function Name: ', text)[1:]]
     rows = []
-    for b in blocks:
-        row = {'mangled': b.split()[0]}
+    for unit, b in blocks:
+        row = {'mangled': b.split()[0], 'unit': unit}
         for key, pat in FIELDS:
             m = re.search(r'remark: [^\n]*?' + pat + r': (\d+)', b)
             row[key] = int(m.group(1)) if m else None
