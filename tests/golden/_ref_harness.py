@@ -118,6 +118,7 @@ class FakeData:
         self.rich = None
         self.sites = {}
         self.robot = (np.zeros(15), np.zeros(15))
+        self.nan_now = False    # scripted fault (FakeSim.fault): this step's gripper site position is NaN
 
     def regenerate(self):
         if self.rich is not None:
@@ -147,6 +148,10 @@ class FakeData:
         if self.rich is not None:
             return self._site(name)['xpos'].copy()
         if name == 'robot0:grip':
+            if self.nan_now:           # what a diverged simulation reports: the reference's np.isnan(o_new).any()
+                bad = self.grip.copy()  # (rollout.py:139) is the only reader that cares
+                bad[0] = np.nan
+                return bad
             return self.grip
         return np.array(self.qpos[name + ':joint'][:3])
 
@@ -170,8 +175,18 @@ class FakeSim:
         self.data = FakeData(self)
         self.script = None      # callable() -> list[(g1, g2)]
         self.n_forward = 0
+        # scripted faults, shared by every sim of one env: {'calls': n, 'raise_at': k, 'nan_at': k} -- the k-th
+        # sim.step() of the env (counted from 1 since the dict was installed) raises MujocoException before anything
+        # is simulated (as mujoco_py does from inside mj_step), or reports a NaN gripper position for that step
+        self.fault = None
 
     def step(self):
+        f = self.fault
+        if f is not None:
+            f['calls'] += 1
+            if f.get('raise_at') == f['calls']:
+                raise sys.modules['mujoco_py'].MujocoException('scripted simulation failure')
+            self.data.nan_now = (f.get('nan_at') == f['calls'])
         self.data.regenerate()
         if self.script is not None:
             pairs = self.script()
@@ -190,6 +205,7 @@ class FakeSim:
     def set_state(self, st):
         self.data.qpos = copy.deepcopy(st[0])
         self.data.grip = st[1].copy()
+        self.data.nan_now = False
         self.data.regenerate()
 
 
@@ -245,6 +261,7 @@ class TimeLimitStandIn:
         self._elapsed_steps = 0
         self.action_space = env.action_space
         self.observation_space = env.observation_space
+        self.reset_log = []     # num_objs after every reset (Variation draws it in _reset_sim, fetch_env.py:647-649)
 
     @property
     def unwrapped(self):
@@ -252,7 +269,9 @@ class TimeLimitStandIn:
 
     def reset(self):
         self._elapsed_steps = 0
-        return self.env.reset()
+        obs = self.env.reset()
+        self.reset_log.append(int(self.env.num_objs))
+        return obs
 
     def step(self, action):
         obs, r, done, info = self.env.step(action)

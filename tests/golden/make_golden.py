@@ -478,6 +478,116 @@ def rollout_trace(env_id, seed, B, modes, pg=False, compute_Q=False):
     return out
 
 
+def restart_trace(env_id, seed, B, faults, pg=False, exploit_first=False):
+    """What the reference's RolloutStudent does when a rollout goes wrong (rollout.py:136-142; policy_gradient/rollout.py
+    :237-246): `faults` is one entry per generate_rollouts call -- None (a normal rollout), ('nan', env j, step k): env
+    j's observation of step k carries a NaN (FakeSim.fault), or ('raise', j, k): env j's sim.step() of step k raises
+    MujocoException.  Recorded per call: the episode the reference finally returns, the contact lists / actions /
+    num_objs of the DISCARDED attempt as well (with quirk Q1 the base variants keep what the discarded steps touched,
+    fetch_env.py:247-255), how many steps every env took in it, the number of resets, and the bookkeeping afterwards."""
+    H.install()
+    if pg:
+        from gym_blocks.policy_gradient.rollout import RolloutStudent
+    else:
+        from gym_blocks.rollout import RolloutStudent
+    logs, envs, fault_dicts = [], [], []
+
+    def make_env():
+        env = H.make(env_id)
+        log = []
+        attach_scripts(env, seed + 1000 * len(logs), log, p_pair=0.05)
+        env.seed(seed + 1000 * len(logs))
+        fd = {'calls': 0}
+        u = env.unwrapped
+        for sim in set((getattr(u, 'sims', None) or []) + [u.sim]):
+            sim.fault = fd
+        logs.append(log)
+        envs.append(env)
+        fault_dicts.append(fd)
+        return env
+
+    np.random.seed(seed)
+    probe = H.make(env_id)
+    probe.seed(seed + 999)
+    o = probe.reset()
+    dims = dict(o=o['observation'].shape[0], u=4, g=o['desired_goal'].shape[0], info_is_success=1)
+    T = probe._max_episode_steps
+    ulog = []
+    policy = RandomPolicy(seed, ulog)
+    policy.kwlog = []
+    inner = policy.get_actions
+
+    def get_actions(o, ag, g, **kw):
+        policy.kwlog.append(dict(kw))
+        return inner(o, ag, g, **kw)
+    policy.get_actions = get_actions
+    kw = dict(make_env=make_env, policy=policy, dims=dims, logger=NullLogger(), T=T, rollout_batch_size=B)
+    if pg:
+        kw.update(expert=None, gamma=1. - 1. / T)
+    worker = RolloutStudent(**kw)
+    worker.seed(seed)
+    out = dict(T=np.int32(T), B=np.int32(B), n_calls=np.int32(len(faults)),
+               faults=np.asarray([[0, -1, -1] if f is None else [1 if f[0] == 'nan' else 2, f[1], f[2]] for f in faults], np.int32))
+    for r, fault in enumerate(faults):
+        for log in logs:
+            del log[:]
+        del ulog[:]
+        del policy.kwlog[:]
+        for e in envs:
+            del e.reset_log[:]
+        for fd in fault_dicts:
+            fd.clear()
+            fd['calls'] = 0
+        if fault is not None:
+            fault_dicts[fault[1]]['nan_at' if fault[0] == 'nan' else 'raise_at'] = fault[2] + 1
+        n_before, hist_before = worker.n_episodes, len(worker.success_history)
+        if pg:
+            ep = worker.generate_rollouts(exploit=bool(exploit_first))
+        else:
+            ep = worker.generate_rollouts()
+        for k, v in ep.items():
+            out['r%d_%s' % (r, k)] = v
+        # steps of the discarded attempt per env = everything the env's script emitted before the last T lists
+        nd = np.asarray([len(log) - T for log in logs], np.int32)
+        assert (nd >= 0).all() and (fault is not None or (nd == 0).all())
+        out['r%d_discard_steps' % r] = nd
+        D = int(nd.max()) if len(nd) else 0
+        con = -np.ones((B, T, MAXCON, 2), np.int16)
+        ncon = np.zeros((B, T), np.int32)
+        dcon = -np.ones((B, D, MAXCON, 2), np.int16)
+        dncon = np.zeros((B, D), np.int32)
+        for b, log in enumerate(logs):
+            for t, pairs in enumerate(log[:nd[b]]):
+                dcon[b, t] = pad_contacts(pairs)
+                dncon[b, t] = len(pairs)
+            for t, pairs in enumerate(log[nd[b]:]):
+                con[b, t] = pad_contacts(pairs)
+                ncon[b, t] = len(pairs)
+        out['r%d_contacts' % r], out['r%d_ncon' % r] = con, ncon
+        out['r%d_discard_contacts' % r], out['r%d_discard_ncon' % r] = dcon, dncon
+        # the policy was asked once per step of either attempt; the last T calls belong to the returned episode
+        nu = len(ulog) - T
+        out['r%d_discard_u' % r] = np.asarray(ulog[:nu], np.float32).reshape((nu, B, 4))
+        out['r%d_policy_calls' % r] = np.int32(len(ulog))
+        if pg:      # the retry is `self.generate_rollouts(render, test)`: `exploit` falls back to its default
+            out['r%d_exploit_seen' % r] = np.asarray([bool(k.get('exploit')) for k in policy.kwlog], np.uint8)
+        # num_objs after every reset of this call, per env: (n_resets, B)
+        nres = {len(e.reset_log) for e in envs}
+        assert len(nres) == 1
+        out['r%d_reset_num_objs' % r] = np.asarray([e.reset_log for e in envs], np.int32).T
+        out['r%d_num_objs' % r] = np.asarray([e.unwrapped.num_objs for e in worker.envs], np.int32)
+        sims = getattr(worker.envs[0].unwrapped, 'sims', None)
+        out['r%d_model_idx' % r] = np.asarray(
+            [e.unwrapped.sims.index(e.unwrapped.sim) if sims else 0 for e in worker.envs], np.int32)
+        out['r%d_success_rate' % r] = np.float64(worker.success_history[-1])
+        out['r%d_n_episodes_added' % r] = np.int32(worker.n_episodes - n_before)
+        out['r%d_history_added' % r] = np.int32(len(worker.success_history) - hist_before)
+        out['r%d_final_ag' % r] = np.asarray([e.unwrapped.achieved_goal.ravel() for e in worker.envs], np.float64)
+        out['r%d_final_has_succeeded' % r] = np.asarray([bool(e.unwrapped.has_succeeded) for e in worker.envs], np.uint8)
+    out['n_episodes'] = np.int32(worker.n_episodes)
+    return out
+
+
 def _worker_inputs(env_id, B, seed, steps_of):
     """(o, g, ag) as the pg worker holds them (policy_gradient/rollout.py:64-66, :188-191: float32 arrays filled
     from the env's float64 observation dicts), env b advanced steps_of(b) scripted steps after its reset."""
@@ -667,6 +777,19 @@ def main(HERE=HERE):
                         **expert_rollout_trace('BlocksTouchChoose-v0', seed=811, B=3, dimo=40, dimg=16))
     np.savez_compressed(os.path.join(HERE, 'rollout_Q_BlocksTouch.npz'),
                         **rollout_trace('BlocksTouch-v0', seed=860, B=5, modes=[0, 0, 0], compute_Q=True))
+    # restarts (rollout.py:136-142, policy_gradient/rollout.py:243-246): a base variant (quirk Q1: the matrix survives
+    # resets, so what the discarded steps touched shows in the retried episode) and Variation (three num_grey draws)
+    nan_raise = [None, ('nan', 2, 7), None, ('raise', 3, 4), ('nan', 0, 0), ('raise', 0, 49), None]
+    np.savez_compressed(os.path.join(HERE, 'restart_BlocksTouch.npz'), **restart_trace('BlocksTouch-v0', 910, 5, nan_raise))
+    np.savez_compressed(os.path.join(HERE, 'restart_BlocksTouchVariation.npz'),
+                        **restart_trace('BlocksTouchVariation-v0', 911, 5, nan_raise))
+    np.savez_compressed(os.path.join(HERE, 'restart_ToppleTower.npz'),
+                        **restart_trace('ToppleTower-v0', 912, 4, [None, ('nan', 3, 49), ('raise', 1, 0), None]))
+    nan_only = [None, ('nan', 1, 12), None, ('nan', 3, 0), None]
+    np.savez_compressed(os.path.join(HERE, 'pg_restart_BlocksTouch.npz'),
+                        **restart_trace('BlocksTouch-v0', 920, 4, nan_only, pg=True, exploit_first=True))
+    np.savez_compressed(os.path.join(HERE, 'pg_restart_BlocksTouchVariation.npz'),
+                        **restart_trace('BlocksTouchVariation-v0', 921, 4, nan_only, pg=True))
     print('golden fixtures written to', HERE)
 
 
