@@ -113,7 +113,19 @@ def _ptr(t):
 class PhysicsError(RuntimeError):
     """What a physics backend raises when its simulation blows up: the stand-in for
     mujoco_py.MujocoException, which the rollout worker answers by starting the rollout over
-    (rollout.py:136-137)."""
+    (rollout.py:136-137).
+
+    The reference steps its envs one after the other (rollout.py:121-137): when env i raises, envs 0 .. i-1 HAVE
+    taken the step and envs i .. B-1 have not -- and with quirk Q1 (the base variants keep the touch matrix across
+    resets, fetch_env.py:247-255) what those envs touched in that step shows in the retried episode.  A backend that
+    knows which env failed says so: failed_env = i and, for the envs before it, the step's contacts (`masks` (B,)
+    packed pair masks, or `contacts` = (pairs, ncon) geom-id lists; entries from i on are ignored); the worker then
+    steps exactly envs 0 .. i-1 before it starts over (BatchedBlocksEnv.step_prefix).  Without failed_env no env takes
+    the step."""
+
+    def __init__(self, *args, failed_env=None, masks=None, contacts=None):
+        super().__init__(*args)
+        self.failed_env, self.masks, self.contacts = failed_env, masks, contacts
 
 
 class SyntheticContacts:
@@ -489,6 +501,10 @@ class BatchedBlocksEnv:
         """The rollout worker's step: `sa` is a bpg_step_args the worker filled with the addresses of the episode's time
         slots (plain integers: no tensor views are made per step); this adds the step's contacts from the contact
         source and the action pointer, and launches.  `action`: (B, 4) float32 contiguous device tensor."""
+        if action.shape != (self.num_envs, self.dimu) or action.dtype != torch.float32 or not action.is_contiguous() \
+                or action.device != self.device:
+            raise ValueError('step: actions must be a contiguous (%d, %d) float32 tensor on %s, got %s %s on %s'
+                             % (self.num_envs, self.dimu, self.device, tuple(action.shape), action.dtype, action.device))
         self.last_action = action
         nxt = self.contact_source.next(self, action)
         st = _stream(self.device)
@@ -498,6 +514,22 @@ class BatchedBlocksEnv:
         sa.d_masks = None if m is None else m.data_ptr()
         sa.d_u_in = action.data_ptr() if sa.d_u_out else None
         _lib.check(self._L.bpg_step_record(self._h, C.byref(sa), st))
+
+    def step_prefix(self, count, action=None, contact_masks=None, contacts=None):
+        """One env step for envs 0 .. count-1 ONLY -- the state the reference's per-env loop (rollout.py:121-137) leaves
+        behind when env `count` raises in the middle of a step.  An error path (PhysicsError.failed_env): the whole
+        batch is stepped by the usual launch and the packed state of envs count .. B-1 is put back; no outputs."""
+        count = int(count)
+        if count <= 0:
+            return
+        if contact_masks is None and contacts is None:
+            raise ValueError('step_prefix needs the contacts of the envs that took the step')
+        keep_now, keep_ever = self.state_now[count:].clone(), self.state_ever[count:].clone()
+        if action is None:
+            action = torch.zeros(self.num_envs, self.dimu, dtype=torch.float32, device=self.device)
+        self._step_core(action, contact_masks, contacts, want_reward=False, want_flags=False)
+        self.state_now[count:].copy_(keep_now)
+        self.state_ever[count:].copy_(keep_ever)
 
     def step(self, action, contact_masks=None, contacts=None, ag_out=None):
         """robot_env.py:57-69 (+ TimeLimit).  Returns (obs, reward, done, info).

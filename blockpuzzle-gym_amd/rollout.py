@@ -22,6 +22,11 @@ from . import _lib
 from .envs import PhysicsError, _ptr, _stream
 
 MAX_ROLLOUT_RESTARTS = 10      # the reference retries without bound (rollout.py:136-142)
+NAN_CHECKS = ('per_step', 'per_rollout')
+
+
+class _NaNCaught(Exception):
+    """np.isnan(o_new).any() held after step t (rollout.py:139-142): raised inside a rollout body in per_step mode."""
 
 
 def configure_dims(env):
@@ -151,7 +156,8 @@ class RolloutStudent:
 
     def __init__(self, make_env, policy, dims, logger, T, rollout_batch_size=1,
                  exploit=False, use_target_net=False, compute_Q=False, noise_eps=0,
-                 random_eps=0, history_len=100, render=False, output=None, async_stats=False, **kwargs):
+                 random_eps=0, history_len=100, render=False, output=None, async_stats=False, nan_check='per_step',
+                 **kwargs):
         """Same arguments as the reference (rollout.py:11-14).  `make_env` may
         return a batched env directly (called as make_env(num_envs=B) when it
         accepts that) or a single env, which is re-created with B envs.
@@ -162,7 +168,16 @@ class RolloutStudent:
         the success count of a rollout (rollout.py:163-167) is copied to pinned host memory behind the rollout's
         launches and `success_history` resolves the entry the first time it is read (np.mean, logs, indexing), as the
         reference's callers do once per epoch (train.py:67-76).  Default False: a float is appended before
-        generate_rollouts returns, as in the reference."""
+        generate_rollouts returns, as in the reference.
+        nan_check (only matters with a backend that writes observations, `writes_observation`; without one nothing can
+        put a NaN there and nothing is checked): 'per_step' (default) = the reference's timing -- the device-side NaN
+        flag is read after EVERY step (one host sync per step) and the rollout starts over at the first step whose
+        observations hold a NaN (rollout.py:139-142); 'per_rollout' = build-defined fast mode -- the flag is read once,
+        after all T steps (see generate_rollouts for what that changes).  generate_rollouts_graphed is always
+        per_rollout: a replay cannot stop in the middle."""
+        if nan_check not in NAN_CHECKS:
+            raise ValueError('nan_check must be one of %s' % (NAN_CHECKS,))
+        self.nan_check = nan_check
         self.make_env, self.policy, self.dims, self.logger, self.T = make_env, policy, dims, logger, T
         self.rollout_batch_size = rollout_batch_size
         self.exploit, self.use_target_net, self.compute_Q = exploit, use_target_net, compute_Q
@@ -203,6 +218,8 @@ class RolloutStudent:
 
     # -- rollout.py:47-64 -------------------------------------------------
     def reset_all_rollouts(self, test=False, num_grey=None, observation_out=None, achieved_goal_out=None):
+        if callable(num_grey):       # explicit draws that differ from reset to reset (a restarted rollout resets up to
+            num_grey = num_grey()    # three times, fetch_env.py:647 draws each time): asked once per reset
         obs = self.env.reset(num_grey=num_grey, observation_out=observation_out, achieved_goal_out=achieved_goal_out)
         if test:                                     # maximum difficulty (rollout.py:53-55)
             obs = self.env.unwrapped.set_test(achieved_goal_out=achieved_goal_out)
@@ -298,23 +315,53 @@ class RolloutStudent:
         episode_return=True: also `episode_return` (B,) float32, every env's undiscounted return r[0] + ... + r[T-1],
         accumulated by the step launches themselves (bpg_step_args.d_return_acc) -- the per-step counterpart of
         generate_rollouts_fused(episode_return=True), same bits.
-        A backend failure (PhysicsError, the stand-in for MujocoException) restarts the rollout
-        (rollout.py:136-137); a NaN in the observations a backend wrote is detected on the device,
-        and the rollout is thrown away, everything reset and generated again (rollout.py:139-142)."""
+        num_grey: explicit (B,) draws for Variation's resets, or a callable returning them (asked once per reset).
+
+        Restarts (rollout.py:136-142), pinned by tests/golden/restart_*.npz recorded from the reference:
+          * a backend failure (PhysicsError, the stand-in for MujocoException, :136-137) starts the rollout over -- one
+            reset, by the retry itself.  The reference has stepped envs 0 .. i-1 when env i raises; a backend that says
+            which env failed (PhysicsError.failed_env + the step's contacts) gets exactly that, otherwise no env takes
+            the failed step;
+          * a NaN in the observations a backend wrote (:139-142) is detected on the device; the attempt is thrown
+            away, everything is reset (:141) and generated again (:142, which resets once more: Variation draws
+            num_grey three times in all).
+        nan_check='per_step' (default) reads the flag after every step, so the discarded attempt ends with the NaN
+        step, as in the reference -- with quirk Q1 the base variants keep what the discarded steps touched
+        (fetch_env.py:247-255), so WHERE the attempt ends shows in the retried episode's achieved_goal.
+        nan_check='per_rollout' is NOT the reference's timing: the flag is read once after all T steps, i.e. the
+        discarded attempt runs to the end (the backend is called T instead of t+1 times and, for the base variants,
+        steps t+1 .. T-1 leave their touches in the state the retry starts from).  It saves T-1 host syncs per rollout
+        with such a backend and is the only mode a graph replay can offer (generate_rollouts_graphed)."""
         for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
             try:
                 ep, Qs = self._rollout_body(test, num_grey, compute_Attention, episode_return)
             except PhysicsError as e:
                 self._log('warning', 'physics backend failed during rollout generation (%s). Trying again...' % e)
+                self._step_envs_before_failure(e)
                 self._resync_success_total()
+                compute_Attention = False        # `return self.generate_rollouts(render, test)`, rollout.py:137
                 continue
-            if self._nan_caught():
+            except _NaNCaught:
+                caught = True
+            else:
+                caught = self._nan_caught()
+            if caught:
                 self._log('warning', 'NaN caught during rollout generation. Trying again...')
                 self._resync_success_total()
                 self.reset_all_rollouts(test, num_grey=num_grey)
+                compute_Attention = False        # rollout.py:142
                 continue
             return self._finish(ep, Qs, counted=True)
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
+
+    def _step_envs_before_failure(self, e):
+        """The reference's per-env loop has stepped envs 0 .. i-1 when env i raises (rollout.py:121-137)."""
+        i = getattr(e, 'failed_env', None)
+        if i is None or int(i) <= 0:
+            return
+        if e.masks is None and e.contacts is None:
+            return
+        self.env.step_prefix(int(i), getattr(self.env, 'last_action', None), contact_masks=e.masks, contacts=e.contacts)
 
     def _log(self, level, msg):
         fn = getattr(self.logger, level, None) or getattr(self.logger, 'info', None)
@@ -324,9 +371,14 @@ class RolloutStudent:
             warnings.warn(msg)
 
     def _nan_caught(self):
-        """One read of the device-side flag per rollout (the step loop never synchronises)."""
+        """One read of the device-side flag (per rollout in per_rollout mode: the step loop never synchronises)."""
         flag = getattr(self, '_nan_flag', None)
         return flag is not None and self._watch_o and bool(flag.item())
+
+    def _check_step_nan(self, t):
+        """per_step mode: np.isnan(o_new).any() right after step t, as the reference checks it (rollout.py:139)."""
+        if self._watch_o and self.nan_check == 'per_step' and bool(self._nan_flag.item()):
+            raise _NaNCaught(t)
 
     def _reset_into_episode(self, test, num_grey, ag_out=None):
         """reset_all_rollouts with the episode's first observation as the reset's target, and where
@@ -410,6 +462,8 @@ class RolloutStudent:
             if not (torch.is_tensor(u) and u.dtype == torch.float32 and u.device == self.device and u.dim() == 2
                     and u.shape[0] == B and u.is_contiguous()):
                 u = torch.as_tensor(u, dtype=torch.float32).to(self.device).reshape(B, -1).contiguous()
+            if u.shape[1] != self.dims['u']:
+                raise ValueError('the policy returned actions of width %d, dims[\'u\'] = %d' % (u.shape[1], self.dims['u']))
             # reward ignored: recomputed for HER (rollout.py:123-125); the step launch also stores the
             # actions into the episode's slot (acts.append(u.copy()), rollout.py:147)
             if fast:
@@ -418,6 +472,7 @@ class RolloutStudent:
                 env._step_with_args(u, sa)
             else:
                 self._step_into(u, ep, t, u_store=ep['u'][t], return_acc=acc)
+                self._check_step_nan(t)
         if self._watch_o:
             self.initial_o = ep['o'][T]                            # rollout.py:153 `self.initial_o[:] = o`
         ep = {k: v.transpose(0, 1) for k, v in ep.items()}         # batch-major views
@@ -456,15 +511,19 @@ class RolloutStudent:
             side = torch.cuda.Stream(self.device)            # device-side stream index advances per replay
             side.wait_stream(torch.cuda.current_stream(self.device))
             snapshot = self.env.state_dict()                   # the warm-up pass must not count
-            with torch.cuda.stream(side):                      # warm-up outside the capture
-                self._graph_body(test, ng)
-                self.env.load_state_dict(snapshot)
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self._resync_success_total()                       # the warm-up pass counted: not a rollout
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._graph_ep, self._graph_Qs = self._graph_body(test, ng)
+            mode, self.nan_check = self.nan_check, 'per_rollout'   # a replay cannot stop in the middle: one read after it
+            try:
+                with torch.cuda.stream(side):                      # warm-up outside the capture
+                    self._graph_body(test, ng)
+                    self.env.load_state_dict(snapshot)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self._resync_success_total()                       # the warm-up pass counted: not a rollout
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._graph_ep, self._graph_Qs = self._graph_body(test, ng)
+            finally:
+                self.nan_check = mode
             self._graph, self._graph_test, self._graph_explicit, self._graph_key = graph, bool(test), explicit, _key
         if explicit:
             self._static_ng.copy_(torch.as_tensor(num_grey).to(self.device, torch.int32))
@@ -685,15 +744,22 @@ class PGRolloutStudent(RolloutStudent):
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None, episode_return=False):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference
-        (`assert(False)`, :237-241); NaN observations restart the rollout (:243-246).
+        (`assert(False)`, :237-241); NaN observations restart the rollout (:243-246) -- reset_all_rollouts, then
+        `self.generate_rollouts(render, test)`: the retry runs with exploit at its default (False), whatever the
+        caller passed, and so does this one.  nan_check: see RolloutStudent.generate_rollouts.
         episode_return=True: also `episode_return` (B,) float32 = r[0] + ... + r[T-1] (the reference's returns[0] at
         gamma = 1), accumulated by the step launches."""
         for attempt in range(MAX_ROLLOUT_RESTARTS + 1):
-            ep = self._pg_body(test, exploit, num_grey, episode_return)
-            if self._nan_caught():
+            try:
+                ep = self._pg_body(test, exploit, num_grey, episode_return)
+                caught = self._nan_caught()
+            except _NaNCaught:
+                caught = True
+            if caught:
                 self._log('info', 'NaN caught during rollout generation. Trying again...')
                 self._resync_success_total()
                 self.reset_all_rollouts(test, num_grey=num_grey)
+                exploit = False                  # policy_gradient/rollout.py:246
                 continue
             return self._finish(ep, counted=True)
         raise RuntimeError('rollout generation failed %d times in a row' % (MAX_ROLLOUT_RESTARTS + 1))
@@ -761,6 +827,7 @@ class PGRolloutStudent(RolloutStudent):
                 env._step_with_args(u.contiguous(), sa)
             else:
                 self._step_into(u, ep, t, reward_out=reward[t], return_acc=acc)
+                self._check_step_nan(t)
         if defer and int(self._trim_bad.item()):
             raise ValueError('trim: an observation row did not hold exactly 2 GREEN / BLUE blocks at some step of the '
                              'rollout (policy_gradient/rollout.py:166)')

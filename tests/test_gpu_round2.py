@@ -244,14 +244,16 @@ def _flaky_worker(env_id, B, T, fail_at, mode, cls=bpg.RolloutStudent, **kw):
     return w, state, log, exp_obs
 
 
+@pytest.mark.parametrize('nan_check', ['per_step', 'per_rollout'])
 @pytest.mark.parametrize('mode', ['raise', 'nan', 'nan_direct'])
-def test_rollout_restarts_after_a_backend_failure(mode):
+def test_rollout_restarts_after_a_backend_failure(mode, nan_check):
     env_id, B, T = 'BlocksTouchChoose-v0', 64, 6
-    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=4, mode=mode)
+    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=4, mode=mode, nan_check=nan_check)
     resets0 = state['resets']
     ep = w.generate_rollouts()
-    # the failed attempt consumed 4 (raise) or all 6 (NaN found at the end) backend calls, then a clean rollout
-    assert state['calls'] == (4 if mode == 'raise' else T) + T
+    # the failed attempt consumed 4 backend calls -- the exception, or (per_step, the reference's timing, rollout.py:139-142)
+    # the step whose observation held the NaN -- or all 6 (per_rollout: NaN found at the end); then a clean rollout
+    assert state['calls'] == (T if (mode != 'raise' and nan_check == 'per_rollout') else 4) + T
     assert len(log.lines) == 1 and ('NaN caught' in log.lines[0]) == (mode != 'raise')
     assert state['resets'] - resets0 == (2 if mode == 'raise' else 3)   # NaN: reset_all_rollouts + the restart's own reset
     assert not torch.isnan(ep['o']).any()
@@ -259,11 +261,12 @@ def test_rollout_restarts_after_a_backend_failure(mode):
     assert w.n_episodes == B and len(w.success_history) == 1            # the failed attempt is not counted
 
 
-def test_pg_rollout_restarts_on_nan_and_keeps_backend_errors_fatal():
+@pytest.mark.parametrize('nan_check', ['per_step', 'per_rollout'])
+def test_pg_rollout_restarts_on_nan_and_keeps_backend_errors_fatal(nan_check):
     env_id, B, T = 'BlocksTouch-v0', 32, 5
-    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=2, mode='nan', cls=bpg.PGRolloutStudent)
+    w, state, log, exp_obs = _flaky_worker(env_id, B, T, fail_at=2, mode='nan', cls=bpg.PGRolloutStudent, nan_check=nan_check)
     ep = w.generate_rollouts()
-    assert state['calls'] == 2 * T and len(log.lines) == 1 and not torch.isnan(ep['o']).any()
+    assert state['calls'] == (2 if nan_check == 'per_step' else T) + T and len(log.lines) == 1 and not torch.isnan(ep['o']).any()
     assert ep['G'].shape == (B, T)
     w, state, log, _ = _flaky_worker(env_id, B, T, fail_at=2, mode='raise', cls=bpg.PGRolloutStudent)
     with pytest.raises(bpg.PhysicsError):                               # policy_gradient/rollout.py:237-241 asserts
