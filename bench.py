@@ -158,7 +158,7 @@ def box_state_under_load(cx, h, seconds=0.6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(n):
-            _lib.check(L.bpg_rollout(env._h, C.byref(args[i % NBUF]), cx.stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i % NBUF]), cx.stream))
         e1.record()
         t0 = time.perf_counter()
         smi = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showmemorypartition', '--showcomputepartition', '--showvbios',
@@ -399,7 +399,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
                 w.wait()                            # stream-level wait, no host block
         if k == 0:
             ev0.record()
-        _lib.check(L.bpg_rollout(env._h, C.byref(args[i]), stream))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i]), stream))
         if k == steps - 1:
             ev1.record()
         if coll_after[i]:
@@ -455,11 +455,11 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
                 for pad in pads:                     # the first repetition is a warm-up
                     pa = probes[pad][4]
                     for i in range(40):
-                        _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                        _lib.check(L.bpg_rollout_v2(env._h, C.byref(pa[i % NBUF]), stream))
                     p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     p0.record()
                     for i in range(60):
-                        _lib.check(L.bpg_rollout(env._h, C.byref(pa[i % NBUF]), stream))
+                        _lib.check(L.bpg_rollout_v2(env._h, C.byref(pa[i % NBUF]), stream))
                     p1.record()
                     torch.cuda.synchronize(dev)
                     if rep:
@@ -482,7 +482,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
                             d_success_count=scratch.data_ptr()) for k in range(NBUF)]
     if prewarm > 0:                        # set-up, not measurement: same launch, scratch statistics row
         for i in range(prewarm):
-            _lib.check(L.bpg_rollout(env._h, C.byref(pre[i % NBUF]), stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(pre[i % NBUF]), stream))
         torch.cuda.synchronize(dev)
     for i in range(warmup):
         one_rollout(i)
@@ -508,7 +508,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
         for i in range(steps):
-            _lib.check(L.bpg_rollout(env._h, C.byref(pre[(g * steps + i) % NBUF]), stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(pre[(g * steps + i) % NBUF]), stream))
         g1.record()
         torch.cuda.synchronize(dev)
         groups.append(g0.elapsed_time(g1) / steps)
@@ -821,7 +821,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         sr_it[0] += 1
         sa = _lib.StepArgs(d_masks=masks[t].data_ptr(), d_reward=reward[t].data_ptr(), d_flags=flags[t].data_ptr(),
                            d_success_f32=succ_f[t].data_ptr(), d_ag=agrec[t + 1].data_ptr(), ld_ag=env.dimg)
-        _lib.check(L.bpg_step_record(env._h, C.byref(sa), stream))
+        _lib.check(L.bpg_step_record_v2(env._h, C.byref(sa), stream))
     res['step_record_single_launch'] = line(timed(step_record, 2 * T), (29 + 4 * env.dimg) * B, B)
     res['step_record_single_launch']['note'] = 'rows into rotating time slots of a (T+1, B, dimg) slab, as the worker writes them'
     del agrec, succ_f
@@ -895,14 +895,14 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
                           d_flags_tb=flags.data_ptr(), ld_out=LD)
 
     def synth():
-        _lib.check(L.bpg_rollout(env._h, C.byref(a2), stream))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a2), stream))
     res['rollout_synth_in_kernel'] = line(timed(synth, 20), B * (T * 5 + 8), B * T)
 
     # (3b) compact outputs: flags alone (bit2 encodes the reward) -> mask 4 in + flags 1 out per env-step
     a2c = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_flags_tb=flags.data_ptr(), ld_masks=LD, ld_out=LD)
 
     def compact():
-        _lib.check(L.bpg_rollout(env._h, C.byref(a2c), stream))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a2c), stream))
     res['rollout_masks_flags_only'] = line(timed(compact, 20), B * (T * 5 + 8), B * T)
 
     # (3c) float view of the packed state: obs['achieved_goal'] (B, 36) f32
@@ -1012,14 +1012,14 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
         def pg_old():
             k = pg_it[0] % NDR
             pg_it[0] += 1
-            _lib.check(L.bpg_rollout(env._h, C.byref(a_old[k]), stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(a_old[k]), stream))
             _lib.check(L.bpg_discounted_return_ld(C.c_void_p(dr_in[k].data_ptr()), B, LD, T, 1.0 - 1.0 / T,
                                                   C.c_void_p(dr_out[k].data_ptr()), dev.index, stream))
 
         def pg_new():
             k = pg_it[0] % NDR
             pg_it[0] += 1
-            _lib.check(L.bpg_rollout(env._h, C.byref(a_new[k]), stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(a_new[k]), stream))
         res['pg_rollout_plus_return_via_reward_stream'] = line(timed(pg_old, 4 * NDR), B * (T * 21 + 12), B * T)
         res['pg_rollout_with_return_from_step_ok_words'] = line(timed(pg_new, 4 * NDR), B * (T * 13 + 12 + 16), B * T)
         del m_sets, a_old, a_new
@@ -1037,7 +1037,7 @@ def extras(torch, bpg, _lib, env, masks, reward, flags, B, T, dev, stream):
                               d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(), d_ep_success=sc.data_ptr())
 
         def episode():
-            _lib.check(L.bpg_rollout(env._h, C.byref(a3), stream))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(a3), stream))
         nbytes = B * (16 + T * 4 + 4 * ((T + 1) * dimg + T * dimg + T))
         res['episode_writer_f32'] = line(timed(episode, 5), nbytes, B * T)
         del ag, gg, sc
@@ -1091,7 +1091,7 @@ def shards_on_streams(torch, _lib, D, total, S, T, dev, line, reps=120):
     def run(n):
         for i in range(n):
             for env, cs, args, _ in per:
-                _lib.check(L.bpg_rollout(env._h, C.byref(args[i % nset]), cs))
+                _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i % nset]), cs))
     run(40)
     torch.cuda.synchronize(dev)
     best = []
@@ -1133,7 +1133,7 @@ def rollout_at(torch, bpg, _lib, Bx, T, dev, stream, timed, line, rollouts=1, ep
     it = [0]
 
     def go():
-        _lib.check(L.bpg_rollout(e._h, C.byref(args[it[0] % nset]), stream))
+        _lib.check(L.bpg_rollout_v2(e._h, C.byref(args[it[0] % nset]), stream))
         it[0] += 1
     out = line(timed(go, max(40, 2 * nset)) / K, Bx * (T * 9 + 12 + (4 if episode_return else 0)), Bx * T)
     out['buffer_sets'] = nset

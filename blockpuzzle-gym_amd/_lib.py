@@ -13,6 +13,13 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libbpgym.so')
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ATTRIBUTE = 0, -1, -2, -3, -4
 MAX_OBJS, NUM_PAIRS, MAX_GEOMS, MAX_MODELS = 6, 21, 64, 3
 FLAG_SUCCESS, FLAG_DONE, FLAG_STEP_OK = 1, 2, 4
+ARGS_MAGIC = 0xB5A90000          # BPG_ARGS_MAGIC
+COMM_ID_BYTES = 128              # BPG_COMM_ID_BYTES
+
+
+def args_tag(size):
+    """BPG_ARGS_TAG(size): the first word of a versioned argument struct."""
+    return (int(size) & 0xFFFF) | ARGS_MAGIC
 
 
 class VariantInfo(C.Structure):
@@ -37,13 +44,13 @@ class RolloutArgs(C.Structure):
         ('d_ep_ag', C.c_void_p), ('d_ep_g', C.c_void_p), ('d_ep_success', C.c_void_p),
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
         ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
-        ('d_G', C.c_void_p), ('gamma', C.c_double), ('d_episode_return', C.c_void_p),
+        ('d_G', C.c_void_p), ('gamma', C.c_double), ('d_episode_return', C.c_void_p), ('d_episode_fail_count', C.c_void_p),
     ]
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
         if not args and 'struct_size' not in kw:
-            self.struct_size = C.sizeof(RolloutArgs)
+            self.struct_size = args_tag(C.sizeof(RolloutArgs))
 
 
 ROLLOUT_ARGS_MIN_SIZE = 120
@@ -60,7 +67,7 @@ class StepArgs(C.Structure):
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
         if not args and 'struct_size' not in kw:
-            self.struct_size = C.sizeof(StepArgs)
+            self.struct_size = args_tag(C.sizeof(StepArgs))
 
 
 STEP_ARGS_MIN_SIZE = 88
@@ -78,6 +85,13 @@ class PlacementArgs(C.Structure):
                 ('test', C.c_int32), ('challenge', C.c_int32),
                 ('d_eu', C.c_void_p), ('n_eu', C.c_int32), ('d_gz', C.c_void_p), ('n_gz', C.c_int32),
                 ('d_gu', C.c_void_p), ('n_gu', C.c_int32), ('d_env_mask', C.c_void_p)]
+
+
+class Curriculum(C.Structure):
+    """bpg_curriculum"""
+    _fields_ = [('difficulty', C.c_int32), ('challenge', C.c_int32), ('obj_range', C.c_double), ('obj_range_step', C.c_double),
+                ('max_obj_range', C.c_double), ('wrong_obj_range', C.c_double), ('wrong_obj_range_step', C.c_double),
+                ('has_step', C.c_int32), ('reserved_', C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/bpgym.h declares
@@ -104,7 +118,8 @@ SIGNATURES = {
     'bpg_contacts_to_masks_tb': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p]),
     'bpg_contacts_csr_to_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    'bpg_step_record': (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
+    'bpg_step_record_v2': (C.c_int, [C.c_void_p, C.POINTER(StepArgs), C.c_void_p]),
+    'bpg_step_record': (C.c_int, []),
     'bpg_step_synth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'bpg_synth_masks_ld': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -126,7 +141,10 @@ SIGNATURES = {
     'bpg_compute_reward_f64_goal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_compute_reward_packed': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
-    'bpg_rollout': (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.c_void_p]),
+    'bpg_rollout_v2': (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.c_void_p]),
+    'bpg_rollout': (C.c_int, []),
+    'bpg_reserve_return_scratch': (C.c_int, [C.c_void_p]),
+    'bpg_episode_return_from_fail_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'bpg_success_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'bpg_discounted_return': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                         C.c_int, C.c_void_p]),
@@ -135,6 +153,20 @@ SIGNATURES = {
     'bpg_discounted_return_scan': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p,
                                              C.c_int, C.c_void_p]),
     'bpg_nan_flag_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    'bpg_get_curriculum': (C.c_int, [C.c_void_p, C.POINTER(Curriculum)]),
+    'bpg_set_curriculum': (C.c_int, [C.c_void_p, C.POINTER(Curriculum)]),
+    'bpg_get_difficulty': (C.c_int, [C.c_void_p]),
+    'bpg_increase_difficulty': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    'bpg_placement_from_curriculum': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(PlacementArgs)]),
+    'bpg_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'bpg_comm_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    'bpg_comm_adopt': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    'bpg_comm_destroy': (C.c_int, [C.c_void_p]),
+    'bpg_comm_rank': (C.c_int, [C.c_void_p]),
+    'bpg_comm_world_size': (C.c_int, [C.c_void_p]),
+    'bpg_allgather_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_allgather_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'bpg_allreduce_sum_u64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'bpg_trim_expert_inputs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }

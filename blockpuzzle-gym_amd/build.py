@@ -8,9 +8,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-UNITS = ('abi', 'step', 'rollout', 'episode', 'returns', 'reward', 'obs_reset_place')
+# the long compiles first (8 units run at once on the build container's 8 cores)
+UNITS = ('returns_stream', 'returns_stream_rt', 'rollout', 'returns', 'episode', 'step', 'reward', 'obs_reset_place', 'abi', 'comm')
 SOURCES = [os.path.join(CSRC, u + '.hip') for u in UNITS]
-HEADERS = [os.path.join(CSRC, 'state.hip.h'), os.path.join(CSRC, 'hooks.hip.h'),
+HEADERS = [os.path.join(CSRC, 'state.hip.h'), os.path.join(CSRC, 'hooks.hip.h'), os.path.join(CSRC, 'returns.hip.h'), os.path.join(CSRC, 'returns_lane.hip.h'),
            os.path.join(os.path.dirname(_HERE), 'include', 'bpgym.h')]
 OBJ_DIR = os.path.join(_HERE, 'lib', 'obj')
 OUT = os.path.join(_HERE, 'lib', 'libbpgym.so')

@@ -30,6 +30,34 @@ struct VariantDef {
     int incr_status;         // quirk Q6
 };
 
+// the curriculum attributes each constructor sets (tasks.py passes obj_range = 0.15 to every preset; the curriculum
+// presets then overwrite it)
+bpg_curriculum initial_curriculum(int v)
+{
+    bpg_curriculum c;
+    std::memset(&c, 0, sizeof(c));
+    c.obj_range = 0.15;
+    switch (v) {
+    case BPG_BLOCKS_TOUCH:                       // fetch_env.py:346-348 (curriculum = False)
+        c.max_obj_range = c.obj_range; c.obj_range_step = 0; c.has_step = 1;
+        break;
+    case BPG_BLOCKS_TOUCH_CURRICULUM:            // :342-345
+    case BPG_BLOCKS_TOUCH_VARIATION:             // :561-563
+        c.obj_range = 0.08; c.obj_range_step = 0.025; c.max_obj_range = 0.2; c.has_step = 1;
+        break;
+    case BPG_BLOCKS_TOUCH_CHOOSE:                // :413-415: no *_step attributes (quirk Q6)
+        c.wrong_obj_range = 0; c.max_obj_range = 0.2;
+        break;
+    case BPG_BLOCKS_TOUCH_CHOOSE_CURRICULUM:     // :407-412
+        c.obj_range = 0.08; c.obj_range_step = 0.025; c.wrong_obj_range = 0.2; c.wrong_obj_range_step = 0.02;
+        c.max_obj_range = 0.3; c.has_step = 1;
+        break;
+    default:                                     // GripperTouch, ToppleTower: obj_range only
+        break;
+    }
+    return c;
+}
+
 const VariantDef kVariants[BPG_NUM_VARIANTS] = {
     // fetch_env.py:323-326, tasks.py:4-20
     {"GripperTouch-v0", 3, {BLUE, GREY, GREEN, 0, 0, 0}, 0, 0, BPG_ERR_UNSUPPORTED},
@@ -114,7 +142,7 @@ int enqueue_bump_counter(uint32_t *d_counter, uint32_t by, hipStream_t st)
 extern "C" {
 
 const char *bpg_last_error(void) { return g_err.c_str(); }
-int bpg_version(void) { return 104; }    // 100 + round
+int bpg_version(void) { return BPG_LIBRARY_VERSION; }
 
 int bpg_variant_from_id(const char *env_id)
 {
@@ -177,6 +205,7 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     b->d_id2obj = nullptr;
     b->d_count_shards = nullptr;
     b->d_okbits = nullptr;
+    b->cur = initial_curriculum(variant);
     std::memset(b->ngeom, 0, sizeof(b->ngeom));
     const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
     hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
@@ -280,6 +309,98 @@ int bpg_counter_ptr(bpg_batch *b, uint32_t **d_counters)
 {
     if (!b || !d_counters) return fail(BPG_ERR_ARG, "NULL argument");
     *d_counters = b->d_reset_counter;
+    return BPG_OK;
+}
+
+int bpg_reserve_return_scratch(bpg_batch *b)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (b->d_okbits) return BPG_OK;
+    DeviceGuard guard(b->device);
+    if (hipMalloc(&b->d_okbits, (size_t)((b->n + 1) & ~(int64_t)1) * sizeof(uint64_t)) != hipSuccess) {
+        b->d_okbits = nullptr;
+        return fail(BPG_ERR_HIP, "hipMalloc failed for the step-ok words");
+    }
+    return BPG_OK;
+}
+
+// the entry points of these names up to round 3 had other argument lists (include/bpgym.h): a stale caller gets an error
+int bpg_step_record(void)
+{
+    return fail(BPG_ERR_UNSUPPORTED, "bpg_step_record(handle, ten arguments) is the round-3 entry point: use bpg_step_record_v2(handle, "
+                                     "const bpg_step_args *, stream) of include/bpgym.h");
+}
+
+int bpg_rollout(void)
+{
+    return fail(BPG_ERR_UNSUPPORTED, "bpg_rollout is the round-3 entry point (a struct without BPG_ARGS_TAG): use bpg_rollout_v2 of "
+                                     "include/bpgym.h");
+}
+
+// ---- curriculum ---------------------------------------------------------------------------------------------------
+int bpg_get_curriculum(const bpg_batch *b, bpg_curriculum *out)
+{
+    if (!b || !out) return fail(BPG_ERR_ARG, "NULL argument");
+    *out = b->cur;
+    return BPG_OK;
+}
+
+int bpg_set_curriculum(bpg_batch *b, const bpg_curriculum *in)
+{
+    if (!b || !in) return fail(BPG_ERR_ARG, "NULL argument");
+    b->cur = *in;
+    return BPG_OK;
+}
+
+int bpg_get_difficulty(const bpg_batch *b) { return b ? b->cur.difficulty : 0; }   // fetch_env.py:96-97
+
+int bpg_increase_difficulty(bpg_batch *b, int *at_max)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (at_max) *at_max = 0;
+    const int v = b->info.variant;
+    if (b->info.increase_difficulty_status == BPG_ERR_UNSUPPORTED)
+        return fail(BPG_ERR_UNSUPPORTED, "increase_difficulty: NotImplementedError (fetch_env.py:93-94)");
+    bpg_curriculum &c = b->cur;
+    if (!c.has_step)                                   // `self.obj_range += self.obj_range_step` raises before anything changes
+        return fail(BPG_ERR_ATTRIBUTE, "increase_difficulty: the preset has no obj_range_step (AttributeError, fetch_env.py:413-420)");
+    bool top = false;
+    if (v == BPG_BLOCKS_TOUCH_CHOOSE || v == BPG_BLOCKS_TOUCH_CHOOSE_CURRICULUM) {     // fetch_env.py:419-432
+        c.obj_range += c.obj_range_step;
+        c.wrong_obj_range -= c.wrong_obj_range_step;
+        if (c.obj_range > c.max_obj_range) {
+            c.obj_range = c.max_obj_range;
+            if (c.wrong_obj_range < 0) {
+                c.wrong_obj_range = 0;
+                top = true;
+            }
+        } else if (c.wrong_obj_range < 0) {
+            c.wrong_obj_range = 0;
+        }
+        if (!top) c.difficulty += 1;
+    } else {                                           // fetch_env.py:351-358 (BlocksTouch*), :623-630 (Variation)
+        c.obj_range += c.obj_range_step;
+        if (c.obj_range > c.max_obj_range) {
+            c.obj_range = c.max_obj_range;
+            top = true;
+        } else {
+            c.difficulty += 1;
+        }
+    }
+    if (at_max) *at_max = top ? 1 : 0;
+    return BPG_OK;
+}
+
+int bpg_placement_from_curriculum(const bpg_batch *b, int test, bpg_placement_args *out)
+{
+    if (!b || !out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (test && !b->info.set_test_supported)
+        return fail(BPG_ERR_UNSUPPORTED, "set_test: NotImplementedError (fetch_env.py:100-101)");
+    out->obj_range = b->cur.obj_range;
+    out->max_obj_range = b->cur.max_obj_range;
+    out->wrong_obj_range = b->cur.wrong_obj_range;
+    out->test = test ? 1 : 0;
+    out->challenge = b->cur.challenge;
     return BPG_OK;
 }
 

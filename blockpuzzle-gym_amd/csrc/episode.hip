@@ -16,7 +16,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
           uint32_t *__restrict__ reward_tb, uint8_t *__restrict__ flags_tb,
           float *__restrict__ ep_ag, float *__restrict__ ep_g, float *__restrict__ ep_succ,
           int64_t n, int T, int64_t ldm, int64_t ldo, int RC, int R, StepConst c, SynthConst s, PairTable tabv,
-          ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits_out, float *__restrict__ ep_return)
+          ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits_out, float *__restrict__ ep_return, uint8_t *__restrict__ ep_fail)
 {
     // The T+1 matrices of an episode are produced in chunks of RC rows (one chunk = the whole
     // episode for T <= 63): a short step phase (lane = env, state in registers, packed rows of
@@ -99,6 +99,7 @@ k_episode(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         // G row (policy_gradient/rollout.py:255-258)
         if (okbits_out) okbits_out[i] = okb;
         if (ep_return) ep_return[i] = -(float)nfail;              // bpg_rollout_args.d_episode_return
+        if (ep_fail) ep_fail[i] = (uint8_t)nfail;                 // ... d_episode_fail_count (the host guarantees T <= 255)
     }
     if (ca.count && lane < 64) {
         const unsigned long long nb = (unsigned long long)__popcll(__ballot(active && (e >> 31) != 0));
@@ -147,11 +148,11 @@ int launch_episode(bpg_batch *b, const EpisodeLaunch &e, hipStream_t st)
         if (synth)
             hipLaunchKernelGGL((k_episode<S, SRC_SYNTH, false>), grid, block, lds, st, b->now, b->ever, e.d_masks, e.reward_tb,
                                e.flags_tb, e.ep_ag, e.ep_g, e.ep_success, b->n, e.T, e.ldm, e.ldo, RC, R, c, s, tab, e.rc, e.ca,
-                               e.okbits, e.ep_return);
+                               e.okbits, e.ep_return, e.ep_fail);
         else
             hipLaunchKernelGGL((k_episode<S, SRC_MASKS, false>), grid, block, lds, st, b->now, b->ever, e.d_masks, e.reward_tb,
                                e.flags_tb, e.ep_ag, e.ep_g, e.ep_success, b->n, e.T, e.ldm, e.ldo, RC, R, c, s, tab, e.rc, e.ca,
-                               e.okbits, e.ep_return);
+                               e.okbits, e.ep_return, e.ep_fail);
         return BPG_OK;
     });
     return rcode != BPG_OK ? rcode : check_launch("k_episode");

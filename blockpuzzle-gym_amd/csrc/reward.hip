@@ -174,6 +174,25 @@ k_compute_reward_packed(const uint32_t *__restrict__ now, const uint32_t *__rest
     }
 }
 
+// d_episode_fail_count -> d_episode_return: out[e] = -(float)count[e] (-0.0f for 0), 16 envs per lane (one 16-byte load, four
+// 16-byte stores)
+__global__ void __launch_bounds__(256)
+k_return_from_fail_count(const uint8_t *__restrict__ cnt, float *__restrict__ out, int64_t n, int vec)
+{
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nv = vec ? n >> 4 : 0;
+    for (int64_t v = gtid; v < nv; v += stride) {
+        const uint4 w = reinterpret_cast<const uint4 *>(cnt)[v];
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            st_f4<OUT_NT>(reinterpret_cast<float4 *>(out) + 4 * v + q,
+                          make_float4(-(float)(ws[q] & 255u), -(float)((ws[q] >> 8) & 255u), -(float)((ws[q] >> 16) & 255u),
+                                      -(float)(ws[q] >> 24)));
+    }
+    for (int64_t i = (nv << 4) + gtid; i < n; i += stride) out[i] = -(float)cnt[i];
+}
+
 // ------------------------------ success count -------------------------------
 // rollout.py:163-167 as its own launch: <= 256 blocks of 1024 lanes, 16-byte
 // loads, block reduction, one atomic per block.
@@ -281,6 +300,18 @@ int bpg_compute_reward_packed(const uint32_t *d_now, const uint32_t *d_ever, uin
                        d_ever, want_touch & PAIR_BITS, want_never & PAIR_BITS, n,
                        reinterpret_cast<uint32_t *>(d_out));
     return check_launch("k_compute_reward_packed");
+}
+
+int bpg_episode_return_from_fail_count(const uint8_t *d_count, float *d_out, int64_t n, int device_id, void *stream)
+{
+    if (!d_count || !d_out) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n <= 0) return n == 0 ? BPG_OK : fail(BPG_ERR_ARG, "n < 0");
+    if (!aligned4(d_out)) return fail(BPG_ERR_ARG, "d_out must be 4-byte aligned");
+    DeviceGuard guard(device_id);
+    const int vec = (aligned16(d_count) && aligned16(d_out)) ? 1 : 0;
+    hipLaunchKernelGGL(k_return_from_fail_count, dim3(grid_for((n + 15) / 16, 256, GRID_UNCAPPED)), dim3(256), 0, (hipStream_t)stream,
+                       d_count, d_out, n, vec);
+    return check_launch("k_return_from_fail_count");
 }
 
 int bpg_success_count(bpg_batch *b, unsigned long long *d_count, void *stream)

@@ -24,16 +24,28 @@ namespace bpgk {
 // lane only ever touches its own, so nothing has to be synchronised between the rollouts of a launch; the counts go out
 // as plain atomics that drain behind the next rollout's steps.
 // BPG_TL(slot) / BPG_ROLLOUT_MINB: hooks.hip.h (empty / 1 in the library build).
-template <int SRC, bool NT, int EPL, int OUT, bool RESET, int UNROLL, bool PIPE, bool NTL, int LB, bool OKB = false,
-          bool MULTI = false, bool RET = false>
+// MODE: how the launch starts -- MODE_CONT: from the state as it is; MODE_RESET: with reset_all_rollouts; MODE_MULTI.
+// AUX: AUX_OKB (the step-ok words) or AUX_RET (a per-env counter of held steps in registers, for the episode return /
+// fail count when there is no step-ok word to take it from) or neither.
+// The by-value constants a form does not use are not parameters of its instantiations (NoConst): the kernarg segment of the
+// masks forms carries no SynthConst, that of MODE_CONT no ResetConst.
+enum { MODE_CONT = 0, MODE_RESET = 1, MODE_MULTI = 2 };
+enum { AUX_NONE = 0, AUX_OKB = 1, AUX_RET = 2 };
+struct NoConst {};
+template <int SRC> using SynthArg = std::conditional_t<SRC == SRC_SYNTH, SynthConst, NoConst>;
+template <int MODE> using ResetArg = std::conditional_t<MODE != MODE_CONT, ResetConst, NoConst>;
+
+template <int SRC, int EPL, int OUT, int MODE, int UNROLL, bool PIPE, int LB, int AUX>
 __global__ void __launch_bounds__(LB, BPG_ROLLOUT_MINB)
 k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_t *__restrict__ masks_all,
           uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
-          StepConst c, SynthConst s, ResetConst rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts,
-          uint32_t *__restrict__ ep_return_all)
+          StepConst c, SynthArg<SRC> s, ResetArg<MODE> rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts,
+          uint32_t *__restrict__ ep_return_all, uint8_t *__restrict__ ep_fail_all)
 {
-    static_assert(!MULTI || (RESET && !OKB), "several rollouts per launch: each starts with its reset; no step-ok words");
+    constexpr bool RESET = MODE != MODE_CONT, MULTI = MODE == MODE_MULTI, OKB = AUX == AUX_OKB, RET = AUX == AUX_RET;
+    constexpr bool NT = true, NTL = true;       // write-once streams leave nontemporal, the read-once mask stream arrives so
+    static_assert(!MULTI || !OKB, "several rollouts per launch: no step-ok words");
     using Vec = typename LaneVec<EPL>::vec;
     using Fl = typename LaneVec<EPL>::fl;
     const int64_t nvec = n / EPL;               // the host guarantees n, ld_masks, ld_out % EPL == 0
@@ -48,12 +60,15 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
     uint8_t *__restrict__ flags_tb = flags_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
     uint32_t *__restrict__ ep_return = ep_return_all ? ep_return_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
+    uint8_t *__restrict__ ep_fail = ep_fail_all ? ep_fail_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
     uint32_t nsucc = 0;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
         // a Variation reset (fetch_env.py:646-679) overwrites the whole state: nothing to read, and
         // no wave starts its episode behind a memory round trip
-        if (!(RESET && rc.is_variation)) {
+        bool keeps_state = true;
+        if constexpr (RESET) keeps_state = !rc.is_variation;
+        if (keeps_state) {
             unpack<EPL>(reinterpret_cast<const Vec *>(now)[v], an);
             unpack<EPL>(reinterpret_cast<const Vec *>(ever)[v], ee);
         }
@@ -72,8 +87,8 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         uint32_t nok[EPL] = {};
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
-            if (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
-            if (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
+            if constexpr (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
+            if constexpr (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
             cm[k] = an[k] & PAIR_BITS;
             el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
             ev[k] = ee[k] & ~SUCC_BIT;
@@ -209,15 +224,22 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
             for (int k = 0; k < EPL; k++) okbits[EPL * v + k] = okb[k];          // adjacent: one 8 * EPL-byte store
         }
         if constexpr (RET || OKB) {
+            // steps of this rollout whose success condition did NOT hold, per env: T - (held steps)
+            uint32_t nf[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; k++) nf[k] = (uint32_t)T - (OKB ? (uint32_t)__popcll(okb[k]) : nok[k]);
             if (ep_return) {                        // uniform (an OKB launch may or may not be asked for the return)
                 // r[0] + r[1] + ... of T float32 rewards in {-1.0f, -0.0f}: -(number of -1.0f), -0.0f if there is none
                 uint32_t rt[EPL];
 #pragma unroll
-                for (int k = 0; k < EPL; k++) {
-                    const uint32_t held = OKB ? (uint32_t)__popcll(okb[k]) : nok[k];
-                    rt[k] = __float_as_uint(-(float)((uint32_t)T - held));
-                }
+                for (int k = 0; k < EPL; k++) rt[k] = __float_as_uint(-(float)nf[k]);
                 reinterpret_cast<Vec *>(ep_return)[v] = pack<EPL>(rt);
+            }
+            if (ep_fail) {                          // the same number as one byte per env (the host guarantees T <= 255)
+                uint32_t f = nf[0];
+#pragma unroll
+                for (int k = 1; k < EPL; k++) f |= nf[k] << (8 * k);
+                reinterpret_cast<Fl *>(ep_fail)[v] = (Fl)f;
             }
         }
         if (tl_pass < 2) BPG_TL(3 + 4 * tl_pass);
@@ -255,12 +277,13 @@ constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
 struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
-                                 const void *flags, const void *ep_return = nullptr)
+                                 const void *flags, const void *ep_return = nullptr, const void *ep_fail = nullptr)
 {
     // 2 envs per lane need an even batch, even row strides and 8-byte aligned mask / reward streams
     // (2-byte flags)
     const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
-                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0 && ((uintptr_t)ep_return & 7u) == 0;
+                     ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0 && ((uintptr_t)ep_return & 7u) == 0 &&
+                     ((uintptr_t)ep_fail & 1u) == 0;
     RolloutGeometry g;
     g.unroll = 5;
     if (ok2 && n >= 131072 && !masks) {
@@ -303,16 +326,85 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
 }
 
 
+// ---- dispatch: one launcher per instantiation, looked up in constexpr tables -------------------------------------
+// A launch form is (shape, OUT, MODE, AUX).  The six shapes are the only ones rollout_geometry() hands out; LB is the block
+// size the shape is launched with.
+template <int SRC_, int EPL_, int UNROLL_, bool PIPE_, int LB_> struct Shape {
+    static constexpr int SRC = SRC_, EPL = EPL_, UNROLL = UNROLL_, LB = LB_;
+    static constexpr bool PIPE = PIPE_;
+};
+using ShapeMasksFat = Shape<SRC_MASKS, 2, 5, false, 1024>;     // >= 524 288 envs
+using ShapeMasksMid = Shape<SRC_MASKS, 2, 5, false, 256>;      // >= 229 376 envs (and aliased rows at >= 4 M)
+using ShapeMasksPipe5 = Shape<SRC_MASKS, 1, 5, true, 256>;     // >= 81 920 envs, or an odd batch / unaligned streams
+using ShapeMasksPipe10 = Shape<SRC_MASKS, 1, 10, true, 256>;   // below
+using ShapeSynthWide = Shape<SRC_SYNTH, 2, 10, false, 256>;    // contacts generated in-kernel: nothing to request
+using ShapeSynthNarrow = Shape<SRC_SYNTH, 1, 5, false, 256>;
+
+struct RolloutLaunch {                 // everything a k_rollout launch takes, whatever its form
+    dim3 grid, block;
+    hipStream_t st;
+    uint32_t *now, *ever;
+    const uint32_t *masks;
+    uint32_t *reward;
+    uint8_t *flags;
+    int64_t n, ldm, ldo;
+    int T, rollouts;
+    StepConst c;
+    SynthConst s;
+    ResetConst rc;
+    CountArgs ca;
+    uint64_t *okbits;
+    uint32_t *ep_return;
+    uint8_t *ep_fail;
+};
+using RolloutLauncher = void (*)(const RolloutLaunch &);
+
+template <class SH, int OUT, int MODE, int AUX> void launch_rollout_as(const RolloutLaunch &l)
+{
+    SynthArg<SH::SRC> s{};
+    if constexpr (SH::SRC == SRC_SYNTH) s = l.s;
+    ResetArg<MODE> rc{};
+    if constexpr (MODE != MODE_CONT) rc = l.rc;
+    hipLaunchKernelGGL((k_rollout<SH::SRC, SH::EPL, OUT, MODE, SH::UNROLL, SH::PIPE, SH::LB, AUX>), l.grid, l.block, 0, l.st,
+                       l.now, l.ever, l.masks, l.reward, l.flags, l.n, l.T, l.ldm, l.ldo, l.c, s, rc, l.ca, l.okbits, l.rollouts,
+                       l.ep_return, l.ep_fail);
+}
+
+constexpr int N_OUT = 4, N_MODE = 3, N_AUX = 3, N_FORMS = N_OUT * N_MODE * N_AUX;
+constexpr int form_index(int out, int mode, int aux) { return (out * N_MODE + mode) * N_AUX + aux; }
+
+template <class SH, int I> constexpr RolloutLauncher form_launcher()
+{
+    constexpr int out = I / (N_MODE * N_AUX), mode = (I / N_AUX) % N_MODE, aux = I % N_AUX;
+    if constexpr (mode == MODE_MULTI && aux == AUX_OKB) return nullptr;       // no step-ok words with several rollouts per launch
+    else return &launch_rollout_as<SH, out, mode, aux>;
+}
+
+template <class SH> struct FormTable {
+    RolloutLauncher at[N_FORMS];
+    template <int... I> static constexpr FormTable make(std::integer_sequence<int, I...>) { return FormTable{{form_launcher<SH, I>()...}}; }
+};
+template <class SH> constexpr FormTable<SH> kForms = FormTable<SH>::make(std::make_integer_sequence<int, N_FORMS>());
+
+RolloutLauncher rollout_launcher(const RolloutGeometry &geo, bool synth, int out, int mode, int aux)
+{
+    const int f = form_index(out, mode, aux);
+    if (synth) return geo.epl == 2 ? kForms<ShapeSynthWide>.at[f] : kForms<ShapeSynthNarrow>.at[f];
+    if (geo.epl == 2) return geo.block == 1024 ? kForms<ShapeMasksFat>.at[f] : kForms<ShapeMasksMid>.at[f];
+    return geo.unroll == 5 ? kForms<ShapeMasksPipe5>.at[f] : kForms<ShapeMasksPipe10>.at[f];
+}
+
 }  // namespace bpgk
 
 extern "C" {
 
-int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
+int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
 {
     if (!b || !args) return fail(BPG_ERR_ARG, "NULL argument");
     // struct versioning (include/bpgym.h): fields the caller's header did not have are zero; bytes this library does
     // not know must be zero
     static_assert(offsetof(bpg_rollout_args, gamma) + sizeof(double) == BPG_ROLLOUT_ARGS_MIN_SIZE, "BPG_ROLLOUT_ARGS_MIN_SIZE");
+    static_assert(sizeof(bpg_rollout_args) < 0x10000 && sizeof(bpg_rollout_args) % 8 == 0, "BPG_ARGS_TAG keeps the size in 16 bits");
     bpg_rollout_args local;
     if (int rc = take_args(local, args, BPG_ROLLOUT_ARGS_MIN_SIZE, "bpg_rollout_args")) return rc;
     const bpg_rollout_args *a = &local;
@@ -349,18 +441,16 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     }
     if (a->d_episode_return && ((uintptr_t)a->d_episode_return & 3u) != 0)
         return fail(BPG_ERR_ARG, "d_episode_return must be 4-byte aligned");
+    if (a->d_episode_fail_count && a->T > 255) return fail(BPG_ERR_ARG, "d_episode_fail_count is one byte per env: T <= 255");
     if (gmode == G_OKBITS && !b->d_okbits) {
         // the step-ok words are handle-owned scratch, allocated by the first call that asks for d_G: a hipMalloc is not
         // a stream operation, so that call must not sit inside a stream capture
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs != hipStreamCaptureStatusNone)
-            return fail(BPG_ERR_ARG, "the first bpg_rollout call with d_G allocates the handle's step-ok words: make it once "
-                                     "outside the stream capture (a warm-up call does)");
-        if (hipMalloc(&b->d_okbits, (size_t)((b->n + 1) & ~(int64_t)1) * sizeof(uint64_t)) != hipSuccess) {
-            b->d_okbits = nullptr;
-            return fail(BPG_ERR_HIP, "hipMalloc failed for the step-ok words");
-        }
+            return fail(BPG_ERR_ARG, "d_G needs the handle's step-ok words and a stream capture cannot allocate them: call "
+                                     "bpg_reserve_return_scratch(handle) once before capturing");
+        if (int rc2 = bpg_reserve_return_scratch(b)) return rc2;      // fallback: set-up code should have called it
     }
     uint64_t *okbits = gmode == G_OKBITS ? b->d_okbits : nullptr;
     // several rollouts in one launch (stream path only): rollout r = reset + T steps + count on rows r*T .. of the streams
@@ -372,53 +462,20 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     if (!episode) {
         const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
         const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb,
-                                                     a->d_episode_return);
-        const dim3 grid(geo.grid), block(geo.block);
-#define BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, RET)                               \
-        hipLaunchKernelGGL((k_rollout<SRC, true, EPL, OUT, RST, UNR, PIPE, true, LB, OKB, MULTI, RET>), grid, block, 0, st, \
-                           b->now, b->ever, a->d_masks, rw, a->d_flags_tb, b->n, a->T, ldm, ldo, c, s, rc, ca, okbits,  \
-                           rollouts, reinterpret_cast<uint32_t *>(a->d_episode_return))
-        // the in-loop counter only where the return is asked for and there is no step-ok word to take it from
-#define BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI)                                    \
-        do {                                                                                                  \
-            if (a->d_episode_return && !(OKB)) BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, false, MULTI, true); \
-            else BPG_LAUNCH_ROLLOUT_4(SRC, EPL, OUT, RST, UNR, PIPE, LB, OKB, MULTI, false);                   \
-        } while (0)
-#define BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, OKB)                                                \
-        do {                                                                                                  \
-            if (rollouts > 1) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, false, true);           \
-            else if (a->reset_first) BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, true, UNR, PIPE, LB, OKB, false);     \
-            else BPG_LAUNCH_ROLLOUT_3(SRC, EPL, OUT, false, UNR, PIPE, LB, OKB, false);                        \
-        } while (0)
-#define BPG_LAUNCH_ROLLOUT_1(SRC, EPL, OUT, UNR, PIPE, LB)                                                     \
-        do {                                                                                                  \
-            if (okbits) BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, true);                              \
-            else BPG_LAUNCH_ROLLOUT_2(SRC, EPL, OUT, UNR, PIPE, LB, false);                                    \
-        } while (0)
-#define BPG_LAUNCH_ROLLOUT(SRC, EPL, UNR, PIPE, LB)                                                            \
-        do {                                                                                                  \
-            switch (out) {                                                                                    \
-            case 0: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 0, UNR, PIPE, LB); break;                                  \
-            case 1: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 1, UNR, PIPE, LB); break;                                  \
-            case 2: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 2, UNR, PIPE, LB); break;                                  \
-            default: BPG_LAUNCH_ROLLOUT_1(SRC, EPL, 3, UNR, PIPE, LB); break;                                 \
-            }                                                                                                 \
-        } while (0)
-        // the instantiations below are the only ones: LB is the block size the shape is launched with
-        if (a->d_masks) {
-            if (geo.epl == 2 && geo.block == 1024) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 1024);
-            else if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 2, 5, false, 256);
-            else if (geo.unroll == 5) BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 5, true, 256);
-            else BPG_LAUNCH_ROLLOUT(SRC_MASKS, 1, 10, true, 256);
-        } else {                                   // nothing to request: the plain loop
-            if (geo.epl == 2) BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 2, 10, false, 256);
-            else BPG_LAUNCH_ROLLOUT(SRC_SYNTH, 1, 5, false, 256);
-        }
-#undef BPG_LAUNCH_ROLLOUT
-#undef BPG_LAUNCH_ROLLOUT_1
-#undef BPG_LAUNCH_ROLLOUT_2
-#undef BPG_LAUNCH_ROLLOUT_3
-#undef BPG_LAUNCH_ROLLOUT_4
+                                                     a->d_episode_return, a->d_episode_fail_count);
+        const bool per_env = a->d_episode_return || a->d_episode_fail_count;
+        const int mode = rollouts > 1 ? MODE_MULTI : (a->reset_first ? MODE_RESET : MODE_CONT);
+        // the in-loop counter only where a per-env count is asked for and there is no step-ok word to take it from
+        const int aux = okbits ? AUX_OKB : (per_env ? AUX_RET : AUX_NONE);
+        RolloutLaunch l;
+        l.grid = dim3(geo.grid); l.block = dim3(geo.block); l.st = st;
+        l.now = b->now; l.ever = b->ever; l.masks = a->d_masks; l.reward = rw; l.flags = a->d_flags_tb;
+        l.n = b->n; l.ldm = ldm; l.ldo = ldo; l.T = a->T; l.rollouts = rollouts;
+        l.c = c; l.s = s; l.rc = rc; l.ca = ca; l.okbits = okbits;
+        l.ep_return = reinterpret_cast<uint32_t *>(a->d_episode_return); l.ep_fail = a->d_episode_fail_count;
+        RolloutLauncher fn = rollout_launcher(geo, a->d_masks == nullptr, out, mode, aux);
+        if (!fn) return fail(BPG_ERR_ARG, "rollouts > 1 takes no d_G");
+        fn(l);
         rcode = check_launch("k_rollout");
     } else {
         if ((a->d_ep_ag && !aligned16(a->d_ep_ag)) || (a->d_ep_g && !aligned16(a->d_ep_g)) ||
@@ -428,6 +485,7 @@ int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream)
         e.d_masks = a->d_masks; e.reward_tb = rw; e.flags_tb = a->d_flags_tb;
         e.ep_ag = a->d_ep_ag; e.ep_g = a->d_ep_g; e.ep_success = a->d_ep_success;
         e.T = a->T; e.ldm = ldm; e.ldo = ldo; e.rc = rc; e.ca = ca; e.okbits = okbits; e.ep_return = a->d_episode_return;
+        e.ep_fail = a->d_episode_fail_count;
         rcode = launch_episode(b, e, st);
     }
     if (rcode == BPG_OK && gmode == G_OKBITS) rcode = launch_returns_from_okbits(b->d_okbits, a->d_G, b->n, a->T, a->gamma, st);

@@ -59,6 +59,7 @@ inline int fail(int code, const std::string &msg) { return bpg_fail_(code, msg);
             return fail(BPG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+constexpr int BPG_LIBRARY_VERSION = 105;                    // bpg_version(): 100 + round
 constexpr uint32_t PAIR_BITS = (1u << BPG_NUM_PAIRS) - 1u;  // bits 0..20
 constexpr uint32_t ELAPSED_SHIFT = 21;
 constexpr uint32_t ELAPSED_MAX = 1023;                      // 10 bits, saturating
@@ -90,7 +91,8 @@ struct bpg_batch {
     int ngeom[BPG_MAX_MODELS];
     unsigned long long *d_count_shards;   // COUNT_SHARDS words on 128-byte lines of their own (block_count_add)
     uint64_t *d_okbits;                   // n words: the step-ok bits of the last rollout that asked for G; allocated by
-                                          // the first bpg_rollout call with d_G (NULL until then)
+                                          // bpg_reserve_return_scratch or the first bpg_rollout_v2 call with d_G (NULL until then)
+    bpg_curriculum cur;                   // difficulty + placement ranges (fetch_env.py:340-348, :404-417, :561-563)
 };
 
 namespace bpgk {   // kernels + launch helpers (named so profiles read bpgk::k_*)
@@ -661,14 +663,17 @@ inline int check_launch(const char *what)
 template <typename A>
 inline int take_args(A &local, const A *args, size_t min_size, const char *what)
 {
-    const size_t caller_size = args->struct_size;
-    if (caller_size < min_size || caller_size > 4096 || caller_size % 8 != 0)
-        return fail(BPG_ERR_ARG, std::string(what) + ".struct_size is not set (use the _INIT macro; this library is bpg_version() 104)");
+    const uint32_t tag = args->struct_size;
+    const size_t caller_size = tag & 0xFFFFu;
+    if ((tag & 0xFFFF0000u) != BPG_ARGS_MAGIC || caller_size < min_size || caller_size > 4096 || caller_size % 8 != 0)
+        return fail(BPG_ERR_ARG, std::string(what) + ".struct_size is not BPG_ARGS_TAG(sizeof) (use the _INIT macro of include/bpgym.h; "
+                                 "this library is bpg_version() " + std::to_string(BPG_LIBRARY_VERSION) + ")");
     std::memset(&local, 0, sizeof(local));
     std::memcpy(&local, args, caller_size < sizeof(local) ? caller_size : sizeof(local));
     for (size_t i = sizeof(local); i < caller_size; i++)
         if (reinterpret_cast<const unsigned char *>(args)[i] != 0)
-            return fail(BPG_ERR_UNSUPPORTED, std::string(what) + " carries fields this library (bpg_version() 104) does not know");
+            return fail(BPG_ERR_UNSUPPORTED, std::string(what) + " carries fields this library (bpg_version() " +
+                                             std::to_string(BPG_LIBRARY_VERSION) + ") does not know");
     return BPG_OK;
 }
 
@@ -687,7 +692,7 @@ BPG_INTERNAL int enqueue_bump_counter(uint32_t *d_counter, uint32_t by, hipStrea
 BPG_INTERNAL int launch_returns_from_okbits(const uint64_t *d_okbits, double *d_G, int64_t n, int T, double gamma, hipStream_t st);   // returns.hip
 struct EpisodeLaunch {                                                                              // episode.hip
     const uint32_t *d_masks; uint32_t *reward_tb; uint8_t *flags_tb; float *ep_ag, *ep_g, *ep_success;
-    int T; int64_t ldm, ldo; ResetConst rc; CountArgs ca; uint64_t *okbits; float *ep_return;
+    int T; int64_t ldm, ldo; ResetConst rc; CountArgs ca; uint64_t *okbits; float *ep_return; uint8_t *ep_fail;
 };
 BPG_INTERNAL int launch_episode(bpg_batch *b, const EpisodeLaunch &e, hipStream_t st);
 

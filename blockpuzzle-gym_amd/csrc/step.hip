@@ -390,9 +390,13 @@ int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int3
     if (!b || !d_contacts || !d_ncon || !d_masks) return fail(BPG_ERR_ARG, "NULL argument");
     if (T < 1 || T > (int)ELAPSED_MAX) return fail(BPG_ERR_ARG, "T must be in 1..1023");
     if (maxcon < 1 || maxcon > 4096) return fail(BPG_ERR_ARG, "maxcon must be in 1..4096");
-    if (!aligned4(d_contacts) || !aligned4(d_masks)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
+    if (!aligned4(d_contacts) || !aligned4(d_masks) || !aligned4(d_ncon) || !aligned4(d_num_grey))
+        return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
     const int64_t ld = ld_masks ? ld_masks : b->n;
     if (ld < b->n) return fail(BPG_ERR_ARG, "ld_masks must be 0 or >= n_envs");
+    // element offsets i * maxcon with i < n_envs * T, and ld * T for the mask rows, are formed in 64 bits: keep them well inside
+    if (b->n > (((int64_t)1 << 62) / T) / maxcon || ld > ((int64_t)1 << 62) / T)
+        return fail(BPG_ERR_ARG, "n_envs * T * maxcon is too large");
     const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
     for (int m = 0; m < models; m++)
         if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
@@ -417,7 +421,7 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
     return check_launch("k_contacts_csr_to_masks");
 }
 
-int bpg_step_record(bpg_batch *b, const bpg_step_args *args, void *stream)
+int bpg_step_record_v2(bpg_batch *b, const bpg_step_args *args, void *stream)
 {
     if (!b || !args) return fail(BPG_ERR_ARG, "NULL argument");
     static_assert(sizeof(bpg_step_args) == BPG_STEP_ARGS_MIN_SIZE, "BPG_STEP_ARGS_MIN_SIZE");

@@ -7,10 +7,13 @@ mirroring `success_rate = mean(successes[-1])` (rollout.py:163-167) and
 `mpi_average` (train.py:21-26): RCCL (`nccl` backend) over xGMI on GPUs, `gloo`
 on CPU for the tests.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_range(total_envs, rank, world_size):
@@ -71,11 +74,13 @@ class StreamShards:
     spreads a job over GPUs (contiguous shards keyed by global env index, no data-path exchange), applied once more
     inside a GPU.  The shards' launches are independent, so the hardware runs them side by side: while one shard's
     rollout launch ramps up or drains, the others stream, and the two ends of a launch that a single stream leaves
-    exposed are covered by other shards' work.  Measured (tools/two_stream_shards.py,
-    profiles/r04_stream_shards.log): 524 288 envs as 2 x 262 144: 37.8-38.2 us per rollout against 44.8-44.9 us for one
-    handle (0.80 against 0.68 of the HBM peak); 1 048 576 envs as 4 x 262 144: 79-80 us against 86.5-89.6 us when the
-    launches overlap.  Shards of about 262 144 envs are the ones that share CUs well (256-lane blocks; the 1024-lane shape of
-    larger shards fills a CU on its own).
+    exposed are covered by other shards' work.  Measured (tools/stream_shards.py,
+    profiles/r04_stream_shards.log, launches back to back, nothing joined between rollouts): 524 288 envs as 2 x 262 144:
+    38.6-39.6 us per rollout against 45.2-45.9 us for one handle (0.76-0.79 against 0.66-0.67 of the HBM peak); 1 048 576
+    envs as 4 x 262 144: 79.9-80.8 us against 90.7-91.1 us (0.75-0.76 against 0.67); 4 194 304 envs as 16 x 262 144: 315-320 us
+    against 355-363 us.  Shards of about 262 144 envs are the ones that share CUs well (256-lane blocks; the 1024-lane
+    shape of larger shards fills a CU on its own).  The gain needs arrays of the shard's own and no per-rollout join: an
+    event wait ahead of every launch costs more than the overlap gains (profiles/r04_substreams_in_library.log).
 
     shards[i] = (env, stream); `first[i]` = first global env index of shard i.  Per-env outputs of the shards are slices
     of ONE array when the caller hands each shard its slice (`slices(x)`), so a gather over GPUs still sees one
@@ -180,9 +185,13 @@ def all_gather_per_env(local_values, total_envs=None, shard_sizes=None, out=None
     concatenation, nothing but the collective touches the data.  Ragged shards: the shards are padded to the longest
     (at most one extra env), still one collective, and the result is compacted on the device.
     async_op=True (equal shards only) returns (out, work) without waiting.
-    Without a process group the input is returned as is; a one-rank group still runs the collective (the rehearsal of
-    the RCCL path on a single GPU)."""
+    Without a process group the input is returned as is (copied into `out` when one is given, so the result is where
+    the caller expects it on every path); a one-rank group still runs the collective (the rehearsal of the RCCL path on
+    a single GPU)."""
     if not dist.is_initialized():
+        if out is not None:              # the same contract as under a group: the result is in `out`
+            out.copy_(local_values)
+            local_values = out
         return (local_values, None) if async_op else local_values
     world = dist.get_world_size()
     n_local = local_values.shape[0]
@@ -211,3 +220,80 @@ def all_gather_per_env(local_values, total_envs=None, shard_sizes=None, out=None
         out.copy_(res)
         return out
     return res
+
+
+def episode_return_from_fail_count(counts, out=None):
+    """(n,) uint8 episode fail counts (bpg_rollout_args.d_episode_fail_count) -> (n,) float32 episode returns, the bits
+    the rollout launch's own d_episode_return has: -(float)count, -0.0f for 0.  One launch on the current stream."""
+    assert counts.dtype == torch.uint8 and counts.is_cuda and counts.is_contiguous()
+    if out is None:
+        out = torch.empty(counts.shape, dtype=torch.float32, device=counts.device)
+    assert out.shape == counts.shape and out.dtype == torch.float32 and out.is_contiguous()
+    _lib.check(_lib.lib().bpg_episode_return_from_fail_count(
+        C.c_void_p(counts.data_ptr()), C.c_void_p(out.data_ptr()), counts.numel(), counts.device.index,
+        C.c_void_p(torch.cuda.current_stream(counts.device).cuda_stream)))
+    return out
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/bpgym.h: bpg_comm_*): collectives issued by libbpgym.so itself on the
+    CALLER's stream -- the stream the rollout launch that produced the input ran on, so no event crosses streams -- and
+    usable from a host that is not PyTorch (examples/c_abi_demo.cpp).  torch.distributed's nccl backend runs its
+    collectives on a stream of its own and orders it against the caller's with events: 12-30 us of serialisation per
+    collective per rollout, which a per-rollout gather pays every time.
+
+    RcclComm(rank, world, device, id_bytes): every rank passes the same 128 bytes (rank 0's RcclComm.unique_id()).
+    RcclComm.from_process_group(device): takes them from rank 0 of the initialised torch.distributed group (any backend:
+    the bytes travel as a broadcast object) -- the process group is only the courier."""
+
+    def __init__(self, rank, world, device, id_bytes):
+        dev = torch.device(device)
+        self.rank, self.world, self.device = int(rank), int(world), dev
+        h = C.c_void_p()
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _lib.check(_lib.lib().bpg_comm_create(C.byref(h), self.rank, self.world, buf, dev.index))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        _lib.check(_lib.lib().bpg_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device):
+        if dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+            box = [cls.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+        else:
+            rank, world, box = 0, 1, [cls.unique_id()]
+        return cls(rank, world, device, box[0])
+
+    def close(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            _lib.lib().bpg_comm_destroy(h)
+
+    __del__ = close
+
+    def _stream(self, stream):
+        return C.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
+
+    def all_gather(self, local, out=None, stream=None):
+        """(n_local,) uint8 or float32 -> (world * n_local,) in rank order (global env order for equal contiguous
+        shards): ONE ncclAllGather on `stream` (default: the current stream)."""
+        assert local.is_cuda and local.is_contiguous() and local.dim() == 1
+        if out is None:
+            out = torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        assert out.numel() == self.world * local.numel() and out.dtype == local.dtype and out.is_contiguous()
+        fn = {torch.uint8: _lib.lib().bpg_allgather_u8, torch.float32: _lib.lib().bpg_allgather_f32}[local.dtype]
+        _lib.check(fn(self._h, C.c_void_p(local.data_ptr()), C.c_void_p(out.data_ptr()), local.numel(), self._stream(stream)))
+        return out
+
+    def all_reduce_sum_(self, counts, stream=None):
+        """In-place sum over the ranks of an int64 / uint64 tensor (the [successes, envs] rows): one ncclAllReduce."""
+        assert counts.is_cuda and counts.is_contiguous() and counts.element_size() == 8 and not counts.is_floating_point()
+        _lib.check(_lib.lib().bpg_allreduce_sum_u64(self._h, C.c_void_p(counts.data_ptr()), counts.numel(), self._stream(stream)))
+        return counts

@@ -235,9 +235,8 @@ class BatchedBlocksEnv:
         self.obj_colors = list(i.obj_colors[:i.num_objs])
         g = np.array(i.goal[:i.dimg], dtype=np.float64 if i.desired_goal_is_float else np.int64)
         self.goal = g
-        self.difficulty = 0
-        self.obj_range = 0.15                      # tasks.py: every preset passes obj_range=0.15
-        self._init_curriculum()
+        if self.env_id == 'BlocksTouchVariation-v0':
+            self.max_num_blocks = 4                # fetch_env.py:523
         self.contact_source = contact_source if contact_source is not None else SyntheticContacts()
         B, dev = self.num_envs, self.device
         self._g = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
@@ -288,55 +287,53 @@ class BatchedBlocksEnv:
         args.update(kw)
         return BatchedBlocksEnv(self.env_id, num_envs=num_envs, **args)
 
-    def _init_curriculum(self):
-        # fetch_env.py:340-348 (BlocksTouch), :404-417 (Choose), :561-563 (Variation)
-        v = self.env_id
-        if v in ('BlocksTouch-v0', 'BlocksTouchCurriculum-v0'):
-            if v == 'BlocksTouchCurriculum-v0':
-                self.obj_range, self.obj_range_step, self.max_obj_range = 0.08, 0.025, 0.2
-            else:
-                self.max_obj_range, self.obj_range_step = self.obj_range, 0
-        elif v in ('BlocksTouchChoose-v0', 'BlocksTouchChooseCurriculum-v0'):
-            if v == 'BlocksTouchChooseCurriculum-v0':
-                self.obj_range, self.obj_range_step = 0.08, 0.025
-                self.wrong_obj_range, self.wrong_obj_range_step = 0.2, 0.02
-                self.max_obj_range = 0.3
-            else:
-                self.wrong_obj_range, self.max_obj_range = 0, 0.2
-            self.challenge = False
-        elif v == 'BlocksTouchVariation-v0':
-            self.max_num_blocks = 4
-            self.obj_range, self.obj_range_step, self.max_obj_range = 0.08, 0.025, 0.2
-
     # ----------------------------------------------------- curriculum surface
+    # fetch_env.py:340-348 (BlocksTouch), :404-417 (Choose), :561-563 (Variation), tasks.py (obj_range = 0.15): the
+    # difficulty counter and the placement ranges live in the C-ABI handle (bpg_curriculum: one copy for the batch, as
+    # rollout.py:66-73 raises every env alike); the attributes the reference's envs carry are views of it.
+    def _curriculum(self):
+        c = _lib.Curriculum()
+        _lib.check(self._L.bpg_get_curriculum(self._h, C.byref(c)))
+        return c
+
+    def _curriculum_attr(name, needs_step=False, kind=float):     # noqa: N805  (a property factory, not a method)
+        def get(self):
+            c = self._curriculum()
+            if needs_step and not c.has_step:       # the preset's constructor never set it (quirk Q6, fetch_env.py:413-415)
+                raise AttributeError("'%s' env has no attribute '%s'" % (self.env_id, name))
+            return kind(getattr(c, name))
+
+        def set_(self, value):
+            c = self._curriculum()
+            setattr(c, name, kind(value))
+            if needs_step:
+                c.has_step = 1
+            _lib.check(self._L.bpg_set_curriculum(self._h, C.byref(c)))
+        return property(get, set_)
+
+    difficulty = _curriculum_attr('difficulty', kind=int)
+    obj_range = _curriculum_attr('obj_range')
+    obj_range_step = _curriculum_attr('obj_range_step', needs_step=True)
+    max_obj_range = _curriculum_attr('max_obj_range')
+    wrong_obj_range = _curriculum_attr('wrong_obj_range')
+    wrong_obj_range_step = _curriculum_attr('wrong_obj_range_step', needs_step=True)
+    challenge = _curriculum_attr('challenge', kind=bool)
+    del _curriculum_attr
+
     def get_difficulty(self):
-        return self.difficulty                     # fetch_env.py:96-97
+        return int(self._L.bpg_get_difficulty(self._h))          # fetch_env.py:96-97
 
     def increase_difficulty(self):
-        v = self.env_id
-        if v in ('GripperTouch-v0', 'ToppleTower-v0'):
-            raise NotImplementedError()             # fetch_env.py:93-94
-        if v in ('BlocksTouchChoose-v0', 'BlocksTouchChooseCurriculum-v0'):
-            # fetch_env.py:419-432; the non-curriculum preset lacks *_step (quirk Q6)
-            self.obj_range += self.obj_range_step
-            self.wrong_obj_range -= self.wrong_obj_range_step
-            if self.obj_range > self.max_obj_range:
-                self.obj_range = self.max_obj_range
-                if self.wrong_obj_range < 0:
-                    self.wrong_obj_range = 0
-                    return True
-            else:
-                if self.wrong_obj_range < 0:
-                    self.wrong_obj_range = 0
-            self.difficulty += 1
-            return False
-        # fetch_env.py:351-358 (BlocksTouch) / :623-630 (Variation)
-        self.obj_range += self.obj_range_step
-        if self.obj_range > self.max_obj_range:
-            self.obj_range = self.max_obj_range
-            return True
-        self.difficulty += 1
-        return False
+        """fetch_env.py:351-358 / :419-432 / :623-630 in the handle (bpg_increase_difficulty); True at the maximum level.
+        NotImplementedError (:93-94) and AttributeError (quirk Q6) as the reference raises them."""
+        top = C.c_int(0)
+        rc = self._L.bpg_increase_difficulty(self._h, C.byref(top))
+        if rc == _lib.ERR_UNSUPPORTED:
+            raise NotImplementedError()
+        if rc == _lib.ERR_ATTRIBUTE:
+            raise AttributeError("'%s' env has no attribute 'obj_range_step'" % self.env_id)
+        _lib.check(rc)
+        return bool(top.value)
 
     def set_test(self, variates=None, env_mask=None, achieved_goal_out=None):
         if not self.info.set_test_supported:
@@ -494,7 +491,7 @@ class BatchedBlocksEnv:
         a = _lib.StepArgs(d_masks=dp(m), d_reward=dp(reward), d_flags=dp(flags), d_success_f32=dp(succ_out), d_ag=dp(ag),
                           ld_ag=int(ag.stride(0)), d_u_in=dp(u_in), d_u_out=dp(u_out), d_success_count=dp(count_out),
                           d_return_acc=dp(return_acc))
-        _lib.check(self._L.bpg_step_record(self._h, C.byref(a), st))
+        _lib.check(self._L.bpg_step_record_v2(self._h, C.byref(a), st))
         return reward, flags, ag
 
     def _step_with_args(self, action, sa):
@@ -513,7 +510,7 @@ class BatchedBlocksEnv:
             m = self._masks_of(nxt[1], None, st) if nxt[0] == 'masks' else self._masks_of(None, (nxt[1], nxt[2]), st)
         sa.d_masks = None if m is None else m.data_ptr()
         sa.d_u_in = action.data_ptr() if sa.d_u_out else None
-        _lib.check(self._L.bpg_step_record(self._h, C.byref(sa), st))
+        _lib.check(self._L.bpg_step_record_v2(self._h, C.byref(sa), st))
 
     def step_prefix(self, count, action=None, contact_masks=None, contacts=None):
         """One env step for envs 0 .. count-1 ONLY -- the state the reference's per-env loop (rollout.py:121-137) leaves
@@ -657,11 +654,12 @@ class BatchedBlocksEnv:
         if status is None:
             status = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         em = self._to_dev(env_mask, torch.uint8)
-        a = _lib.PlacementArgs(grip_x=float(grip_xy[0]), grip_y=float(grip_xy[1]), obj_range=float(self.obj_range),
-                               max_obj_range=float(getattr(self, 'max_obj_range', 0.0)),
-                               wrong_obj_range=float(getattr(self, 'wrong_obj_range', 0.0)),
-                               test=int(bool(test)), challenge=int(bool(getattr(self, 'challenge', False))),
+        a = _lib.PlacementArgs(grip_x=float(grip_xy[0]), grip_y=float(grip_xy[1]),
                                d_env_mask=None if em is None else em.data_ptr())
+        # obj_range / max_obj_range / wrong_obj_range / challenge as the handle holds them.  (`test` is passed on as given:
+        # the sampler's test mode is also used by variants whose set_test() raises, through randomize_objects(test=True).)
+        _lib.check(self._L.bpg_placement_from_curriculum(self._h, 0, C.byref(a)))
+        a.test = int(bool(test))
         keep = [em]
         if variates is not None:
             for k in ('eu', 'gz', 'gu'):
@@ -692,14 +690,18 @@ class BatchedBlocksEnv:
 
     # ------------------------------------------------------------ state I/O
     def state_dict(self):
+        c = self._curriculum()
         return {'now': self.state_now.clone(), 'ever': self.state_ever.clone(),
-                'counters': self.state_counters.clone()}
+                'counters': self.state_counters.clone(),
+                'curriculum': {name: getattr(c, name) for name, _ in _lib.Curriculum._fields_}}
 
     def load_state_dict(self, sd):
         self.state_now.copy_(sd['now'])
         self.state_ever.copy_(sd['ever'])
         if 'counters' in sd:
             self.state_counters.copy_(sd['counters'])
+        if 'curriculum' in sd:
+            _lib.check(self._L.bpg_set_curriculum(self._h, C.byref(_lib.Curriculum(**sd['curriculum']))))
         self._fill_static_observation()
 
 

@@ -534,7 +534,8 @@ class RolloutStudent:
         return self._finish(dict(self._graph_ep), self._graph_Qs, counted=True)
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
-                                want_reward=False, materialize_constants=False, gamma=None, episode_return=False):
+                                want_reward=False, materialize_constants=False, gamma=None, episode_return=False,
+                                episode_fail_count=False):
         """Whole rollout in ONE kernel launch (no policy between steps): contacts
         come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
         source when None.  Same episode dict as generate_rollouts; `o` is the
@@ -547,7 +548,10 @@ class RolloutStudent:
         step-ok bits of the launch -- no reward stream is written or read for it.
         episode_return: also return `episode_return` (B,) float32, every env's undiscounted return
         r[0] + ... + r[T-1] (bpg_rollout_args.d_episode_return: the per-env array a multi-GPU job
-        all-gathers, distributed.all_gather_per_env), from a counter of the same launch."""
+        all-gathers, distributed.all_gather_per_env), from a counter of the same launch.
+        episode_fail_count: also `episode_fail_count` (B,) uint8, the same quantity as one byte per env (the number of steps
+        whose success condition did not hold; episode_return == -episode_fail_count bit for bit, T <= 255): the form a
+        multi-GPU job puts on the wire (a quarter of the bytes; distributed.episode_return_from_fail_count expands it)."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
@@ -561,10 +565,14 @@ class RolloutStudent:
             ep['u'].copy_(torch.as_tensor(actions).to(self.device))               # stored as given (rollout.py:147)
         reward = time_major_empty(T, B, torch.float32, self.device) if want_reward else None
         G = torch.empty((B, T), dtype=torch.float64, device=self.device) if gamma is not None else None
+        if G is not None:       # the handle's step-ok words: allocated once, outside any stream capture (idempotent)
+            _lib.check(_lib.lib().bpg_reserve_return_scratch(env._h))
         ret = torch.empty(B, dtype=torch.float32, device=self.device) if episode_return else None
+        nfail = torch.empty(B, dtype=torch.uint8, device=self.device) if episode_fail_count else None
         args = _lib.RolloutArgs(T=T, d_masks=None if masks is None else masks.data_ptr(),
                                 d_G=None if G is None else G.data_ptr(), gamma=0.0 if gamma is None else float(gamma),
                                 d_episode_return=None if ret is None else ret.data_ptr(),
+                                d_episode_fail_count=None if nfail is None else nfail.data_ptr(),
                                 d_reward_tb=None if reward is None else reward.data_ptr(),
                                 d_ep_ag=ep['ag'].data_ptr(),
                                 d_ep_g=ep['g'].data_ptr() if materialize_constants else None,
@@ -575,7 +583,7 @@ class RolloutStudent:
             assert masks.shape == (T, B) and masks.stride(1) == 1 and masks.element_size() == 4 \
                 and (T == 1 or masks.stride(0) >= B)
             args.ld_masks = int(masks.stride(0)) if T > 1 else B
-        _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
+        _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
         out = self._finish(ep, counted=True)
         if want_reward:
             out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
@@ -583,6 +591,8 @@ class RolloutStudent:
             out['G'] = G if self.output == 'torch' else G.cpu().numpy()
         if ret is not None:
             out['episode_return'] = ret if self.output == 'torch' else ret.cpu().numpy()
+        if nfail is not None:
+            out['episode_fail_count'] = nfail if self.output == 'torch' else nfail.cpu().numpy()
         return out
 
     def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
@@ -629,7 +639,7 @@ class RolloutStudent:
                                 d_reward_tb=None if reward_tb is None else reward_tb.data_ptr(),
                                 d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
                                 d_success_count=counts.data_ptr())
-        _lib.check(_lib.lib().bpg_rollout(env._h, C.byref(args), _stream(self.device)))
+        _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
         if env.info.is_variation:       # the K in-launch resets drew new block counts: the env's observation rows follow
             env._fill_static_observation()
         rates = [float(c) / B for c in counts.tolist()]
@@ -685,6 +695,8 @@ class PGRolloutStudent(RolloutStudent):
         if hasattr(policy, 'kwargs'):
             self.kwargs = policy.kwargs             # policy_gradient/rollout.py:53: trim reads ['info']['env_name'] from it
         self._trim_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if gamma is not None:   # the fused form keeps the step rewards as step-ok words in handle-owned scratch: allocated here,
+            _lib.check(_lib.lib().bpg_reserve_return_scratch(self.env._h))   # not by a hipMalloc in the middle of the first rollout
 
     def save_policy_weights(self, path):
         self.policy.save_weights(path)              # policy_gradient/rollout.py:313-314 (train.py:112)
@@ -735,12 +747,13 @@ class PGRolloutStudent(RolloutStudent):
         return o_, g_, ag_
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None, want_reward=False,
-                                materialize_constants=False, gamma=None, episode_return=False):
+                                materialize_constants=False, gamma=None, episode_return=False, episode_fail_count=False):
         """The whole pg rollout in one call without a policy between the steps: the episode arrays and
         the return `G` for this worker's gamma (policy_gradient/rollout.py:255-258, :283-288)."""
         return super().generate_rollouts_fused(test=test, masks=masks, num_grey=num_grey, actions=actions,
                                                want_reward=want_reward, materialize_constants=materialize_constants,
-                                               gamma=self.gamma if gamma is None else gamma, episode_return=episode_return)
+                                               gamma=self.gamma if gamma is None else gamma, episode_return=episode_return,
+                                               episode_fail_count=episode_fail_count)
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None, episode_return=False):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference

@@ -93,10 +93,10 @@ int main()
     unsigned long long *d_c2; HIP(hipMalloc(&d_c2, 16)); HIP(hipMemset(d_c2, 0, 16));
     bpg_rollout_args ra = BPG_ROLLOUT_ARGS_INIT;      // struct_size = sizeof(bpg_rollout_args), every other field zero
     ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_reward_tb = d_r0; ra.d_flags_tb = d_f0; ra.d_success_count = d_c2;
-    CHECK(bpg_rollout(h, &ra, nullptr));
+    CHECK(bpg_rollout_v2(h, &ra, nullptr));
     ra.d_masks = d_m1; ra.d_reward_tb = d_r1; ra.d_flags_tb = d_f1; ra.d_success_count = d_c2 + 1;
     ra.ld_masks = ld; ra.ld_out = ld;
-    CHECK(bpg_rollout(h, &ra, nullptr));
+    CHECK(bpg_rollout_v2(h, &ra, nullptr));
     HIP(hipDeviceSynchronize());
     std::vector<float> r0((size_t)T * B), r1((size_t)T * ld);
     std::vector<uint8_t> f0((size_t)T * B), f1((size_t)T * ld);
@@ -125,7 +125,7 @@ int main()
     // env) from the same launch: d_episode_return
     float *d_ret; HIP(hipMalloc(&d_ret, (size_t)B * 4));
     ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_G = d_G; ra.gamma = gamma; ra.d_episode_return = d_ret;
-    CHECK(bpg_rollout(h, &ra, nullptr));
+    CHECK(bpg_rollout_v2(h, &ra, nullptr));
     HIP(hipDeviceSynchronize());
     std::vector<double> G((size_t)B * T), ref(T);
     std::vector<float> ret((size_t)B);
@@ -163,11 +163,11 @@ int main()
     CHECK(bpg_synth_masks(h2, 0, K * T, d_mk, nullptr));
     ra = BPG_ROLLOUT_ARGS_INIT;
     ra.T = T; ra.reset_first = 1; ra.rollouts = K; ra.d_masks = d_mk; ra.d_flags_tb = d_fk; ra.d_success_count = d_ck;
-    CHECK(bpg_rollout(h2, &ra, nullptr));
+    CHECK(bpg_rollout_v2(h2, &ra, nullptr));
     for (int k = 0; k < K; k++) {
         ra = BPG_ROLLOUT_ARGS_INIT;
         ra.T = T; ra.reset_first = 1; ra.d_masks = d_mk + (size_t)k * T * B; ra.d_success_count = d_ck + K + k;
-        CHECK(bpg_rollout(h3, &ra, nullptr));
+        CHECK(bpg_rollout_v2(h3, &ra, nullptr));
     }
     HIP(hipDeviceSynchronize());
     unsigned long long ck[2 * K];

@@ -78,6 +78,19 @@ enum {
 
 typedef struct bpg_batch bpg_batch;     /* opaque: one batch of envs on one GPU */
 
+/* Versioned argument structs (bpg_step_args, bpg_rollout_args): the first word is BPG_ARGS_TAG(sizeof(the struct as the
+ * caller compiled it)) -- the size in the low 16 bits, a magic number in the high 16, so that a struct of another layout
+ * (a caller built against a header that had no struct_size word there: T or a pointer sits in its place) can never
+ * validate.  Fields are only ever appended; a library that knows more fields than the caller passed treats the missing ones
+ * as zero, a library that knows fewer accepts the call only if the bytes it does not know are all zero
+ * (BPG_ERR_UNSUPPORTED otherwise).  The entry points that take them carry a _v2 suffix: the round-3 names bpg_step_record
+ * (ten positional arguments) and bpg_rollout (a struct without the size word) still exist and return BPG_ERR_UNSUPPORTED
+ * without touching their arguments, so a stale caller gets an error code, not a crash.
+ * `bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT;` for automatic variables (C and C++, no warnings under -Wall -Wextra
+ * -pedantic); `static bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT_STATIC;` is a constant initialiser (C statics / globals). */
+#define BPG_ARGS_MAGIC 0xB5A90000u
+#define BPG_ARGS_TAG(size) ((uint32_t)(size) | BPG_ARGS_MAGIC)
+
 /* Static facts about a variant (tasks.py presets + fetch_env.py class consts). */
 typedef struct {
     int32_t variant;
@@ -193,10 +206,9 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
 
 /* One env.step exactly as the rollout worker consumes it (rollout.py:121-131, :144-150), in ONE
  * launch: the step of bpg_step_masks plus whatever of the following is asked for (every pointer is optional, NULL = not
- * produced; d_u_in / d_u_out go together).  Versioned like bpg_rollout_args: struct_size = sizeof(bpg_step_args) as the
- * caller compiled it (BPG_STEP_ARGS_INIT sets it), fields are only appended, unknown trailing bytes must be zero. */
+ * produced; d_u_in / d_u_out go together).  A versioned struct (see BPG_ARGS_TAG): BPG_STEP_ARGS_INIT sets struct_size. */
 typedef struct {
-    uint32_t struct_size;
+    uint32_t struct_size;      /* BPG_ARGS_TAG(sizeof(bpg_step_args)) */
     uint32_t reserved_;        /* 0 */
     const uint32_t *d_masks;   /* (n_envs) packed pair masks of the step; NULL = the synthetic source */
     float *d_reward;           /* (n_envs) float32 step reward, -1.0f / -0.0f */
@@ -221,11 +233,14 @@ static inline bpg_step_args bpgh_step_args_init(void)
 {
     bpg_step_args a;
     memset(&a, 0, sizeof(a));
-    a.struct_size = (uint32_t)sizeof(a);
+    a.struct_size = BPG_ARGS_TAG(sizeof(a));
     return a;
 }
 #define BPG_STEP_ARGS_INIT bpgh_step_args_init()
-int bpg_step_record(bpg_batch *b, const bpg_step_args *args, void *stream);
+#define BPG_STEP_ARGS_INIT_STATIC { BPG_ARGS_TAG(sizeof(bpg_step_args)), 0u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }
+int bpg_step_record_v2(bpg_batch *b, const bpg_step_args *args, void *stream);
+/* the round-3 entry point of that name took ten positional arguments: kept as a stub that returns BPG_ERR_UNSUPPORTED */
+int bpg_step_record(void);
 
 /* One step whose contacts come from the build-defined counter-based synthetic
  * source keyed (seed, global env id, elapsed step) -- physics stand-in for
@@ -360,12 +375,10 @@ int bpg_trim_expert_inputs(const float *d_o, const float *d_g, const float *d_ag
  * in ONE launch: state stays in registers, every array below is optional
  * (NULL = not produced).  With reset_first the launch also performs the
  * reset_all_rollouts of rollout.py:79; otherwise call bpg_reset first.
- * Versioning: the caller sets struct_size = sizeof(bpg_rollout_args) of the header it was built against
- * (BPG_ROLLOUT_ARGS_INIT does).  Fields are only ever appended; a library that knows more fields than the caller
- * passed treats the missing ones as zero, a library that knows fewer accepts the call only if the bytes it does not
- * know are all zero (BPG_ERR_UNSUPPORTED otherwise).  struct_size < BPG_ROLLOUT_ARGS_MIN_SIZE is BPG_ERR_ARG. */
+ * A versioned struct (see BPG_ARGS_TAG): BPG_ROLLOUT_ARGS_INIT sets struct_size; a size below BPG_ROLLOUT_ARGS_MIN_SIZE or a
+ * first word without the tag is BPG_ERR_ARG. */
 typedef struct {
-    uint32_t struct_size;      /* sizeof(bpg_rollout_args) as the caller compiled it */
+    uint32_t struct_size;      /* BPG_ARGS_TAG(sizeof(bpg_rollout_args)) as the caller compiled it */
     int32_t T;
     int32_t reset_first;       /* 1: reset every env (bpg_reset semantics) inside the launch, before step 0 */
     int32_t rollouts;          /* 0 / 1: one rollout.  K > 1 (stream path, reset_first = 1, no d_ep_*, no d_G): K consecutive
@@ -390,8 +403,8 @@ typedef struct {
                                   (policy_gradient/rollout.py:217-231, :255-258), bit-identical to the reference's
                                   float64 accumulation, WITHOUT a reward stream: for T <= 64 and 0 <= gamma with finite
                                   powers the rollout launch keeps each env's step rewards as one 64-bit step-ok word
-                                  (8 bytes per env, handle-owned, allocated by the first call that asks for d_G -- make
-                                  that call outside a stream capture) and a second launch enqueued by the same call
+                                  (8 bytes per env, handle-owned: bpg_reserve_return_scratch, or the first call that asks
+                                  for d_G, which must then be outside a stream capture) and a second launch enqueued by the same call
                                   expands the words into the rows; 64 < T <= 319, or a gamma that is negative or whose
                                   powers overflow: computed from d_reward_tb, which is then required.  8-byte aligned
                                   (16 for the fast T = 50 / 10 forms).  NULL = not produced */
@@ -403,21 +416,36 @@ typedef struct {
                                   condition did not hold), and -0.0f when it held at every step (a sum that starts from r[0]
                                   keeps the sign of zero; numerically equal to np.sum(rewards, axis=0)).  BASELINE.json's
                                   "aggregated rollout return": 4 bytes per env from a per-env counter in registers, no reward
-                                  stream written or read for it; the one per-env array a multi-GPU job exchanges
-                                  (all-gather).  4-byte aligned.  NULL = not produced */
+                                  stream written or read for it.  4-byte aligned.  NULL = not produced */
+    uint8_t *d_episode_fail_count; /* (n_envs) uint8, or (rollouts, n_envs): the same quantity as ONE BYTE per env -- the
+                                  number of steps of the rollout whose success condition did not hold, so that
+                                  d_episode_return[e] == -(float)d_episode_fail_count[e] bit for bit (-0.0f for 0).  Needs
+                                  T <= 255.  The array a multi-GPU job exchanges (all-gather): a quarter of
+                                  the float32 form's bytes on the wire, expanded on the receiving side by
+                                  bpg_episode_return_from_fail_count.  NULL = not produced */
 } bpg_rollout_args;
-#define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma */
+#define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma (low 16 bits of struct_size) */
 /* `bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT;` -- struct_size set, every other field zero (C and C++, no warnings under
  * -Wall -Wextra -pedantic).  bpgh_* are header-only helpers, not symbols of the library. */
 static inline bpg_rollout_args bpgh_rollout_args_init(void)
 {
     bpg_rollout_args a;
     memset(&a, 0, sizeof(a));
-    a.struct_size = (uint32_t)sizeof(a);
+    a.struct_size = BPG_ARGS_TAG(sizeof(a));
     return a;
 }
 #define BPG_ROLLOUT_ARGS_INIT bpgh_rollout_args_init()
-int bpg_rollout(bpg_batch *b, const bpg_rollout_args *args, void *stream);
+#define BPG_ROLLOUT_ARGS_INIT_STATIC { BPG_ARGS_TAG(sizeof(bpg_rollout_args)), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0 }
+int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream);
+/* the round-3 entry point of that name took a struct without the size word: kept as a stub that returns BPG_ERR_UNSUPPORTED */
+int bpg_rollout(void);
+/* The step-ok words behind bpg_rollout_args.d_G (8 bytes per env) are handle-owned scratch that the first call asking for d_G
+ * would otherwise allocate with a device-synchronising hipMalloc in the middle of the stream (and could not at all inside a
+ * stream capture): allocate them up front, once, from set-up code.  Idempotent. */
+int bpg_reserve_return_scratch(bpg_batch *b);
+/* d_out[e] = -(float)d_count[e] (-0.0f for 0): bpg_rollout_args.d_episode_fail_count back into d_episode_return's float32
+ * form, e.g. after an all-gather of the byte form.  n elements on `device_id`. */
+int bpg_episode_return_from_fail_count(const uint8_t *d_count, float *d_out, int64_t n, int device_id, void *stream);
 
 /* rollout.py:163-167 `successful = successes[-1]`: number of envs whose
  * has_succeeded latch is set, added to *d_count (uint64, caller zeroes it). */
@@ -450,6 +478,53 @@ int bpg_discounted_return_scan(const float *d_reward_tb, int64_t n, int64_t ld, 
  * worker reads the flag once per rollout instead of synchronising every step. */
 int bpg_nan_flag_f32(const float *d_x, int64_t rows, int cols, int64_t ld, uint32_t *d_flag,
                      int device_id, void *stream);
+
+/* ---- curriculum (fetch_env.py:340-358, :404-432, :561-563, :623-630; tasks.py presets) ----------------------------------
+ * The ranges _randomize_objects samples from and the difficulty counter are per-env-object attributes in the reference;
+ * one handle = one batch of identical envs (rollout.py:66-73 raises the difficulty of every env alike), so the handle holds
+ * ONE copy.  bpg_create initialises it as the variant's constructor does. */
+typedef struct {
+    int32_t difficulty;              /* get_difficulty() (fetch_env.py:96-97) */
+    int32_t challenge;               /* BlocksTouchChoose*: self.challenge (:417) */
+    double obj_range, obj_range_step, max_obj_range;
+    double wrong_obj_range, wrong_obj_range_step;
+    int32_t has_step;                /* 0: the preset has no *_step attributes -> increase_difficulty raises AttributeError (Q6) */
+    int32_t reserved_;
+} bpg_curriculum;
+int bpg_get_curriculum(const bpg_batch *b, bpg_curriculum *out);
+/* overwrite the whole state (restoring a checkpoint; a test that starts from a given difficulty) */
+int bpg_set_curriculum(bpg_batch *b, const bpg_curriculum *in);
+int bpg_get_difficulty(const bpg_batch *b);
+/* increase_difficulty() of the variant (fetch_env.py:351-358 BlocksTouch*, :419-432 BlocksTouchChoose*, :623-630 Variation):
+ * *at_max = what the reference returns (1 = the maximum level was reached, nothing else changed).  BPG_ERR_UNSUPPORTED where
+ * the reference raises NotImplementedError (:93-94), BPG_ERR_ATTRIBUTE where it raises AttributeError (quirk Q6). */
+int bpg_increase_difficulty(bpg_batch *b, int *at_max);
+/* The ranges of a placement as reset() (test = 0) or set_test() (test = 1, fetch_env.py:365-368, :443-446) uses them, from the
+ * handle's curriculum state, into `out` (grip_x / grip_y, the variates and the env mask are the caller's to fill).
+ * BPG_ERR_UNSUPPORTED with test = 1 where set_test raises NotImplementedError (:100-101). */
+int bpg_placement_from_curriculum(const bpg_batch *b, int test, bpg_placement_args *out);
+
+/* ---- the one exchange of a multi-GPU job (train.py:21-26 mpi_average, rollout.py:163-167) -----------------
+ * RCCL collectives issued by the library itself on the caller's stream, so that a host that is not PyTorch can run a sharded
+ * job and so that the collective sits on the SAME stream as the rollout launch that produced its input (no cross-stream
+ * event).  librccl.so is loaded on first use: single-GPU hosts never need it (BPG_ERR_UNSUPPORTED if it cannot be loaded).
+ * One process per GPU: rank 0 calls bpg_comm_unique_id, hands the 128 bytes to every rank by its own means (MPI, a socket,
+ * torch.distributed's store), every rank calls bpg_comm_create with the same bytes.  bpg_comm_adopt wraps a communicator
+ * the host already has (an ncclComm_t as void*); bpg_comm_destroy leaves an adopted one alone. */
+typedef struct bpg_comm bpg_comm;
+#define BPG_COMM_ID_BYTES 128
+int bpg_comm_unique_id(void *id_bytes);
+int bpg_comm_create(bpg_comm **out, int rank, int world_size, const void *id_bytes, int device_id);
+int bpg_comm_adopt(bpg_comm **out, void *nccl_comm, int rank, int world_size, int device_id);
+int bpg_comm_destroy(bpg_comm *c);
+int bpg_comm_rank(const bpg_comm *c);
+int bpg_comm_world_size(const bpg_comm *c);
+/* d_out (world_size * n_local elements, global env order for equal contiguous shards) <- every rank's d_local (n_local
+ * elements): the episode fail counts (uint8) or returns (float32) of a rollout, one ncclAllGather on `stream`. */
+int bpg_allgather_u8(bpg_comm *c, const uint8_t *d_local, uint8_t *d_out, int64_t n_local, void *stream);
+int bpg_allgather_f32(bpg_comm *c, const float *d_local, float *d_out, int64_t n_local, void *stream);
+/* in-place sum over the ranks of `count` uint64 words (the [successes, envs] rows of rollout.py:163-167): one ncclAllReduce */
+int bpg_allreduce_sum_u64(bpg_comm *c, unsigned long long *d_inout, int64_t count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -133,10 +133,13 @@ def test_row_stride_helper_is_a_pure_host_function():
         assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
-    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 16 + 9 * 8 + 16 + 16 + 8
-    # BPG_ROLLOUT_ARGS_INIT: the mirror fills in its own size; the minimum the library accepts ends behind gamma
-    assert a.struct_size == C.sizeof(_lib.RolloutArgs) == 128
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 16 + 9 * 8 + 16 + 16 + 8 + 8
+    # BPG_ROLLOUT_ARGS_INIT: the mirror fills in BPG_ARGS_TAG(its own size); the minimum the library accepts ends behind gamma
+    assert a.struct_size == _lib.args_tag(C.sizeof(_lib.RolloutArgs)) == 0xB5A90000 | 136
     assert _lib.RolloutArgs.gamma.offset + 8 == _lib.ROLLOUT_ARGS_MIN_SIZE == 120
+    # the round-3 names survive as stubs: a stale caller gets an error code whatever it passes
+    assert L.bpg_rollout() == _lib.ERR_UNSUPPORTED and b'bpg_rollout_v2' in L.bpg_last_error()
+    assert L.bpg_step_record() == _lib.ERR_UNSUPPORTED and b'bpg_step_record_v2' in L.bpg_last_error()
 
 
 def test_every_kernel_stub_has_a_device_kernel_of_the_same_name():
@@ -176,7 +179,7 @@ def test_no_kernel_uses_scratch_memory():
     for r in rows:
         m = re.search(r'k_rollout<(.*)>', r['name'])
         if m:
-            lb = int(m.group(1).split(',')[8])
+            lb = int(m.group(1).split(',')[6])
             assert lb in (256, 1024) and r['vgpr'] <= (128 if lb == 1024 else 256), r
             seen += 1
     assert seen >= 100
@@ -213,8 +216,12 @@ def test_header_is_plain_c_and_its_structs_have_the_layout_ctypes_assumes(tmp_pa
     the structs a C compiler lays out must be what blockpuzzle-gym_amd/_lib.py mirrors, field by field."""
     import subprocess
     pairs = [('bpg_rollout_args', _lib.RolloutArgs), ('bpg_step_args', _lib.StepArgs), ('bpg_variant_info', _lib.VariantInfo),
-             ('bpg_phys_state', _lib.PhysState), ('bpg_placement_args', _lib.PlacementArgs)]
-    body = ''
+             ('bpg_phys_state', _lib.PhysState), ('bpg_placement_args', _lib.PlacementArgs), ('bpg_curriculum', _lib.Curriculum)]
+    # the constant initialisers (C statics) carry the same tag as the function-style ones
+    body = ('  static bpg_rollout_args sr = BPG_ROLLOUT_ARGS_INIT_STATIC; static bpg_step_args ss = BPG_STEP_ARGS_INIT_STATIC;\n'
+            '  bpg_rollout_args ar = BPG_ROLLOUT_ARGS_INIT; bpg_step_args as = BPG_STEP_ARGS_INIT;\n'
+            '  if (sr.struct_size != ar.struct_size || ss.struct_size != as.struct_size || sr.d_episode_fail_count || ss.d_return_acc) return 1;\n'
+            '  printf("tag.rollout %u\\n", sr.struct_size); printf("tag.step %u\\n", ss.struct_size);\n')
     for cname, ct in pairs:
         body += '  printf("%s.size %%zu\\n", sizeof(%s));\n' % (cname, cname)
         for f in ct._fields_:
@@ -225,6 +232,7 @@ def test_header_is_plain_c_and_its_structs_have_the_layout_ctypes_assumes(tmp_pa
     subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src),
                     '-o', str(exe)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out['tag.rollout']) == _lib.args_tag(C.sizeof(_lib.RolloutArgs)) and int(out['tag.step']) == _lib.args_tag(C.sizeof(_lib.StepArgs))
     for cname, ct in pairs:
         assert int(out[cname + '.size']) == C.sizeof(ct), cname
         for f in ct._fields_:
@@ -242,7 +250,7 @@ def test_every_entry_point_is_exercised_somewhere():
     idle = [n for n in declared
             if not re.search(r'\b%s\b' % n, tests) and len(re.findall(r'\b%s\b' % n, pkg)) < 2]      # 1 = the signature table only
     assert idle == ['bpg_version'], idle            # bpg_version: below
-    assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 104
+    assert C.CDLL(_lib.LIB_PATH).bpg_version() >= 105
 
 
 def test_lazy_success_history_reads_like_a_deque_of_floats():

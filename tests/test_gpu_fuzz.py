@@ -119,7 +119,7 @@ def test_random_api_sequences_vs_oracle(env_id, B):
             with_G = rng.rand() < 0.6               # with d_G the return comes from the step-ok word, without from the counter
             a = bpg._lib.RolloutArgs(T=Tp, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
                                      d_G=G.data_ptr() if with_G else None, gamma=0.9, d_episode_return=ret.data_ptr())
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
             if not with_G:
                 bpg._lib.check(L.bpg_discounted_return(C.c_void_p(rew.data_ptr()), B, Tp, 0.9, C.c_void_p(G.data_ptr()), 0, None))
             torch.cuda.synchronize()
@@ -149,7 +149,7 @@ def test_random_api_sequences_vs_oracle(env_id, B):
             a = bpg._lib.RolloutArgs(T=Tp, reset_first=1, rollouts=K, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(),
                                      d_flags_tb=flg.data_ptr(), d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr(),
                                      d_episode_return=ret.data_ptr() if rng.rand() < 0.7 else None)
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
             torch.cuda.synchronize()
             if a.d_episode_return:
                 rr = rew.cpu().numpy()

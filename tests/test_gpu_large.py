@@ -33,7 +33,7 @@ def packed_rollout(env, masks=None, ret=None):
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_reward_tb=reward.data_ptr(),
                              d_flags_tb=flags.data_ptr(), d_success_count=cnt.data_ptr(),
                              d_episode_return=None if ret is None else ret.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     return masks, reward, flags, cnt
 
 
@@ -101,7 +101,7 @@ def test_episode_arrays_beyond_2_31_elements():
         sc = torch.empty((n, T, 1), dtype=torch.float32, device=DEV)
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), d_ep_ag=ag.data_ptr(),
                                  d_ep_g=g.data_ptr(), d_ep_success=sc.data_ptr())
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         return ag, g, sc
 
     big = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=8)
@@ -138,7 +138,7 @@ def test_return_from_step_ok_words_at_full_size_and_beyond_2_31_elements():
         ng = (torch.arange(B, device=DEV, dtype=torch.int32) * 5) % 3
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
                                  d_reward_tb=reward.data_ptr(), d_G=G.data_ptr(), gamma=gamma)
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         # the last column is the last reward; the recurrence holds within rounding, chunk by chunk (memory)
         step = 1 << 22
         for lo in range(0, B, step):

@@ -40,7 +40,7 @@ def _rollout(env, from_memory=False):
     ng = ((torch.arange(env.num_envs, device=env.device, dtype=torch.int32) + env.env_id_base) * 7) % 3
     args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_episode_return=ret.data_ptr(),
                                 d_success_count=cnt.data_ptr(), **kw)
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(args), None))
     succ = (env.state_ever < 0).float()
     torch.cuda.synchronize()
     return ret, succ, cnt
@@ -124,7 +124,7 @@ def _single_batch_checksum(total, seed):
     ret = torch.empty(total, dtype=torch.float32, device=env.device)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
                              ld_masks=int(masks.stride(0)), d_episode_return=ret.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     nf = (-ret).to(torch.int64)
     w = (torch.arange(total, device=env.device, dtype=torch.int64) % 65521) + 1
     return int(nf.sum()), int((nf * w).sum())

@@ -249,7 +249,7 @@ def test_packed_rollout_and_steps_vs_oracle(env_id, B):
     rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
     flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
     args = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env2._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(env2._h, C.byref(args), None))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(bits(rew), exp_r)
     np.testing.assert_array_equal(flg.cpu().numpy(), exp_f)
@@ -307,10 +307,10 @@ def test_single_launch_rollout_reset_and_count(env_id, B):
                                     d_reward_tb=rew_a.data_ptr(),
                                     d_success_count=counts.data_ptr() + 8 * cur,
                                     d_zero_count=counts.data_ptr() + 8 * (1 - cur))
-        bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+        bpg._lib.check(L.bpg_rollout_v2(a._h, C.byref(args), None))
         b.reset(num_grey=num_grey)
         args_b = bpg._lib.RolloutArgs(T=T, d_masks=dm.data_ptr(), d_reward_tb=rew_b.data_ptr())
-        bpg._lib.check(L.bpg_rollout(b._h, C.byref(args_b), None))
+        bpg._lib.check(L.bpg_rollout_v2(b._h, C.byref(args_b), None))
         assert torch.equal(rew_a.view(torch.int32), rew_b.view(torch.int32))
         assert torch.equal(a.state_now, b.state_now) and torch.equal(a.state_ever, b.state_ever)
         assert int(counts[cur].item()) == int(b.success_count().item()) == int((b.state_ever < 0).sum().item())
@@ -320,9 +320,9 @@ def test_single_launch_rollout_reset_and_count(env_id, B):
     counts.zero_()
     args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=dm.data_ptr(),
                                 d_ep_ag=ag.data_ptr(), d_success_count=counts.data_ptr())
-    bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(a._h, C.byref(args), None))
     b.reset(num_grey=num_grey)
-    bpg._lib.check(L.bpg_rollout(b._h, C.byref(args_b), None))
+    bpg._lib.check(L.bpg_rollout_v2(b._h, C.byref(args_b), None))
     assert torch.equal(a.state_ever, b.state_ever) and int(counts[0].item()) == int(b.success_count().item())
     assert torch.equal(ag[:, T], b._get_obs()['achieved_goal'])
 
@@ -432,7 +432,7 @@ def test_full_size_properties():
     rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
     flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
     args = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr())
-    bpg._lib.check(L.bpg_rollout(full._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(full._h, C.byref(args), None))
     # (a)
     step = bpg.make(env_id, num_envs=B, device=DEV, seed=seed)
     step.reset()
@@ -448,7 +448,7 @@ def test_full_size_properties():
         h.reset()
         rw = torch.empty((T, B // 2), dtype=torch.float32, device=DEV)
         a = bpg._lib.RolloutArgs(T=T, d_masks=None, d_reward_tb=rw.data_ptr())
-        bpg._lib.check(L.bpg_rollout(h._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(h._h, C.byref(a), None))
         sl = slice(k * (B // 2), (k + 1) * (B // 2))
         assert torch.equal(rw.view(torch.int32), rew[:, sl].view(torch.int32))
         assert torch.equal(h.state_ever, full.state_ever[sl])
@@ -601,7 +601,7 @@ def test_edge_batch_sizes(B):
             kw = dict(d_ep_ag=ag.data_ptr(), d_ep_g=g.data_ptr(), d_ep_success=sc.data_ptr())
         args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=dm.data_ptr(),
                                     d_reward_tb=rew.data_ptr(), d_success_count=cnt.data_ptr(), **kw)
-        bpg._lib.check(L.bpg_rollout(e2._h, C.byref(args), None))
+        bpg._lib.check(L.bpg_rollout_v2(e2._h, C.byref(args), None))
         np.testing.assert_array_equal(bits(rew), ref['reward'].view(np.uint32))
         assert int(cnt.item()) == int(ref['info_is_success'][:, -1, 0].sum())
         assert torch.equal(e2.state_now, env.state_now) and torch.equal(e2.state_ever, env.state_ever)
@@ -639,9 +639,9 @@ def test_argument_errors_are_reported():
     with pytest.raises(bpg._lib.BpgError):       # contact lists before an id2obj table -> fine here, table is preset
         bpg._lib.check(L.bpg_step_contacts(env._h, None, None, 4, None, None, None))
     args = bpg._lib.RolloutArgs(T=0)
-    assert L.bpg_rollout(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
+    assert L.bpg_rollout_v2(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
     args = bpg._lib.RolloutArgs(T=5000)
-    assert L.bpg_rollout(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
+    assert L.bpg_rollout_v2(env._h, C.byref(args), None) == bpg._lib.ERR_ARG
     buf = torch.empty(16 * 16 + 1, dtype=torch.float32, device=DEV)
     assert L.bpg_get_achieved_goal_f32(env._h, C.c_void_p(buf.data_ptr()), 8, None) == bpg._lib.ERR_ARG   # ld < dimg
     # misaligned (4-byte offset) output still works through the scalar path
@@ -757,7 +757,7 @@ def test_time_limit_saturation_at_maximum_horizon():
     flg = torch.empty((T, B), dtype=torch.uint8, device=DEV)
     rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
     args = bpg._lib.RolloutArgs(T=T, d_masks=i32(masks).data_ptr(), d_flags_tb=flg.data_ptr(), d_reward_tb=rew.data_ptr())
-    bpg._lib.check(bpg._lib.lib().bpg_rollout(env._h, C.byref(args), None))
+    bpg._lib.check(bpg._lib.lib().bpg_rollout_v2(env._h, C.byref(args), None))
     f = flg.cpu().numpy()
     assert not (f[:-1] & 2).any() and (f[-1] & 2).all()
     L = O.lib()

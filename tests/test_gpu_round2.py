@@ -408,7 +408,7 @@ def test_fused_rollout_shapes_agree_with_single_steps(B, reset_first):
     args = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
                                 d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr(),
                                 d_success_count=cnt.data_ptr())
-    bpg._lib.check(L.bpg_rollout(a._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(a._h, C.byref(args), None))
     if reset_first:
         b.reset(num_grey=ng)
     for t in range(T):
@@ -424,10 +424,10 @@ def test_fused_rollout_shapes_agree_with_single_steps(B, reset_first):
         for e in (c, c2):                                   # both continue from the same (post-rollout) state
             e.load_state_dict(a.state_dict())
         args = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), **kw)
-        bpg._lib.check(L.bpg_rollout(c._h, C.byref(args), None))
+        bpg._lib.check(L.bpg_rollout_v2(c._h, C.byref(args), None))
         full = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
                                     d_reward_tb=r0.data_ptr(), d_flags_tb=f0.data_ptr())
-        bpg._lib.check(L.bpg_rollout(c2._h, C.byref(full), None))
+        bpg._lib.check(L.bpg_rollout_v2(c2._h, C.byref(full), None))
         assert torch.equal(c.state_now, c2.state_now) and torch.equal(c.state_ever, c2.state_ever)
         if 'd_reward_tb' in kw:
             assert torch.equal(reward.view(torch.int32), r0.view(torch.int32))
@@ -447,7 +447,7 @@ def test_synthetic_rollout_shapes_vs_oracle_spec(B):
     flags = torch.empty((T, B), dtype=torch.uint8, device=DEV)
     args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_reward_tb=reward.data_ptr(),
                                 d_flags_tb=flags.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(args), None))
     pick = np.r_[0:64, B // 2:B // 2 + 64, B - 64:B]
     exp_masks = O.synth_masks(seed, base + pick, T, 4 + ng.cpu().numpy()[pick])
     r = reward.cpu().numpy()[:, pick]
@@ -456,7 +456,7 @@ def test_synthetic_rollout_shapes_vs_oracle_spec(B):
     np.testing.assert_array_equal(r.view(np.uint32) == 0x80000000, ((exp_masks >> p23) & 1) == 1)
     # continuing WITHOUT reset uses the per-lane elapsed counters: steps T .. 2T-1 of the same source
     args2 = bpg._lib.RolloutArgs(T=T, reset_first=0, d_reward_tb=reward.data_ptr(), d_flags_tb=flags.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args2), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(args2), None))
     exp2 = O.synth_masks(seed, base + pick, 2 * T, 4 + ng.cpu().numpy()[pick])[T:]
     np.testing.assert_array_equal(reward.cpu().numpy()[:, pick].view(np.uint32) == 0x80000000, ((exp2 >> p23) & 1) == 1)
 
@@ -748,8 +748,8 @@ def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
         a1 = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_num_grey=ng.data_ptr(), d_masks=m1.data_ptr(),
                                   d_reward_tb=r1.data_ptr(), d_flags_tb=f1.data_ptr(), d_success_count=c1.data_ptr(),
                                   ld_masks=ld, ld_out=ld)
-        bpg._lib.check(L.bpg_rollout(a._h, C.byref(a0), None))
-        bpg._lib.check(L.bpg_rollout(b._h, C.byref(a1), None))
+        bpg._lib.check(L.bpg_rollout_v2(a._h, C.byref(a0), None))
+        bpg._lib.check(L.bpg_rollout_v2(b._h, C.byref(a1), None))
         assert torch.equal(r1[:, :B].view(torch.int32), r0.view(torch.int32)) and torch.equal(f1[:, :B], f0)
         assert bool((r1[:, B:] == 7.0).all()) and bool((f1[:, B:] == 0xEE).all())
         assert torch.equal(a.state_now, b.state_now) and torch.equal(a.state_ever, b.state_ever)
@@ -768,8 +768,8 @@ def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
     a2 = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m1.data_ptr(),
                               d_reward_tb=r2.data_ptr(), ld_masks=ld)
     a0 = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m0.data_ptr(), d_reward_tb=r0.data_ptr())
-    bpg._lib.check(L.bpg_rollout(a._h, C.byref(a0), None))
-    bpg._lib.check(L.bpg_rollout(b._h, C.byref(a2), None))
+    bpg._lib.check(L.bpg_rollout_v2(a._h, C.byref(a0), None))
+    bpg._lib.check(L.bpg_rollout_v2(b._h, C.byref(a2), None))
     assert torch.equal(r2.view(torch.int32), r0.view(torch.int32))
     # the episode writer reading padded masks
     if B <= 131074:
@@ -780,7 +780,7 @@ def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
             args = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(),
                                         d_ep_ag=ag.data_ptr(), d_ep_success=sc.data_ptr(), d_reward_tb=rw.data_ptr(),
                                         ld_masks=ldm, ld_out=ld)
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(args), None))
             return ag, sc, rw
         ag0, sc0, rw0 = episode(a, m0, 0)
         ag1, sc1, rw1 = episode(b, m1, ld)
@@ -788,7 +788,7 @@ def test_padded_time_major_streams_equal_contiguous_ones(B, pad):
         assert torch.equal(rw0[:, :B].view(torch.int32), r0.view(torch.int32)) and torch.equal(rw0, rw1)
     # a stride below the batch size is refused
     bad = bpg._lib.RolloutArgs(T=T, d_masks=m0.data_ptr(), ld_masks=B - 2)
-    assert L.bpg_rollout(a._h, C.byref(bad), None) != 0
+    assert L.bpg_rollout_v2(a._h, C.byref(bad), None) != 0
     assert L.bpg_synth_masks_ld(a._h, 0, 1, P(m0), B - 1, None) != 0
     assert L.bpg_discounted_return_ld(P(r0), B, B - 1, 50, 0.98, P(G0), 0, None) != 0
 

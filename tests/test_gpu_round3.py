@@ -111,7 +111,7 @@ def _rollout_with_G(env, T, gamma, masks=None, num_grey=None, reset_first=1, wan
     if episode:
         out['ag'] = torch.empty((B, T + 1, env.dimg), dtype=torch.float32, device=DEV)
         args.d_ep_ag = out['ag'].data_ptr()
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(args), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(args), None))
     torch.cuda.synchronize()
     out['G'] = G
     return out
@@ -177,9 +177,9 @@ def test_rollout_return_for_long_horizons_goes_through_the_reward_stream():
     same_bits(o['G'].cpu().numpy(), oracle_G(o['reward'].cpu().numpy(), gamma))
     G = torch.empty((B, T), dtype=torch.float64, device=DEV)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_G=G.data_ptr(), gamma=gamma)
-    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'd_reward_tb' in L.bpg_last_error()
+    assert L.bpg_rollout_v2(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'd_reward_tb' in L.bpg_last_error()
     a = bpg._lib.RolloutArgs(T=50, reset_first=1, d_G=G.data_ptr() + 4, gamma=gamma)
-    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
+    assert L.bpg_rollout_v2(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
 
 
 @pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower', 'GripperTouch', 'BlocksTouchChoose'])
@@ -240,7 +240,7 @@ def test_masks_with_pairs_of_absent_objects_behave_as_in_the_reference():
         ngt = torch.as_tensor(ng.astype(np.int32), device=DEV)
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ngt.data_ptr(), d_masks=dm.data_ptr(),
                                  d_reward_tb=rew.data_ptr(), ld_out=int(rew.stride(0)))
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         np.testing.assert_array_equal(rew.cpu().numpy()[:, :nb].view(np.uint32), ref['reward'].view(np.uint32))
         env2 = bpg.make(env_id, num_envs=B, device=DEV)
         env2.reset(num_grey=ng)
@@ -264,7 +264,7 @@ def test_success_count_is_exact_at_every_grid_size_and_over_repeated_launches():
         for it in range(3):
             a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr(), ld_out=int(fl.stride(0)),
                                      d_success_count=cnt.data_ptr() + 8 * (it % 2), d_zero_count=cnt.data_ptr() + 8 * ((it + 1) % 2))
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
             torch.cuda.synchronize()
             want = int((fl[T - 1] & 1).sum().item())
             assert int(cnt[it % 2].item()) == want and int(cnt[(it + 1) % 2].item()) == 0, (B, it)
@@ -375,14 +375,14 @@ def test_rollout_with_return_is_capturable_in_a_hip_graph():
     fl = bpg.time_major_empty(T, B, torch.uint8, DEV)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=int(m.stride(0)),
                              d_flags_tb=fl.data_ptr(), ld_out=int(fl.stride(0)), d_G=G.data_ptr(), gamma=gamma)
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     torch.cuda.synchronize()
     want = G.clone()
     s = torch.cuda.Stream(DEV)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), C.c_void_p(s.cuda_stream)))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), C.c_void_p(s.cuda_stream)))
     for _ in range(3):
         G.zero_()
         g.replay()
@@ -433,12 +433,12 @@ def test_k_rollouts_in_one_launch_equal_k_launches(env_id, explicit, B):
                                      d_reward_tb=None if r1 is None else r1[k * T:].data_ptr(),
                                      d_flags_tb=None if f1 is None else f1[k * T:].data_ptr(),
                                      d_success_count=c1[k:].data_ptr())
-            bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+            bpg._lib.check(L.bpg_rollout_v2(one._h, C.byref(a), None))
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ldm, ld_out=ldo if outs else 0,
                                  d_num_grey=None if ng is None else ng.data_ptr(),
                                  d_reward_tb=None if rk is None else rk.data_ptr(),
                                  d_flags_tb=None if fk is None else fk.data_ptr(), d_success_count=ck.data_ptr())
-        bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(many._h, C.byref(a), None))
         torch.cuda.synchronize()
         assert torch.equal(c1, ck), (outs, c1.tolist(), ck.tolist())
         if r1 is not None:
@@ -463,9 +463,9 @@ def test_k_rollouts_from_the_synthetic_source_and_the_argument_checks():
     c1, ck = torch.zeros(K, dtype=torch.int64, device=DEV), torch.zeros(K, dtype=torch.int64, device=DEV)
     for k in range(K):
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=f1[k * T:].data_ptr(), ld_out=B, d_success_count=c1[k:].data_ptr())
-        bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(one._h, C.byref(a), None))
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_flags_tb=fk.data_ptr(), ld_out=B, d_success_count=ck.data_ptr())
-    bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(many._h, C.byref(a), None))
     torch.cuda.synchronize()
     assert torch.equal(f1, fk) and torch.equal(c1, ck)
     # (the synthetic source times its goal contacts by the env key alone, so the K flag blocks are equal by
@@ -480,7 +480,7 @@ def test_k_rollouts_from_the_synthetic_source_and_the_argument_checks():
                 dict(reset_first=1, rollouts=2, d_ep_ag=ag.data_ptr()), dict(reset_first=1, rollouts=-1),
                 dict(reset_first=1, rollouts=5000)):
         with pytest.raises(bpg._lib.BpgError) as e:
-            bpg._lib.check(L.bpg_rollout(many._h, C.byref(bpg._lib.RolloutArgs(T=T, **bad)), None))
+            bpg._lib.check(L.bpg_rollout_v2(many._h, C.byref(bpg._lib.RolloutArgs(T=T, **bad)), None))
         assert e.value.code == bpg._lib.ERR_ARG
     torch.cuda.synchronize()
     for key, v in many.state_dict().items():
@@ -709,10 +709,10 @@ def test_k_rollouts_in_one_launch_at_4m_envs_with_rows_a_power_of_two_apart():
     for k in range(K):
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_masks=masks[k * T:].data_ptr(), ld_masks=B, ld_out=B,
                                  d_reward_tb=r1[k * T:].data_ptr(), d_flags_tb=f1[k * T:].data_ptr(), d_success_count=c1[k:].data_ptr())
-        bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(one._h, C.byref(a), None))
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=B, ld_out=B,
                              d_reward_tb=rk.data_ptr(), d_flags_tb=fk.data_ptr(), d_success_count=ck.data_ptr())
-    bpg._lib.check(L.bpg_rollout(many._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(many._h, C.byref(a), None))
     torch.cuda.synchronize()
     assert torch.equal(c1, ck) and torch.equal(f1, fk) and torch.equal(r1.view(torch.int32), rk.view(torch.int32))
     assert [int((fk[k * T + T - 1] & 1).sum().item()) for k in range(K)] == ck.tolist()
@@ -871,7 +871,7 @@ def test_k_rollouts_at_the_edges_of_the_argument_ranges_against_the_oracle(B, K,
     cnt = torch.zeros(K, dtype=torch.int64, device=DEV)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=dm.data_ptr(), d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(),
                              d_num_grey=dng.data_ptr(), d_success_count=cnt.data_ptr())
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     torch.cuda.synchronize()
     rew, flg = rew.cpu().numpy().view(np.uint32), flg.cpu().numpy()
     oenvs = [O.OracleEnv(env_id) for _ in range(B)]

@@ -96,7 +96,7 @@ def test_two_envs_per_lane_shapes_directly_against_the_oracle(B, pow2_rows):
     def launch(row0, **kw):
         a = bpg._lib.RolloutArgs(T=T, d_masks=masks[row0].data_ptr(), d_reward_tb=reward[row0].data_ptr(),
                                  d_flags_tb=flags[row0].data_ptr(), ld_masks=ld, ld_out=ld, **kw)
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         return env.state_now.clone(), env.state_ever.clone()
 
     states = {}
@@ -188,7 +188,7 @@ def test_episode_return_of_every_launch_form_vs_oracle(env_id, B):
             ret = torch.full((B,), 3.0, dtype=torch.float32, device=DEV)
             a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=dng.data_ptr(), d_masks=dm.data_ptr(),
                                      d_episode_return=ret.data_ptr(), **kw)
-            bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
             return ret
         rew = torch.empty((T, B), dtype=torch.float32, device=DEV)
         fl = torch.empty((T, B), dtype=torch.uint8, device=DEV)
@@ -212,7 +212,7 @@ def test_episode_return_of_every_launch_form_vs_oracle(env_id, B):
     ret = torch.empty(B, dtype=torch.float32, device=DEV)
     for reset_first in (1, 0):
         a = bpg._lib.RolloutArgs(T=T, reset_first=reset_first, d_reward_tb=rew.data_ptr(), d_episode_return=ret.data_ptr())
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         assert torch.equal(ret, -((rew != 0).sum(0).float())) and bool(torch.signbit(ret).all())
 
 
@@ -246,12 +246,16 @@ def test_rollout_args_struct_versioning():
     env = bpg.make(ENV_ID, num_envs=B, device=DEV, seed=1)
     fl = torch.zeros((T, B), dtype=torch.uint8, device=DEV)
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr())
-    assert a.struct_size == C.sizeof(bpg._lib.RolloutArgs)
+    assert a.struct_size == bpg._lib.args_tag(C.sizeof(bpg._lib.RolloutArgs))
     a.struct_size = 0
-    assert L.bpg_rollout(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'struct_size' in L.bpg_last_error()
-    a.struct_size = bpg._lib.ROLLOUT_ARGS_MIN_SIZE
+    assert L.bpg_rollout_v2(env._h, C.byref(a), None) == bpg._lib.ERR_ARG and b'struct_size' in L.bpg_last_error()
+    # a struct of a layout without the tagged size word (the round-3 one had T there: 120, 128, ... passed as sizes in round 4)
+    for stale in (120, 128, 136):
+        a.struct_size = stale
+        assert L.bpg_rollout_v2(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
+    a.struct_size = bpg._lib.args_tag(bpg._lib.ROLLOUT_ARGS_MIN_SIZE)
     a.d_episode_return = 0xdead0000                      # behind the caller's struct: must not be read
-    assert L.bpg_rollout(env._h, C.byref(a), None) == 0
+    assert L.bpg_rollout_v2(env._h, C.byref(a), None) == 0
     torch.cuda.synchronize()
     assert int((fl[T - 1] & 2).sum()) == 0 and int(fl.sum()) >= 0
 
@@ -259,8 +263,8 @@ def test_rollout_args_struct_versioning():
         _fields_ = [('base', bpg._lib.RolloutArgs), ('future_field', C.c_void_p)]
     big = Bigger()
     big.base = bpg._lib.RolloutArgs(T=T, reset_first=1, d_flags_tb=fl.data_ptr())
-    big.base.struct_size = C.sizeof(Bigger)
-    fn = L.bpg_rollout
+    big.base.struct_size = bpg._lib.args_tag(C.sizeof(Bigger))
+    fn = L.bpg_rollout_v2
     rc = fn(env._h, C.cast(C.pointer(big), C.POINTER(bpg._lib.RolloutArgs)), None)
     assert rc == 0
     big.future_field = 1
@@ -286,10 +290,10 @@ def test_return_for_gammas_outside_the_subtractable_set(gamma):
     with np.errstate(over='ignore'):
         subtractable = gamma >= 0 and not np.signbit(gamma) and np.isfinite(np.float64(gamma) ** (T - 1))
     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=dng.data_ptr(), d_masks=dm.data_ptr(), d_G=G.data_ptr(), gamma=gamma)
-    rc = L.bpg_rollout(env._h, C.byref(a), None)
+    rc = L.bpg_rollout_v2(env._h, C.byref(a), None)
     assert (rc == 0) == bool(subtractable), (gamma, rc)
     a.d_reward_tb = rew.data_ptr()
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     with np.errstate(all='ignore'):
         want = oracle_G(rew.cpu().numpy(), gamma)
     for got in (G.cpu().numpy(), bpg.discounted_return(rew, gamma).cpu().numpy()):
@@ -319,12 +323,12 @@ def test_step_ok_words_are_allocated_on_first_use_only():
     held = free0 - torch.cuda.mem_get_info()[0]
     assert 8 * B <= held < 8 * B + (24 << 20), held
     a = bpg._lib.RolloutArgs(T=10, reset_first=1)
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     assert free0 - torch.cuda.mem_get_info()[0] == held
     G = torch.empty((B, 10), dtype=torch.float64, device=DEV)
     free1 = torch.cuda.mem_get_info()[0]
     a = bpg._lib.RolloutArgs(T=10, reset_first=1, d_G=G.data_ptr(), gamma=0.9)
-    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     torch.cuda.synchronize()
     assert 8 * B <= free1 - torch.cuda.mem_get_info()[0] < 8 * B + (8 << 20)
     del G
@@ -455,19 +459,19 @@ def test_per_step_rollouts_accumulate_the_same_episode_return(env_id):
     # struct versioning of bpg_step_args: unset size refused; unknown trailing bytes must be zero
     env = bpg.make(env_id, num_envs=64, device=DEV)
     a = bpg._lib.StepArgs()
-    assert a.struct_size == C.sizeof(bpg._lib.StepArgs) == bpg._lib.STEP_ARGS_MIN_SIZE
-    assert L.bpg_step_record(env._h, C.byref(a), None) == 0
+    assert a.struct_size == bpg._lib.args_tag(C.sizeof(bpg._lib.StepArgs)) == bpg._lib.args_tag(bpg._lib.STEP_ARGS_MIN_SIZE)
+    assert L.bpg_step_record_v2(env._h, C.byref(a), None) == 0
     a.struct_size = 0
-    assert L.bpg_step_record(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
+    assert L.bpg_step_record_v2(env._h, C.byref(a), None) == bpg._lib.ERR_ARG
 
     class Bigger(C.Structure):
         _fields_ = [('base', bpg._lib.StepArgs), ('future_field', C.c_void_p)]
     big = Bigger()
-    big.base.struct_size = C.sizeof(Bigger)
+    big.base.struct_size = bpg._lib.args_tag(C.sizeof(Bigger))
     ptr = C.cast(C.pointer(big), C.POINTER(bpg._lib.StepArgs))
-    assert L.bpg_step_record(env._h, ptr, None) == 0
+    assert L.bpg_step_record_v2(env._h, ptr, None) == 0
     big.future_field = 5
-    assert L.bpg_step_record(env._h, ptr, None) == bpg._lib.ERR_UNSUPPORTED
+    assert L.bpg_step_record_v2(env._h, ptr, None) == bpg._lib.ERR_UNSUPPORTED
     torch.cuda.synchronize()
 
 
@@ -498,14 +502,14 @@ def test_stream_shards_of_one_gpu_equal_one_batch(total, S):
                 a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld,
                                          d_reward_tb=rew.data_ptr(), d_flags_tb=flg.data_ptr(), d_episode_return=ret.data_ptr(),
                                          d_success_count=cnt[it:].data_ptr())
-                bpg._lib.check(L.bpg_rollout(one._h, C.byref(a), None))
+                bpg._lib.check(L.bpg_rollout_v2(one._h, C.byref(a), None))
             else:
                 def go(i, env, st):
                     lo = sh.first[i]
                     a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng[lo:].data_ptr(), d_masks=masks[:, lo:].data_ptr(),
                                              ld_masks=ld, ld_out=ld, d_reward_tb=rew[:, lo:].data_ptr(), d_flags_tb=flg[:, lo:].data_ptr(),
                                              d_episode_return=ret[lo:].data_ptr(), d_success_count=cnt[it * S + i:].data_ptr())
-                    bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), C.c_void_p(st.cuda_stream)))
+                    bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), C.c_void_p(st.cuda_stream)))
                 sh.fork()                            # the masks were written on the current stream
                 sh.for_each(go)
                 sh.join()
@@ -633,7 +637,7 @@ def test_return_from_step_ok_words_at_any_horizon(T):
         assert (G.data_ptr() % 16 == 0) == (off == 0)
         a = bpg._lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=masks.data_ptr(), d_reward_tb=rew.data_ptr(),
                                  d_G=G.data_ptr(), gamma=gamma)
-        bpg._lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        bpg._lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         torch.cuda.synchronize()
         same_bits64(G.cpu().numpy(), oracle_G(rew.cpu().numpy(), gamma))
         tail = flat[off + shift + B * T:]

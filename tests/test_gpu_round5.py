@@ -187,3 +187,165 @@ def test_policy_action_width_is_checked():
         w.generate_rollouts()
     with pytest.raises(ValueError):
         w.env._step_with_args(torch.zeros((B, 3), device=DEV), _lib.StepArgs())
+
+
+# --------------------------------------------------------------------------
+# the byte form of the episode return (bpg_rollout_args.d_episode_fail_count)
+# --------------------------------------------------------------------------
+def bits32(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize('B,T', [(1, 50), (1003, 50), (65536, 50), (262144, 7), (524288, 50), (1048576, 50), (4096, 255)])
+def test_episode_fail_count_is_the_return_in_one_byte(B, T):
+    """Every launch shape of the stream path, the episode writer, one and several rollouts per launch, with and without the
+    step-ok words: d_episode_fail_count[e] == number of -1.0f rewards of env e, and expanding it gives the float32 return
+    the same launch wrote, bit for bit (-0.0f where every step succeeded)."""
+    L = _lib.lib()
+    env_id = 'BlocksTouchVariation-v0'
+    env = bpg.make(env_id, num_envs=B, device=DEV, seed=3)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for K in (1, 3):
+        masks = bpg.time_major_empty(K * T, B, torch.int32, DEV)
+        _lib.check(L.bpg_synth_masks_ld(env._h, 0, K * T, C.c_void_p(masks.data_ptr()), int(masks.stride(0)) if K * T > 1 else B, st))
+        masks |= (torch.rand((K * T, B), device=DEV) < 0.2).to(torch.int32) << 14        # pair (2, 3): some successes
+        reward = bpg.time_major_empty(K * T, B, torch.float32, DEV)
+        ret = torch.empty((K, B), dtype=torch.float32, device=DEV)
+        cnt = torch.full((K, B), 77, dtype=torch.uint8, device=DEV)
+        a = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=int(masks.stride(0)),
+                             d_reward_tb=reward.data_ptr(), ld_out=int(reward.stride(0)), d_episode_return=ret.data_ptr(),
+                             d_episode_fail_count=cnt.data_ptr())
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), st))
+        want = (reward.view(K, T, B) == -1.0).sum(1)
+        assert torch.equal(cnt.to(torch.int64), want)
+        np.testing.assert_array_equal(bits32(bpg.distributed.episode_return_from_fail_count(cnt.view(-1))), bits32(ret.view(-1)))
+        # the count alone (no float32 return asked for), and with the step-ok words (d_G) in the same launch
+        cnt2 = torch.zeros(B, dtype=torch.uint8, device=DEV)
+        G = torch.empty((B, T), dtype=torch.float64, device=DEV) if T <= 64 else None
+        a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=masks.data_ptr(), ld_masks=int(masks.stride(0)),
+                             d_episode_fail_count=cnt2.data_ptr(), d_G=None if G is None else G.data_ptr(), gamma=0.98)
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), st))
+        assert torch.equal(cnt2, cnt[0])
+    # the episode writer
+    if B <= 65536:
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None, dims_of(env_id), None, T,
+                               rollout_batch_size=B, output='torch')
+        ep = w.generate_rollouts_fused(masks=masks[:T], want_reward=True, episode_return=True, episode_fail_count=True)
+        assert torch.equal(ep['episode_fail_count'].to(torch.int64), (ep['reward_tb'] == -1.0).sum(0))
+        np.testing.assert_array_equal(bits32(bpg.distributed.episode_return_from_fail_count(ep['episode_fail_count'])),
+                                      bits32(ep['episode_return']))
+    if T == 255:                                    # one byte per env: longer horizons are refused
+        a = _lib.RolloutArgs(T=256, reset_first=1, d_episode_fail_count=cnt2.data_ptr())
+        assert L.bpg_rollout_v2(env._h, C.byref(a), st) == _lib.ERR_ARG
+    # unaligned / odd-length expansion
+    c = torch.randint(0, 256, (1000003,), dtype=torch.uint8, device=DEV)
+    for off in (0, 1, 5):
+        out = bpg.distributed.episode_return_from_fail_count(c[off:].contiguous() if off == 0 else c[off:].clone())
+        np.testing.assert_array_equal(bits32(out), bits32(-(c[off:].to(torch.float32))))
+
+
+# --------------------------------------------------------------------------
+# curriculum in the handle (fetch_env.py:351-358, :419-432, :623-630)
+# --------------------------------------------------------------------------
+def test_curriculum_traces_through_the_c_abi():
+    """The difficulty traces recorded from the reference's increase_difficulty (variants.json) replayed through
+    bpg_increase_difficulty / bpg_get_difficulty / bpg_get_curriculum -- the state lives in the handle, the Python env's
+    attributes are views of it -- including the reference's exceptions (NotImplementedError, AttributeError: quirk Q6)."""
+    L = _lib.lib()
+    for env_id, v in VARIANTS.items():
+        env = bpg.make(env_id, num_envs=4, device=DEV)
+        top, cur = C.c_int(-1), _lib.Curriculum()
+        if 'error' in v['difficulty']:
+            want = {'NotImplementedError': _lib.ERR_UNSUPPORTED, 'AttributeError': _lib.ERR_ATTRIBUTE}[v['difficulty']['error']]
+            assert L.bpg_increase_difficulty(env._h, C.byref(top)) == want
+            assert L.bpg_get_difficulty(env._h) == 0
+            continue
+        for row in v['difficulty']['rows']:
+            assert L.bpg_increase_difficulty(env._h, C.byref(top)) == 0
+            assert bool(top.value) is row['ret'] and L.bpg_get_difficulty(env._h) == row['difficulty'] == env.get_difficulty()
+            _lib.check(L.bpg_get_curriculum(env._h, C.byref(cur)))
+            assert cur.obj_range == row['obj_range'] == env.obj_range
+            if row['wrong_obj_range'] is not None:
+                assert cur.wrong_obj_range == row['wrong_obj_range'] == env.wrong_obj_range
+        # what a placement at this level samples from: reset() the current ranges, set_test() the maximum ones
+        pa = _lib.PlacementArgs()
+        _lib.check(L.bpg_placement_from_curriculum(env._h, 0, C.byref(pa)))
+        assert (pa.obj_range, pa.max_obj_range, pa.test) == (cur.obj_range, cur.max_obj_range, 0)
+        rc = L.bpg_placement_from_curriculum(env._h, 1, C.byref(pa))
+        assert rc == (0 if v['set_test'] == 'ok' else _lib.ERR_UNSUPPORTED)
+        # a checkpoint carries the level
+        sd = env.state_dict()
+        other = bpg.make(env_id, num_envs=4, device=DEV)
+        other.load_state_dict(sd)
+        assert other.get_difficulty() == env.get_difficulty() and other.obj_range == env.obj_range
+        # the attribute views write through
+        env.obj_range = 0.123
+        _lib.check(L.bpg_get_curriculum(env._h, C.byref(cur)))
+        assert cur.obj_range == 0.123
+
+
+# --------------------------------------------------------------------------
+# collectives issued by the library (bpg_comm_*): one rank is all a one-GPU box can hold
+# --------------------------------------------------------------------------
+def test_library_collectives_on_a_one_rank_communicator():
+    """ncclAllGather / ncclAllReduce from librccl.so (loaded lazily by libbpgym.so) on the caller's stream: with one rank
+    the gather is a copy and the reduce the identity -- the path (dlopen, communicator, datatype, stream) is the one N ranks
+    take.  Multi-rank RCCL needs one GPU per rank: the driver's 8-GPU run is the first to see it."""
+    B, T = 65536, 50
+    env = bpg.make('BlocksTouchVariation-v0', num_envs=B, device=DEV, seed=5)
+    comm = bpg.distributed.RcclComm.from_process_group(torch.device(DEV))
+    assert (comm.rank, comm.world) == (0, 1)
+    side = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(side):
+        cnt = torch.empty(B, dtype=torch.uint8, device=DEV)
+        a = _lib.RolloutArgs(T=T, reset_first=1, d_episode_fail_count=cnt.data_ptr())
+        st = C.c_void_p(side.cuda_stream)
+        _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(a), st))
+        gathered = comm.all_gather(cnt)                         # same stream: ordered behind the launch without an event
+        ret = bpg.distributed.episode_return_from_fail_count(gathered)
+        f = comm.all_gather(ret)
+        stats = torch.tensor([[3, B], [5, B]], dtype=torch.int64, device=DEV)
+        comm.all_reduce_sum_(stats)
+    side.synchronize()
+    assert torch.equal(gathered, cnt) and torch.equal(f, ret) and stats.tolist() == [[3, B], [5, B]]
+    assert int(cnt.max()) <= T and bool((ret <= 0).all())
+    comm.close()
+    L = _lib.lib()
+    assert L.bpg_allgather_u8(None, None, None, 1, None) == _lib.ERR_ARG
+    assert L.bpg_comm_rank(None) == -1 and L.bpg_comm_world_size(None) == 0 and L.bpg_comm_destroy(None) == 0
+    h = C.c_void_p()
+    assert L.bpg_comm_adopt(C.byref(h), None, 0, 1, 0) == _lib.ERR_ARG
+
+
+def test_return_scratch_is_reserved_up_front_and_all_gather_fills_out():
+    """the step-ok words behind d_G are allocated by bpg_reserve_return_scratch (the pg worker's constructor
+    calls it), so the FIRST d_G rollout can already sit inside a stream capture; all_gather_per_env fills `out` on the
+    no-group path too."""
+    L = _lib.lib()
+    B, T = 4096, 50
+    env = bpg.make('BlocksTouch-v0', num_envs=B, device=DEV)
+    G = torch.empty((B, T), dtype=torch.float64, device=DEV)
+    a = _lib.RolloutArgs(T=T, reset_first=1, d_G=G.data_ptr(), gamma=0.98)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(s):
+        s.synchronize()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(g, stream=s):
+                rc = L.bpg_rollout_v2(env._h, C.byref(a), C.c_void_p(s.cuda_stream))
+        finally:
+            pass
+    assert rc == _lib.ERR_ARG and b'bpg_reserve_return_scratch' in L.bpg_last_error()
+    assert L.bpg_reserve_return_scratch(env._h) == 0 and L.bpg_reserve_return_scratch(env._h) == 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(G).all())
+    x = torch.arange(7, dtype=torch.float32, device=DEV)
+    out = torch.full((7,), -1.0, device=DEV)
+    assert bpg.distributed.all_gather_per_env(x, total_envs=7, out=out) is out and torch.equal(out, x)
+    # the round-3 names are stubs now (a stale caller gets an error code, whatever it passes)
+    assert L.bpg_step_record() == _lib.ERR_UNSUPPORTED and L.bpg_rollout() == _lib.ERR_UNSUPPORTED

@@ -78,20 +78,20 @@ def child(which):
         ld = int(m.stride(0))
         _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), ld, None))
         a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), ld_masks=ld, ld_out=ld)
-        _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
         G = [torch.empty((B, T), dtype=torch.float64, device=dev) for _ in range(nrot)]
         res['discounted_return %d' % B] = timed(lambda: _lib.check(L.bpg_discounted_return_ld(P(r), B, ld, T, 0.98, P(rot(G)), 0, None)), 12)
         res['discounted_return_scan %d' % B] = timed(lambda: _lib.check(L.bpg_discounted_return_scan(P(r), B, ld, T, 0.98, P(rot(G)), 0, None)), 12)
 
         def pg():
             a2 = _lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m.data_ptr(), ld_masks=ld, d_G=rot(G).data_ptr(), gamma=0.98)
-            _lib.check(L.bpg_rollout(env._h, C.byref(a2), None))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(a2), None))
         res['rollout + G from step-ok words %d' % B] = timed(pg, 12)
         sf = torch.empty(B, dtype=torch.float32, device=dev)
         def record():
             sa = _lib.StepArgs(d_masks=m[3].data_ptr(), d_reward=r[3].data_ptr(), d_success_f32=sf.data_ptr(),
                                d_ag=rot(ag).data_ptr(), ld_ag=36)
-            _lib.check(L.bpg_step_record(env._h, C.byref(sa), None))
+            _lib.check(L.bpg_step_record_v2(env._h, C.byref(sa), None))
         res['step_record (nontemporal in both) %d' % B] = timed(record, 30)
         fl = torch.empty(B, dtype=torch.uint8, device=dev)
         res['step_masks, same batch (state cache-resident) %d' % B] = timed(

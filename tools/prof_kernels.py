@@ -52,7 +52,7 @@ def rollout(B, reps, synth=False, contiguous=False, pg=False, ret=False):
                              d_flags_tb=f.data_ptr(), d_success_count=None if synth else cnt.data_ptr(),
                              d_G=None if G is None else G.data_ptr(), gamma=0.98,
                              d_episode_return=None if er is None else er.data_ptr())
-        _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     torch.cuda.synchronize()
 
 
@@ -73,7 +73,7 @@ def multi(B, K, reps):
         m, r, f = sets[i % nset]
         a = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_num_grey=ng.data_ptr(), ld_masks=m.stride(0), ld_out=f.stride(0),
                              d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(), d_success_count=cnt.data_ptr())
-        _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+        _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
     torch.cuda.synchronize()
 
 
@@ -146,14 +146,14 @@ def main():
             _lib.check(L.bpg_synth_masks_ld(env._h, 0, T, P(m), LD, None))
             a = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
                                  ld_masks=LD, ld_out=LD)
-            _lib.check(L.bpg_rollout(env._h, C.byref(a), None))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(a), None))
             if w == 'record':
                 ag = torch.empty((B, 36), dtype=torch.float32, device=DEV)
                 sf = torch.empty(B, dtype=torch.float32, device=DEV)
                 for i in range(20):
                     sa = _lib.StepArgs(d_masks=m[i].data_ptr(), d_reward=r[i].data_ptr(), d_flags=f[i].data_ptr(),
                                        d_success_f32=sf.data_ptr(), d_ag=ag.data_ptr(), ld_ag=36)
-                    _lib.check(L.bpg_step_record(env._h, C.byref(sa), None))
+                    _lib.check(L.bpg_step_record_v2(env._h, C.byref(sa), None))
             elif w in ('return', 'scan'):
                 # three (reward, G) pairs round-robin: nothing of the previous launch is left in the 256 MiB cache
                 rs = [r] + [TM(B, torch.float32) for _ in range(2)]
@@ -170,7 +170,7 @@ def main():
                 a3 = _lib.RolloutArgs(T=T, reset_first=1, d_masks=m.data_ptr(), ld_masks=LD, d_ep_ag=ag.data_ptr(), d_ep_g=gg.data_ptr(),
                                       d_ep_success=sc.data_ptr())
                 for i in range(6):
-                    _lib.check(L.bpg_rollout(env._h, C.byref(a3), None))
+                    _lib.check(L.bpg_rollout_v2(env._h, C.byref(a3), None))
             else:
                 n = 4 * B
                 cag = torch.randint(-1, 2, (n, 36), device=DEV).to(torch.float32)

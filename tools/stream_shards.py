@@ -55,7 +55,7 @@ def setup(S, layout='own'):
 def run(shards, n):
     for i in range(n):
         for env, st, args, _ in shards:
-            _lib.check(L.bpg_rollout(env._h, C.byref(args[i % NB]), st))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i % NB]), st))
 
 
 for S, layout in [(S, lay) for _ in range(2) for S in SPLITS for lay in LAYOUTS]:

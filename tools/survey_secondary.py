@@ -131,5 +131,5 @@ env2 = bpg.make(ENV_ID, num_envs=B, device=dev, seed=1, max_episode_steps=T2)
 
 def pg40(g):
     a = _lib.RolloutArgs(T=T2, reset_first=1, d_num_grey=ng.data_ptr(), d_masks=m40.data_ptr(), ld_masks=int(m40.stride(0)), d_G=g.data_ptr(), gamma=0.98)
-    _lib.check(L.bpg_rollout(env2._h, C.byref(a), None))
+    _lib.check(L.bpg_rollout_v2(env2._h, C.byref(a), None))
 timed('rollout + G from step-ok words, T = 40 (two launches)', B * (4 * T2 + 12 + 16 + 8 * T2), [lambda g=g: pg40(g) for g in Gs])

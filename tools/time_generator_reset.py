@@ -26,12 +26,12 @@ for B in (65536, 1 << 20):
         args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=g, d_masks=m.data_ptr(), d_reward_tb=r.data_ptr(), d_flags_tb=f.data_ptr(),
                                  ld_masks=int(m.stride(0)), ld_out=int(m.stride(0)), d_success_count=cnt.data_ptr()) for m, r, f in sets]
         for i in range(2 * nset):
-            _lib.check(L.bpg_rollout(env._h, C.byref(args[i % nset]), None))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i % nset]), None))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = max(60, 3 * nset)
         e0.record()
         for i in range(n):
-            _lib.check(L.bpg_rollout(env._h, C.byref(args[i % nset]), None))
+            _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i % nset]), None))
         e1.record()
         torch.cuda.synchronize()
         print('%8d envs  %-18s %7.2f us per launch' % (B, name, e0.elapsed_time(e1) * 1e3 / n))
