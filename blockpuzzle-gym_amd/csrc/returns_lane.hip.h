@@ -16,7 +16,7 @@ namespace bpgk {
 // in the reference's order.  The choice is per wave and changes no result bit.
 // SCAN: SURVEY 8(f3)'s O(T) reverse scan G[t] = fma(gamma, G[t+1], r[t]) -- NOT the reference's summation
 // order: |G_scan - G_ref| <= 4 T 2^-53 sum_k gamma^k |r[t+k]| (include/bpgym.h states the bound).
-enum { DRM_EXACT = 0, DRM_SCAN = 1 };
+constexpr int DRM_EXACT = 0, DRM_SCAN = 1;
 
 // RT: any horizon T_rt <= TT through the TT-accumulator form -- rows t >= T_rt are neither read nor do they contribute
 // (every guard below is wave-uniform and compiled out when !RT), only the first T_rt entries of a row leave.

@@ -29,8 +29,10 @@ namespace bpgk {
 // fail count when there is no step-ok word to take it from) or neither.
 // The by-value constants a form does not use are not parameters of its instantiations (NoConst): the kernarg segment of the
 // masks forms carries no SynthConst, that of MODE_CONT no ResetConst.
-enum { MODE_CONT = 0, MODE_RESET = 1, MODE_MULTI = 2 };
-enum { AUX_NONE = 0, AUX_OKB = 1, AUX_RET = 2 };
+// (plain ints, not enumerators of an unnamed enum: such a type in a kernel's template-dependent signature is mangled with a
+// per-pass counter -- `$_0` on the host, `$_1` on the device -- and the launch then dies with "Cannot find Symbol")
+constexpr int MODE_CONT = 0, MODE_RESET = 1, MODE_MULTI = 2;
+constexpr int AUX_NONE = 0, AUX_OKB = 1, AUX_RET = 2;
 struct NoConst {};
 template <int SRC> using SynthArg = std::conditional_t<SRC == SRC_SYNTH, SynthConst, NoConst>;
 template <int MODE> using ResetArg = std::conditional_t<MODE != MODE_CONT, ResetConst, NoConst>;

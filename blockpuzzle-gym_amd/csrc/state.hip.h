@@ -363,7 +363,7 @@ __device__ __forceinline__ void reset_core(uint32_t &now, uint32_t &ever, int64_
 }
 
 // ------------------------------ single step ---------------------------------
-enum { SRC_MASKS = 0, SRC_SYNTH = 1 };
+constexpr int SRC_MASKS = 0, SRC_SYNTH = 1;      // plain ints: see MODE_* in rollout.hip
 
 // the step's contact mask: read from memory, or the synthetic source at the env's elapsed step
 template <int SRC>
@@ -437,7 +437,7 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, const Count
 // OUT: which per-step streams are written (bit 0 reward, bit 1 flags) -- a compile-time choice,
 // because a store behind a run-time `if (pointer)` makes the compiler assume "maybe not issued"
 // when it counts outstanding memory operations, and every wait then also drains the stores.
-enum { OUT_REWARD = 1, OUT_FLAGS = 2 };
+constexpr int OUT_REWARD = 1, OUT_FLAGS = 2;
 
 __device__ __forceinline__ void wave_lds_sync()
 {

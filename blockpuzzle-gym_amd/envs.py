@@ -693,7 +693,8 @@ class BatchedBlocksEnv:
         c = self._curriculum()
         return {'now': self.state_now.clone(), 'ever': self.state_ever.clone(),
                 'counters': self.state_counters.clone(),
-                'curriculum': {name: getattr(c, name) for name, _ in _lib.Curriculum._fields_}}
+                # the handle's difficulty and placement ranges, field order of bpg_curriculum (float64 holds the ints exactly)
+                'curriculum': torch.tensor([float(getattr(c, name)) for name, _ in _lib.Curriculum._fields_], dtype=torch.float64)}
 
     def load_state_dict(self, sd):
         self.state_now.copy_(sd['now'])
@@ -701,7 +702,10 @@ class BatchedBlocksEnv:
         if 'counters' in sd:
             self.state_counters.copy_(sd['counters'])
         if 'curriculum' in sd:
-            _lib.check(self._L.bpg_set_curriculum(self._h, C.byref(_lib.Curriculum(**sd['curriculum']))))
+            c = _lib.Curriculum()
+            for (name, ctype), v in zip(_lib.Curriculum._fields_, sd['curriculum'].tolist()):
+                setattr(c, name, int(v) if ctype is C.c_int32 else v)
+            _lib.check(self._L.bpg_set_curriculum(self._h, C.byref(c)))
         self._fill_static_observation()
 
 
