@@ -12,8 +12,16 @@ Weak scaling by default: every GPU holds `--envs` envs (BASELINE configs[2] per 
 `--total-envs E` fixes the JOB size instead and shards it over the ranks (strong scaling).
 With N>1 the run has a SECOND timed leg, reported under `extra.config3_as_written`: BASELINE configs[3] as written --
 4 194 304 envs in total sharded over the N ranks (524 288 per GPU at N = 8), the rollout launch writes every env's
-episode return (4 B/env, bpg_rollout_args.d_episode_return) and the ranks all-gather those returns over RCCL once per
-rollout (`--gpus 8 --total-envs 4194304 --collective allgather --reduce-every 1` makes that leg the headline instead).
+episode fail count (1 B/env, bpg_rollout_args.d_episode_fail_count: the episode return is its negative; `--gather-dtype f32`
+moves the float32 return, 4 B/env, instead), the ranks all-gather those bytes over RCCL once per rollout and expand them to the
+float32 returns on the device (`--gpus 8 --total-envs 4194304 --collective allgather --reduce-every 1` makes that leg the
+headline instead).  A THIRD leg, `extra.config3_cabi_collectives`, repeats it with the collectives issued by the library itself
+on the launch stream (bpg_comm_*, include/bpgym.h) instead of torch.distributed.
+TIMING: `value` = total env-steps of the K timed steps / MAX over ranks of the HIP-event span on the launch stream that covers
+them and the completion of their last exchange, measured inside the barrier + synchronize bracket (see rollout_leg); the wall
+clock of the bracket is reported beside it (`timing`).  N = 1 and N = 8 are measured the same way.
+At N = 1 the line also carries `roofline_sharded`: the same batch run as stream shards (views of the batch on streams of their own),
+which is what the package's fused evaluator does by default from 524 288 envs on.
 
     python bench.py [--gpus N --steps K --warmup W] [--total-envs E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -60,6 +68,17 @@ def parse():
     p.add_argument('--collective', choices=['allreduce', 'allgather'], default='allreduce',
                    help='per-rollout exchange at N>1: all-reduce of (successes, envs) [16 B] or all-gather of every '
                         'env\'s episode return [4 B/env, written by the rollout launch]')
+    p.add_argument('--gather-dtype', choices=['u8', 'f32'], default='u8',
+                   help='all-gather legs: what travels per env -- u8 = the episode fail count (bpg_rollout_args.d_episode_fail_count, '
+                        '1 B/env, expanded to the float32 return on the device after the gather), f32 = the float32 return itself')
+    p.add_argument('--collective-impl', choices=['torch', 'cabi'], default='torch',
+                   help='who issues the collectives: torch.distributed (its nccl backend runs them on a stream of its own, ordered '
+                        'against the launch stream with events) or the library (bpg_comm_*: ncclAllGather / ncclAllReduce on the '
+                        'launch stream itself)')
+    p.add_argument('--no-cabi-leg', action='store_true',
+                   help='N>1: skip the extra configs[3] leg with the library-issued collectives (extra.config3_cabi_collectives)')
+    p.add_argument('--cabi-leg-timeout', type=float, default=90.0,
+                   help='seconds before the extra library-collective leg is given up (the result line is printed without it)')
     p.add_argument('--config3-total', type=int, default=CONFIG3_TOTAL,
                    help='N>1: total envs of the second timed leg (BASELINE configs[3] as written: sharded over the ranks, '
                         'all-gather of the episode returns once per rollout), reported under extra.config3_as_written')
@@ -78,6 +97,8 @@ def parse():
     p.add_argument('--contiguous-rows', action='store_true',
                    help='time-major streams with rows exactly B elements apart (default: bpg_row_stride(B))')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
+    p.add_argument('--no-sharded', action='store_true',
+                   help='skip roofline_sharded (the batch as stream shards: views of the headline batch, and the evaluator worker\'s default)')
     p.add_argument('--stride-pads', default='0,256,768', help='row pads (elements) of the row-stride probe')
     p.add_argument('--no-stride-probe', action='store_true',
                    help='skip the set-up probe of the headline launch at row strides B, B + 256, B + 768')
@@ -185,6 +206,96 @@ def box_state_under_load(cx, h, seconds=0.6):
         except Exception:  # noqa: BLE001
             pass
         return {'error': repr(e)[:300]}
+
+
+def sharded_roofline(cx, h, steps, warmup):
+    """The headline batch as STREAM SHARDS (untimed part of the run, after the measurement; `value` never uses it).
+    (a) views: S = auto_shards(B) views of the headline env (bpg_create_view: contiguous env ranges that share its packed state),
+        each on a stream of its own, launching the headline's own launch (one rollout per launch, same buffer sets -- every
+        shard reads and writes its column range of them) K times back to back; the shards are forked from / joined into the
+        launch stream ONCE around the K steps.  us per rollout of the WHOLE batch = event span / K.
+    (b) worker: what a user of the package gets by default -- RolloutStudent.evaluate_rollouts_fused (the evaluator's test loop,
+        train.py:63-64: K rollouts per call) splits a batch of this size into the same shards itself, one launch of K rollouts
+        per shard, joined before it returns; timed from outside, everything it does included (the K success counts read back,
+        Variation's observation rows rewritten after the K resets); shards=1 beside it.
+    Algorithmic bytes per rollout as in `roofline`: B * (9 T + 12)."""
+    torch, _lib, L, dev, T = cx.torch, cx._lib, cx.L, cx.dev, cx.T
+    import blockpuzzle_gym_amd as bpg
+    B, LD, NBUF, env = h['B'], h['LD'], h['NBUF'], h['env']
+    S = bpg.rollout.auto_shards(B)
+    nbytes = B * (T * 9 + 12)
+    out = {'shards': S, 'envs_per_shard': B // max(S, 1), 'bytes_per_rollout': nbytes, 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+
+    def figure(ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {'ms_per_rollout': ms, 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS, 'env_steps_per_sec': B * T / (ms * 1e-3)}
+    if S < 2:
+        out['note'] = 'a batch of %d envs is not split (auto_shards)' % B
+        return out
+    cur = torch.cuda.current_stream(dev)
+    ng = ((torch.arange(B, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
+    # ---- (a) views of the headline env on the headline's arrays
+    vs = bpg.rollout._ViewShards(env, S)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    vargs = []
+    for hv, st, lo, n in vs.views:
+        vargs.append([_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr() + 4 * lo, d_masks=h['masks'][k].data_ptr() + 4 * lo,
+                                       d_reward_tb=h['reward'][k].data_ptr() + 4 * lo, d_flags_tb=h['flags'][k].data_ptr() + lo,
+                                       ld_masks=LD, ld_out=LD, d_success_count=cnt.data_ptr()) for k in range(NBUF)])
+
+    def train(n_it, first):
+        vs.fork()
+        for i in range(n_it):
+            for (hv, st, lo, n), va in zip(vs.views, vargs):
+                _lib.check(L.bpg_rollout_v2(hv, C.byref(va[(first + i) % NBUF]), C.c_void_p(st.cuda_stream)))
+        vs.join()
+    train(warmup, 0)
+    torch.cuda.synchronize(dev)
+    runs = []
+    for g in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        train(steps, g * steps)
+        e1.record(cur)
+        torch.cuda.synchronize(dev)
+        runs.append(e0.elapsed_time(e1) / steps)
+    out['views_back_to_back'] = dict(figure(min(runs)), runs_ms=runs, launches_per_shard=steps,
+                                     how='%d views x %d launches each on %d streams, forked / joined once around them; HIP events on '
+                                         'the launch stream; min of 3 groups' % (S, steps, S))
+    vs.close()
+    # ---- (b) the evaluator worker's default
+    dims = dict(o=env.dimo, u=4, g=env.dimg, info_is_success=1)
+    w = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=dev, seed=cx.a.seed), None, dims, None, T,
+                           rollout_batch_size=B, output='torch')
+    K = steps
+    masks = torch.empty((K * T, LD), dtype=torch.int32, device=dev)[:, :B]
+    for k in range(K):                              # rollout k reads the rows of buffer set k % NBUF's generator seed
+        w.env.seed(cx.a.seed + k)
+        _lib.check(L.bpg_synth_masks_ld(w.env._h, 0, T, C.c_void_p(masks[k * T].data_ptr()), LD, cx.stream))
+    w.env.seed(cx.a.seed)
+    rw = torch.empty((K * T, LD), dtype=torch.float32, device=dev)[:, :B]
+    fl = torch.empty((K * T, LD), dtype=torch.uint8, device=dev)[:, :B]
+    ngk = ng[None].expand(K, B).contiguous()
+    for label, sh in (('worker_default', None), ('worker_one_launch', 1)):
+        w.evaluate_rollouts_fused(masks, num_grey=ngk, reward_tb=rw, flags_tb=fl, shards=sh)        # warm-up (creates the views)
+        torch.cuda.synchronize(dev)
+        runs = []
+        for g in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            rates = w.evaluate_rollouts_fused(masks, num_grey=ngk, reward_tb=rw, flags_tb=fl, shards=sh)
+            e1.record(cur)
+            torch.cuda.synchronize(dev)
+            runs.append(e0.elapsed_time(e1) / K)
+        out[label] = dict(figure(min(runs)), runs_ms=runs, rollouts_per_call=K, success_rate_last=rates[-1],
+                          how='RolloutStudent.evaluate_rollouts_fused(masks of %d rollouts%s): HIP events around the call, min of 3 calls'
+                              % (K, '' if sh is None else ', shards=1'))
+    del w, masks, rw, fl
+    torch.cuda.empty_cache()
+    # the top-level figure: the package's default for a batch of this size
+    out.update({k: out['worker_default'][k] for k in ('ms_per_rollout', 'achieved', 'frac')})
+    out['kernel'] = 'k_rollout<masks, 2 envs/lane x 256 lanes, reward+flags, %d rollouts per launch> on %d views / streams' % (K, S)
+    return out
 
 
 METRIC = 'env_steps_per_sec'
@@ -328,13 +439,21 @@ def collective_schedule(n_it, warmup, R, multi):
     return coll_after, grp
 
 
-def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_probe=False):
+def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_probe=False, impl='torch', gather_dtype='u8'):
     """One timed leg: W warm-up + exactly K timed fused rollouts of this rank's B-env shard of a `total`-env job, bracketed
-    by barrier + synchronize, MAX over ranks.  collective (N > 1 or forced): 'allreduce' = the [successes, envs] rows in
-    slabs of R rollouts (16 B per rollout); 'allgather' = every env's episode return (bpg_rollout_args.d_episode_return,
-    4 B/env, written by the rollout launch itself) all-gathered into global env order once per R rollouts -- the
-    exchange BASELINE configs[3] names.  Collectives are asynchronous: RCCL runs them on its own stream, so the
-    exchange of rollout i overlaps the kernel of rollout i+1; a return buffer is reused only after its gather is done."""
+    by barrier + synchronize.  collective (N > 1 or forced): 'allreduce' = the [successes, envs] rows in slabs of R rollouts
+    (16 B per rollout); 'allgather' = every env's episode return all-gathered into global env order once per R rollouts --
+    the exchange BASELINE configs[3] names -- as the rollout launch's own per-env byte (bpg_rollout_args.d_episode_fail_count,
+    1 B/env; expanded to the float32 return on the device behind the gather) or as the float32 return (4 B/env).
+    impl = 'torch': torch.distributed issues the collectives (RCCL on its own stream, asynchronous: the exchange of rollout i
+    overlaps the kernel of rollout i+1; a buffer is reused only after its gather is done).  impl = 'cabi': the library issues
+    them on the launch stream (bpg_comm_*): stream order is the only synchronisation.
+    TIMING.  The K timed steps are bracketed by barrier + synchronize on both sides (wall clock `wall_dt`, as before), and
+    INSIDE the bracket a pair of HIP events on the launch stream spans them: the first recorded in front of the first timed
+    launch, the second behind the last launch AND behind the completion of the last exchange (the launch stream waits for it
+    first -- a stream-level wait).  `dt` = MAX over ranks of that device-side span: the same quantity at N = 1 (no collective,
+    no barrier) and at N = 8, where the wall figure additionally holds a dist.barrier() and the host's drain of the collective
+    handles (about 150 us per leg: 8 % of a 20-step window)."""
     torch, dist, _lib, D, L, a = cx.torch, cx.dist, cx._lib, cx.D, cx.L, cx.a
     dev, stream, rank, world, multi, T = cx.dev, cx.stream, cx.rank, cx.world, cx.multi, cx.T
     env = D.make_sharded(ENV_ID, total, rank, world, device=dev, seed=a.seed)
@@ -375,50 +494,87 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     # a collective follows every R-th rollout, the last warm-up rollout and the last rollout; grp[i] = number of
     # collectives before rollout i = the exchange that will carry rollout i's results
     coll_after, grp = collective_schedule(n_it, warmup, R, multi)
-    ret = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
-    gathered = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+    u8 = gather and gather_dtype == 'u8'
+    wire = torch.uint8 if u8 else torch.float32
+    ret = [torch.zeros(B, dtype=wire, device=dev) for _ in range(2)] if gather else None          # what the launch writes
+    gathered = [torch.zeros(total, dtype=wire, device=dev) for _ in range(2)] if gather else None  # what the gather delivers
+    # the float32 returns of all envs, global env order: the gathered array itself, or its expansion on the device
+    returns_f32 = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)] if u8 else gathered
+    comm = cx.comm() if (multi and impl == 'cabi') else None
+
+    def per_env_arg(buf):
+        return dict(d_episode_fail_count=buf.data_ptr()) if u8 else dict(d_episode_return=buf.data_ptr())
     args = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(),
                              d_masks=masks[i % NBUF].data_ptr(), d_reward_tb=reward[i % NBUF].data_ptr(),
                              d_flags_tb=flags[i % NBUF].data_ptr(), ld_masks=LD, ld_out=LD,
-                             d_episode_return=ret[grp[i] % 2].data_ptr() if gather else None,
-                             d_success_count=stats.data_ptr() + 16 * i) for i in range(n_it)]
+                             d_success_count=stats.data_ptr() + 16 * i,
+                             **(per_env_arg(ret[grp[i] % 2]) if gather else {})) for i in range(n_it)]
     # ONE pair of HIP events on the launch stream around the K timed launches: the kernel's average duration =
     # elapsed / K.  (An event pair around every launch puts two marker packets between consecutive kernels: +2.4 us per
     # launch on this stream, measured with round 2's tools/tune_geometry.)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    ev_end = torch.cuda.Event(enable_timing=True)   # behind the last launch AND the last exchange: closes the timed span
     works = []                     # all-reduce handles
-    gworks = {}                    # group index -> all-gather handle
+    gworks = {}                    # group index -> all-gather handle (torch) whose result has not been consumed yet
     pending = [0]                  # first statistics row that has not been all-reduced yet
     ncoll = [0]
 
+    def expand(g):                 # u8 on the wire: the float32 returns on the device, behind the gather, on the launch stream
+        if u8:
+            D.episode_return_from_fail_count(gathered[g % 2], out=returns_f32[g % 2])
+
+    def settle(g):
+        """The launch stream waits for the gather of group g (a stream-level wait, no host block) and expands its bytes."""
+        w = gworks.pop(g, None)
+        if w is not None:
+            w.wait()
+            expand(g)
+
     def one_rollout(i, k=None):
-        if gather and (i == 0 or coll_after[i - 1]):
-            w = gworks.pop(grp[i] - 2, None)      # this group's return buffer was read by the gather two groups ago
-            if w is not None:
-                w.wait()                            # stream-level wait, no host block
+        group_start = gather and impl == 'torch' and (i == 0 or coll_after[i - 1])
+        if group_start:
+            settle(grp[i] - 2)     # this group's buffers were read by the gather two groups ago (settled already, normally)
         if k == 0:
             ev0.record()
         _lib.check(L.bpg_rollout_v2(env._h, C.byref(args[i]), stream))
         if k == steps - 1:
             ev1.record()
+        if group_start:
+            settle(grp[i] - 1)     # the previous group's gather ran beside this launch: wait + expansion go BEHIND the launch
         if coll_after[i]:
             ncoll[0] += 1
             if not gather:
                 # one collective per R rollouts: the [successes, envs] rows not yet reduced
                 lo, pending[0] = pending[0], i + 1
-                works.append(dist.all_reduce(stats[lo:i + 1], async_op=True))
+                if comm is not None:
+                    comm.all_reduce_sum_(stats[lo:i + 1])
+                else:
+                    works.append(dist.all_reduce(stats[lo:i + 1], async_op=True))
+            elif comm is not None:     # the library's ncclAllGather on the launch stream: stream order is all there is
+                g = grp[i]
+                comm.all_gather(ret[g % 2], out=gathered[g % 2])
+                expand(g)
             elif equal_shards:     # one all_gather_into_tensor straight into the (total,) result
                 g = grp[i]
                 gworks[g] = D.all_gather_per_env(ret[g % 2], total_envs=total, out=gathered[g % 2], async_op=True)[1]
             else:                  # ragged shards: padded, still one collective, compacted on the device
                 D.all_gather_per_env(ret[grp[i] % 2], total_envs=total, out=gathered[grp[i] % 2])
+                expand(grp[i])
+
+    def close_span():
+        """Everything the K steps started has completed on the launch stream when ev_end fires."""
+        for w in works:
+            w.wait()               # stream-level: the launch stream waits for RCCL's stream
+        for g in sorted(gworks):
+            settle(g)
+        ev_end.record()
 
     def drain():
         while works:
             works.pop().wait()
         for g in sorted(gworks):
-            gworks.pop(g).wait()
+            settle(g)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -478,8 +634,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     scratch = torch.zeros(2, dtype=torch.int64, device=dev)
     pre = [_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=num_grey.data_ptr(), d_masks=masks[k].data_ptr(),
                             d_reward_tb=reward[k].data_ptr(), d_flags_tb=flags[k].data_ptr(), ld_masks=LD, ld_out=LD,
-                            d_episode_return=ret[0].data_ptr() if gather else None,
-                            d_success_count=scratch.data_ptr()) for k in range(NBUF)]
+                            d_success_count=scratch.data_ptr(), **(per_env_arg(ret[0]) if gather else {})) for k in range(NBUF)]
     if prewarm > 0:                        # set-up, not measurement: same launch, scratch statistics row
         for i in range(prewarm):
             _lib.check(L.bpg_rollout_v2(env._h, C.byref(pre[i % NBUF]), stream))
@@ -491,14 +646,22 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     t0 = time.perf_counter()
     for k in range(steps):
         one_rollout(warmup + k, k)
+    close_span()
     host_dt = time.perf_counter() - t0          # time to ENQUEUE the K steps (host side only)
     drain()
     fence()
-    dt = time.perf_counter() - t0
+    wall_dt = time.perf_counter() - t0
+    span_dt = ev0.elapsed_time(ev_end) * 1e-3    # device-side span of the K steps incl. the completion of the last exchange
+    rank_span_ms, rank_wall_ms = [span_dt * 1e3], [wall_dt * 1e3]
+    dt = span_dt
     if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        both = torch.tensor([span_dt, wall_dt], dtype=torch.float64, device=dev)
+        allb = [torch.zeros_like(both) for _ in range(dist.get_world_size())]
+        dist.all_gather(allb, both)
+        rank_span_ms = [float(b[0].item()) * 1e3 for b in allb]
+        rank_wall_ms = [float(b[1].item()) * 1e3 for b in allb]
+        dt = max(rank_span_ms) * 1e-3
+        wall_dt = max(rank_wall_ms) * 1e-3
     kernel_ms = ev0.elapsed_time(ev1) / steps
     # Spread (untimed, after the measurement): three more groups of K launches of the same kernel on the same buffers,
     # each between its own event pair, no collectives -- how much the launch duration moves on this box, and at N > 1
@@ -529,13 +692,18 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     if gather:
         # the gathered (total,) returns of the LAST rollout, reduced to two integers any single-batch run can reproduce:
         # failed steps summed over all envs, and the same weighted by (global env index mod 65521) + 1
-        gl = gathered[grp[n_it - 1] % 2]
+        gl = returns_f32[grp[n_it - 1] % 2]
         nf = (-gl).to(torch.int64)
         wts = (torch.arange(total, device=dev, dtype=torch.int64) % 65521) + 1
         checksum = {'failed_steps': int(nf.sum().item()), 'weighted': int((nf * wts).sum().item()),
                     'all_negative_zero_or_below': bool(torch.signbit(gl).all().item()),
-                    'mask_buffer_set': (n_it - 1) % NBUF, 'seed': a.seed + (n_it - 1) % NBUF}
-    return dict(env=env, masks=masks, reward=reward, flags=flags, B=B, total=total, LD=LD, NBUF=NBUF, R=R, dt=dt,
+                    'mask_buffer_set': (n_it - 1) % NBUF, 'seed': a.seed + (n_it - 1) % NBUF,
+                    'on_the_wire': 'u8 fail counts, expanded on the device' if u8 else 'f32 returns'}
+        if u8:      # the bytes that travelled ARE the returns: -(float)count, bit for bit
+            checksum['expansion_matches_bytes'] = bool(torch.equal(gl, -(gathered[grp[n_it - 1] % 2].to(torch.float32))))
+    return dict(env=env, masks=masks, reward=reward, flags=flags, B=B, total=total, LD=LD, NBUF=NBUF, R=R, dt=dt, wall_dt=wall_dt,
+                rank_span_ms=rank_span_ms, rank_wall_ms=rank_wall_ms, impl=impl if multi else None,
+                wire_bytes_per_env=(1 if u8 else 4) if gather else None,
                 host_dt=host_dt, kernel_ms=kernel_ms, rank_kernel_ms=rank_kernel_ms, spread=spread, succ_rate=succ_rate,
                 checksum=checksum, probe=probe, collectives=ncoll[0], gather=gather, steps=steps, warmup=warmup)
 
@@ -578,16 +746,33 @@ def run(a):
         torch.cuda.set_stream(torch.cuda.Stream(dev))
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     cx = types.SimpleNamespace(torch=torch, dist=dist, _lib=_lib, D=D, L=L, a=a, dev=dev, stream=stream, rank=rank,
-                               world=world, multi=multi, T=T)
+                               world=world, multi=multi, T=T, _comm=None)
 
-    h = rollout_leg(cx, total, B, a.collective, a.reduce_every, a.steps, a.warmup, a.prewarm, stride_probe=True)
+    def comm():         # the library's own RCCL communicator (bpg_comm_*), created on first use: a collective over the ranks
+        if cx._comm is None:
+            cx._comm = D.RcclComm.from_process_group(dev)
+        return cx._comm
+    cx.comm = comm
+    # which device every rank really runs on (LOCAL_RANK -> cuda index, the visible-device lists, the device's identity)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {'rank': rank, 'local_rank': local, 'device': 'cuda:%d' % dev.index, 'name': props.name,
+            'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': getattr(props, 'pci_bus_id', None),
+            'HIP_VISIBLE_DEVICES': os.environ.get('HIP_VISIBLE_DEVICES'), 'ROCR_VISIBLE_DEVICES': os.environ.get('ROCR_VISIBLE_DEVICES'),
+            'CUDA_VISIBLE_DEVICES': os.environ.get('CUDA_VISIBLE_DEVICES'), 'visible_device_count': torch.cuda.device_count()}
+    rank_devices = [mine]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        rank_devices = [None] * dist.get_world_size()
+        dist.all_gather_object(rank_devices, mine)
+
+    h = rollout_leg(cx, total, B, a.collective, a.reduce_every, a.steps, a.warmup, a.prewarm, stride_probe=True,
+                    impl=a.collective_impl, gather_dtype=a.gather_dtype)
     dt, kernel_ms, LD, NBUF, R = h['dt'], h['kernel_ms'], h['LD'], h['NBUF'], h['R']
 
     # algorithmic bytes of the fused rollout launch: per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env the packed state 8 B out (the in-launch Variation reset
     # overwrites the whole state, so the old state is not an input) + the explicit num_grey draw 4 B in
     # (+ the episode return 4 B out when the leg all-gathers it)
-    bytes_per_launch = B * (T * 9 + 8 + 4 + (4 if h['gather'] else 0))
+    bytes_per_launch = B * (T * 9 + 8 + 4 + (h['wire_bytes_per_env'] or 0))
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     tf = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -620,11 +805,19 @@ def run(a):
         'metric': 'env_steps_per_sec', 'value': total * T * a.steps / dt, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
         'host_enqueue_ms_per_step': h['host_dt'] / a.steps * 1e3,
+        # how `value` is timed: see rollout_leg.  The wall figure (perf_counter from in front of the first enqueue to behind the
+        # closing synchronize / barrier / synchronize) is what rounds 1-4 reported as ms_per_step.
+        'timing': {'value_uses': 'MAX over ranks of the HIP-event span on the launch stream: first timed launch -> behind the last '
+                                 'launch and the completion of the last exchange; inside the barrier + synchronize bracket',
+                   'span_ms_per_rank': h['rank_span_ms'], 'wall_ms_per_rank': h['rank_wall_ms'],
+                   'wall_ms_per_step_incl_sync_and_barrier': h['wall_dt'] / a.steps * 1e3,
+                   'value_from_wall_clock': total * T * a.steps / h['wall_dt']},
         'higher_is_better': True, 'scaling': 'strong' if a.total_envs else 'weak', 'vs_baseline': None, 'dtype': 'u32',
         'data': 'synthetic',
         'config': {'workload': '%s, %d envs per GPU x T=%d fused rollout per step, contact masks (T,B) u32 '
                                '(rows %d elements apart) resident in HBM, packed now/ever state, reward f32 + flags u8 written per '
-                               'env-step%s' % (ENV_ID, B, T, LD, ', episode return f32 per env' if h['gather'] else ''),
+                               'env-step%s' % (ENV_ID, B, T, LD, (', episode %s per env' % ('fail count u8' if h['wire_bytes_per_env'] == 1 else 'return f32'))
+                                               if h['gather'] else ''),
                    'envs_per_gpu': B, 'total_envs': total, 'T': T, 'row_stride_elements': LD,
                    'parallelism': 'env-shard x%d' % world,
                    'buffer_sets': NBUF, 'collective': coll,
@@ -634,9 +827,11 @@ def run(a):
         'rccl_world_size': (dist.get_world_size() if dist.is_initialized() else 1),
         'backend': (dist.get_backend() if dist.is_initialized() else None),
         'collective': coll,
+        'collective_impl': h['impl'],
+        'rank_devices': rank_devices,
         'collectives_issued': (h['collectives'] if multi else None),
-        'collective_bytes_per_rollout': (None if not multi else (4 * total if h['gather'] else 16)),
-        'gathered_bytes_per_rollout': (4 * total if h['gather'] else None),
+        'collective_bytes_per_rollout': (None if not multi else (h['wire_bytes_per_env'] * total if h['gather'] else 16)),
+        'gathered_bytes_per_rollout': (h['wire_bytes_per_env'] * total if h['gather'] else None),
         'gathered_return_checksum': h['checksum'],
         'kernel_ms_per_rank': {'min': min(h['rank_kernel_ms']), 'max': max(h['rank_kernel_ms']), 'all': h['rank_kernel_ms']},
         'kernel_ms_spread': h['spread'],
@@ -647,6 +842,14 @@ def run(a):
                      'kernel_ms_spread': {'min': h['spread']['min'], 'max': h['spread']['max']},
                      'rocprofv3_committed': rocprof_of('k_rollout_masks_bench', bytes_per_launch) if B == (1 << 20) and T == 50 and not h['gather'] else None},
     }
+    # the job ran as described: one rank per GPU, every rank on a device of its own, every rank's figure present
+    if out['rccl_world_size'] != world or len(out['kernel_ms_per_rank']['all']) != world or len(rank_devices) != world:
+        raise RuntimeError('the process group holds %d ranks, %d kernel figures, %d device records for --gpus %d'
+                           % (out['rccl_world_size'], len(out['kernel_ms_per_rank']['all']), len(rank_devices), world))
+    if world > 1 and not a.single_device:
+        ids = [(d['uuid'] or d['pci_bus_id'] or d['device']) for d in rank_devices]
+        if len(set(ids)) != world:
+            raise RuntimeError('ranks share a GPU: %s' % ids)
     if h['probe'] is not None:
         out['row_stride_probe'] = h['probe']
     # (not under a profiler: its preloaded library would ride along into the child process)
@@ -654,6 +857,12 @@ def run(a):
     if rank == 0 and world == 1 and not a.no_box_state and not profiled:
         out['box_state_under_load'] = box_state_under_load(cx, h)
 
+    if rank == 0 and world == 1 and not a.no_sharded:
+        try:
+            out['roofline_sharded'] = sharded_roofline(cx, h, a.steps, a.warmup)
+        except Exception as e:  # noqa: BLE001
+            traceback.print_exc()
+            out['roofline_sharded'] = {'error': repr(e)[:300]}
     if rank == 0 and world == 1 and not a.no_extras:
         out['extra'] = extras(torch, bpg, _lib, h['env'], h['masks'][0], h['reward'][0], h['flags'][0], B, T, dev, stream)
         # SURVEY 8(d)'s per-step accounting (25 B/env-step: state read+written every step) for the
@@ -673,23 +882,24 @@ def run(a):
     # BASELINE configs[3] as written, as a second timed leg of the same run whenever the job has a collective path
     # (N > 1, or the one-rank RCCL rehearsal): 4 194 304 envs in total sharded over the ranks, every env's episode return
     # all-gathered once per rollout.  The headline above stays the weak-scaling figure the driver's scaling curve needs.
-    if multi and not a.no_config3 and not (h['gather'] and total == a.config3_total and R == 1):
-        del h
-        torch.cuda.empty_cache()
-        c_lo, c_hi = D.shard_range(a.config3_total, rank, world)
-        c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50))
-        cb = c['B'] * (T * 9 + 16)
-        out.setdefault('extra', {})['config3_as_written'] = {
-            'workload': '%s, %d envs in total = %d per GPU x %d GPUs, T=%d fused rollout per step, every env\'s episode return '
-                        '(f32, written by the rollout launch) all-gathered into global env order once per rollout'
-                        % (ENV_ID, c['total'], c['B'], world, T),
+    def config3_record(c, note):
+        cb = c['B'] * (T * 9 + 12 + c['wire_bytes_per_env'])
+        return {
+            'workload': '%s, %d envs in total = %d per GPU x %d GPUs, T=%d fused rollout per step, every env\'s episode %s '
+                        '(written by the rollout launch) all-gathered into global env order once per rollout%s'
+                        % (ENV_ID, c['total'], c['B'], world, T, 'fail count (u8)' if c['wire_bytes_per_env'] == 1 else 'return (f32)',
+                           ', expanded to the f32 returns on the device' if c['wire_bytes_per_env'] == 1 else ''),
+            'collectives_issued_by': note,
             'value': c['total'] * T * c['steps'] / c['dt'], 'unit': 'env-steps/s', 'scaling': 'strong',
             'steps': c['steps'], 'warmup': c['warmup'], 'ms_per_step': c['dt'] / c['steps'] * 1e3,
+            'wall_ms_per_step_incl_sync_and_barrier': c['wall_dt'] / c['steps'] * 1e3,
+            'span_ms_per_rank': c['rank_span_ms'],
             'host_enqueue_ms_per_step': c['host_dt'] / c['steps'] * 1e3,
             'total_envs': c['total'], 'envs_per_gpu': c['B'], 'row_stride_elements': c['LD'], 'buffer_sets': c['NBUF'],
             'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(),
             'collective': 'allgather', 'rollouts_per_collective': 1, 'collectives_issued': c['collectives'],
-            'sent_bytes_per_rank_per_rollout': 4 * c['B'], 'gathered_bytes_per_rollout': 4 * c['total'],
+            'sent_bytes_per_rank_per_rollout': c['wire_bytes_per_env'] * c['B'],
+            'gathered_bytes_per_rollout': c['wire_bytes_per_env'] * c['total'],
             'gathered_return_checksum': c['checksum'], 'success_rate': c['succ_rate'],
             'stream_ms_per_rollout_incl_collective_waits': c['kernel_ms'],
             'kernel_ms_no_collective': c['spread']['later_groups'],
@@ -697,7 +907,40 @@ def run(a):
             'roofline_kernel_only': {'bound': 'hbm', 'bytes_per_launch': cb, 'kernel_ms': min(c['spread']['later_groups']),
                                      'frac': cb / (min(c['spread']['later_groups']) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+
+    if multi and not a.no_config3 and not (h['gather'] and total == a.config3_total and R == 1):
+        del h
+        torch.cuda.empty_cache()
+        c_lo, c_hi = D.shard_range(a.config3_total, rank, world)
+        c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50),
+                        impl=a.collective_impl, gather_dtype=a.gather_dtype)
+        out.setdefault('extra', {})['config3_as_written'] = config3_record(
+            c, 'torch.distributed (RCCL on its own stream, asynchronous)' if a.collective_impl == 'torch'
+            else 'libbpgym.so (ncclAllGather on the launch stream)')
         del c
+        # The same leg with the collectives issued by the OTHER implementation, for the comparison on hardware.  The library's
+        # communicator is created here for the first time (ncclCommInitRank over the ranks): should that never return, a
+        # watchdog prints the result line without this leg and ends the process -- on every rank alike.
+        if not a.no_cabi_leg and a.collective_impl == 'torch':
+            import threading
+            done = threading.Event()
+
+            def give_up():
+                if not done.wait(a.cabi_leg_timeout):
+                    out['extra']['config3_cabi_collectives'] = {'error': 'no result within %.0f s (given up by the watchdog)' % a.cabi_leg_timeout}
+                    if rank == 0:
+                        emit(out)
+                    os._exit(0 if rank == 0 else 3)
+            threading.Thread(target=give_up, daemon=True).start()
+            try:
+                torch.cuda.empty_cache()
+                c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50),
+                                impl='cabi', gather_dtype=a.gather_dtype)
+                out['extra']['config3_cabi_collectives'] = config3_record(c, 'libbpgym.so (ncclAllGather on the launch stream)')
+                del c
+            except Exception as e:  # noqa: BLE001
+                out['extra']['config3_cabi_collectives'] = {'error': repr(e)[:300]}
+            done.set()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(T, a.cpu_seconds)
     if multi:

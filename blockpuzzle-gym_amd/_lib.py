@@ -45,6 +45,7 @@ class RolloutArgs(C.Structure):
         ('d_success_count', C.c_void_p), ('d_zero_count', C.c_void_p),
         ('ld_masks', C.c_int64), ('ld_out', C.c_int64),
         ('d_G', C.c_void_p), ('gamma', C.c_double), ('d_episode_return', C.c_void_p), ('d_episode_fail_count', C.c_void_p),
+        ('ld_rollouts', C.c_int64),
     ]
 
     def __init__(self, *args, **kw):
@@ -105,6 +106,8 @@ SIGNATURES = {
     'bpg_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_int,
                              C.c_uint64, C.c_int64]),
     'bpg_destroy': (C.c_int, [C.c_void_p]),
+    'bpg_create_view': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64]),
+    'bpg_advance_generator': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     'bpg_num_envs': (C.c_int64, [C.c_void_p]),
     'bpg_seed': (C.c_int, [C.c_void_p, C.c_uint64]),
     'bpg_set_id2obj': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int8), C.c_int]),

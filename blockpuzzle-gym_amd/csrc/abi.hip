@@ -206,6 +206,7 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     b->d_count_shards = nullptr;
     b->d_okbits = nullptr;
     b->cur = initial_curriculum(variant);
+    b->parent = nullptr;
     std::memset(b->ngeom, 0, sizeof(b->ngeom));
     const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
     hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
@@ -231,10 +232,57 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     return BPG_OK;
 }
 
+int bpg_create_view(bpg_batch **out, bpg_batch *parent, int64_t first_env, int64_t n_envs)
+{
+    if (!out) return fail(BPG_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!parent) return fail(BPG_ERR_ARG, "parent is NULL");
+    if (parent->parent) return fail(BPG_ERR_ARG, "views of views are not supported: take the view of the parent");
+    if (first_env < 0 || n_envs < 1 || first_env + n_envs > parent->n) return fail(BPG_ERR_ARG, "the view's range is not inside the parent");
+    if (first_env % 4 != 0) return fail(BPG_ERR_ARG, "first_env must be a multiple of 4 (16-byte aligned state slices)");
+    DeviceGuard guard(parent->device);
+    bpg_batch *b = new (std::nothrow) bpg_batch(*parent);
+    if (!b) return fail(BPG_ERR_ARG, "out of host memory");
+    b->parent = parent;
+    b->n = n_envs;
+    b->env_base = parent->env_base + first_env;
+    b->now = parent->now + first_env;
+    b->ever = parent->ever + first_env;
+    b->d_okbits = nullptr;
+    b->d_count_shards = nullptr;
+    const size_t shard_bytes = (size_t)COUNT_SHARDS * COUNT_SHARD_STRIDE * sizeof(unsigned long long);
+    if (hipMalloc(&b->d_count_shards, shard_bytes) != hipSuccess || hipMemset(b->d_count_shards, 0, shard_bytes) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        if (b->d_count_shards) (void)hipFree(b->d_count_shards);
+        delete b;
+        return fail(BPG_ERR_HIP, "hipMalloc failed for the view's scratch");
+    }
+    *out = b;
+    return BPG_OK;
+}
+
+int bpg_advance_generator(bpg_batch *b, uint32_t resets, uint32_t placements, void *stream)
+{
+    if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (b->parent) return fail(BPG_ERR_ARG, "the generator's stream indices belong to the parent handle");
+    DeviceGuard guard(b->device);
+    if (resets)
+        if (int rc = enqueue_bump_counter(b->d_reset_counter, resets, (hipStream_t)stream)) return rc;
+    if (placements)
+        if (int rc = enqueue_bump_counter(b->d_reset_counter + 1, placements, (hipStream_t)stream)) return rc;
+    return BPG_OK;
+}
+
 int bpg_destroy(bpg_batch *b)
 {
     if (!b) return BPG_OK;
     DeviceGuard guard(b->device);
+    if (b->parent) {                       // a view owns its scratch only
+        if (b->d_count_shards) (void)hipFree(b->d_count_shards);
+        if (b->d_okbits) (void)hipFree(b->d_okbits);
+        delete b;
+        return BPG_OK;
+    }
     if (b->now) (void)hipFree(b->now);
     if (b->ever) (void)hipFree(b->ever);
     if (b->d_id2obj) (void)hipFree(b->d_id2obj);
@@ -250,6 +298,7 @@ int64_t bpg_num_envs(const bpg_batch *b) { return b ? b->n : 0; }
 int bpg_seed(bpg_batch *b, uint64_t seed)
 {
     if (!b) return fail(BPG_ERR_ARG, "handle is NULL");
+    if (b->parent) return fail(BPG_ERR_ARG, "bpg_seed: a view shares its parent's seed -- seed the parent");
     DeviceGuard guard(b->device);
     // Synchronous by contract: launches in flight on ANY stream (torch side streams do not order
     // against the null stream) still read the old key and stream indices.
@@ -263,6 +312,7 @@ int bpg_seed(bpg_batch *b, uint64_t seed)
 int bpg_set_id2obj(bpg_batch *b, int model_idx, const int8_t *id2obj, int ngeom)
 {
     if (!b || !id2obj) return fail(BPG_ERR_ARG, "NULL argument");
+    if (b->parent) return fail(BPG_ERR_ARG, "bpg_set_id2obj: a view shares its parent's tables -- set them on the parent");
     if (model_idx < 0 || model_idx >= BPG_MAX_MODELS) return fail(BPG_ERR_ARG, "model_idx out of range");
     if (ngeom < 1 || ngeom > BPG_MAX_GEOMS) return fail(BPG_ERR_ARG, "ngeom must be in 1..64");
     int8_t tab[BPG_MAX_GEOMS];
@@ -341,18 +391,18 @@ int bpg_rollout(void)
 int bpg_get_curriculum(const bpg_batch *b, bpg_curriculum *out)
 {
     if (!b || !out) return fail(BPG_ERR_ARG, "NULL argument");
-    *out = b->cur;
+    *out = root_of(b)->cur;
     return BPG_OK;
 }
 
 int bpg_set_curriculum(bpg_batch *b, const bpg_curriculum *in)
 {
     if (!b || !in) return fail(BPG_ERR_ARG, "NULL argument");
-    b->cur = *in;
+    root_of(b)->cur = *in;
     return BPG_OK;
 }
 
-int bpg_get_difficulty(const bpg_batch *b) { return b ? b->cur.difficulty : 0; }   // fetch_env.py:96-97
+int bpg_get_difficulty(const bpg_batch *b) { return b ? root_of(b)->cur.difficulty : 0; }   // fetch_env.py:96-97
 
 int bpg_increase_difficulty(bpg_batch *b, int *at_max)
 {
@@ -361,7 +411,7 @@ int bpg_increase_difficulty(bpg_batch *b, int *at_max)
     const int v = b->info.variant;
     if (b->info.increase_difficulty_status == BPG_ERR_UNSUPPORTED)
         return fail(BPG_ERR_UNSUPPORTED, "increase_difficulty: NotImplementedError (fetch_env.py:93-94)");
-    bpg_curriculum &c = b->cur;
+    bpg_curriculum &c = root_of(b)->cur;
     if (!c.has_step)                                   // `self.obj_range += self.obj_range_step` raises before anything changes
         return fail(BPG_ERR_ATTRIBUTE, "increase_difficulty: the preset has no obj_range_step (AttributeError, fetch_env.py:413-420)");
     bool top = false;
@@ -396,11 +446,11 @@ int bpg_placement_from_curriculum(const bpg_batch *b, int test, bpg_placement_ar
     if (!b || !out) return fail(BPG_ERR_ARG, "NULL argument");
     if (test && !b->info.set_test_supported)
         return fail(BPG_ERR_UNSUPPORTED, "set_test: NotImplementedError (fetch_env.py:100-101)");
-    out->obj_range = b->cur.obj_range;
-    out->max_obj_range = b->cur.max_obj_range;
-    out->wrong_obj_range = b->cur.wrong_obj_range;
+    out->obj_range = root_of(b)->cur.obj_range;
+    out->max_obj_range = root_of(b)->cur.max_obj_range;
+    out->wrong_obj_range = root_of(b)->cur.wrong_obj_range;
     out->test = test ? 1 : 0;
-    out->challenge = b->cur.challenge;
+    out->challenge = root_of(b)->cur.challenge;
     return BPG_OK;
 }
 

@@ -722,8 +722,8 @@ int bpg_reset_obs(bpg_batch *b, const int32_t *d_num_grey, const uint8_t *d_env_
                        b->now, b->ever, b->n, reset_const(b, 1, d_num_grey), d_env_mask,
                        static_obs(b, d_obs, ld, true, d_env_mask));
     if (int rc = check_launch("k_reset")) return rc;
-    if (b->info.is_variation && !d_num_grey)     // only generator-drawn resets consume a stream index
-        return enqueue_bump_counter(b->d_reset_counter, 1u, (hipStream_t)stream);
+    if (b->info.is_variation && !d_num_grey && !b->parent)     // only generator-drawn resets consume a stream index
+        return enqueue_bump_counter(b->d_reset_counter, 1u, (hipStream_t)stream);     // (views: bpg_advance_generator on the parent)
     return BPG_OK;
 }
 
@@ -889,7 +889,7 @@ int bpg_randomize_objects(bpg_batch *b, const bpg_placement_args *a, double *d_x
     hipLaunchKernelGGL(k_randomize_objects, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        b->n, pc, d_xy, d_status);
     if (int rc = check_launch("k_randomize_objects")) return rc;
-    if (!explicit_draws) return enqueue_bump_counter(b->d_reset_counter + 1, 1u, (hipStream_t)stream);
+    if (!explicit_draws && !b->parent) return enqueue_bump_counter(b->d_reset_counter + 1, 1u, (hipStream_t)stream);
     return BPG_OK;
 }
 

@@ -43,7 +43,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
           uint32_t *__restrict__ reward_all, uint8_t *__restrict__ flags_all, int64_t n, int T,
           int64_t ld_masks, int64_t ld_out,
           StepConst c, SynthArg<SRC> s, ResetArg<MODE> rc, CountArgs ca, uint64_t *__restrict__ okbits, int rollouts,
-          uint32_t *__restrict__ ep_return_all, uint8_t *__restrict__ ep_fail_all)
+          uint32_t *__restrict__ ep_return_all, uint8_t *__restrict__ ep_fail_all, int64_t ld_env)
 {
     constexpr bool RESET = MODE != MODE_CONT, MULTI = MODE == MODE_MULTI, OKB = AUX == AUX_OKB, RET = AUX == AUX_RET;
     constexpr bool NT = true, NTL = true;       // write-once streams leave nontemporal, the read-once mask stream arrives so
@@ -61,8 +61,9 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     const uint32_t *__restrict__ masks = masks_all + (MULTI ? (int64_t)ro * T * ld_masks : 0);
     uint32_t *__restrict__ reward_tb = reward_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
     uint8_t *__restrict__ flags_tb = flags_all + (MULTI ? (int64_t)ro * T * ld_out : 0);
-    uint32_t *__restrict__ ep_return = ep_return_all ? ep_return_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
-    uint8_t *__restrict__ ep_fail = ep_fail_all ? ep_fail_all + (MULTI ? (int64_t)ro * n : 0) : nullptr;
+    // rollout ro of a MULTI launch owns row ro of the (rollouts, ld_env) per-env arrays (ld_env = n unless the caller says otherwise)
+    uint32_t *__restrict__ ep_return = ep_return_all ? ep_return_all + (MULTI ? (int64_t)ro * ld_env : 0) : nullptr;
+    uint8_t *__restrict__ ep_fail = ep_fail_all ? ep_fail_all + (MULTI ? (int64_t)ro * ld_env : 0) : nullptr;
     uint32_t nsucc = 0;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         uint32_t an[EPL] = {}, ee[EPL] = {};
@@ -89,7 +90,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
         uint32_t nok[EPL] = {};
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
-            if constexpr (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * n : 0);
+            if constexpr (RESET) reset_core(an[k], ee[k], EPL * v + k, rc, MULTI ? (uint32_t)ro : 0u, MULTI ? (int64_t)ro * ld_env : 0);
             if constexpr (SRC == SRC_SYNTH) sl[k] = synth_lane(s, (uint32_t)(EPL * v + k), nobj_of(ee[k]));
             cm[k] = an[k] & PAIR_BITS;
             el[k] = RESET ? 0u : (an[k] >> ELAPSED_SHIFT) & ELAPSED_MAX;
@@ -279,13 +280,13 @@ constexpr int64_t ROLLOUT_UNROLL5_FROM = 81920, ROLLOUT_EPL2_FROM = 229376;
 struct RolloutGeometry { int epl, block, grid, unroll; bool pipe; };
 
 RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, const void *masks, const void *reward,
-                                 const void *flags, const void *ep_return = nullptr, const void *ep_fail = nullptr)
+                                 const void *flags, const void *ep_return = nullptr, const void *ep_fail = nullptr, int64_t ld_env = 0)
 {
     // 2 envs per lane need an even batch, even row strides and 8-byte aligned mask / reward streams
     // (2-byte flags)
     const bool ok2 = n % 2 == 0 && ld_masks % 2 == 0 && ld_out % 2 == 0 && ((uintptr_t)masks & 7u) == 0 &&
                      ((uintptr_t)reward & 7u) == 0 && ((uintptr_t)flags & 1u) == 0 && ((uintptr_t)ep_return & 7u) == 0 &&
-                     ((uintptr_t)ep_fail & 1u) == 0;
+                     ((uintptr_t)ep_fail & 1u) == 0 && ld_env % 2 == 0;
     RolloutGeometry g;
     g.unroll = 5;
     if (ok2 && n >= 131072 && !masks) {
@@ -358,6 +359,7 @@ struct RolloutLaunch {                 // everything a k_rollout launch takes, w
     uint64_t *okbits;
     uint32_t *ep_return;
     uint8_t *ep_fail;
+    int64_t ld_env;
 };
 using RolloutLauncher = void (*)(const RolloutLaunch &);
 
@@ -369,7 +371,7 @@ template <class SH, int OUT, int MODE, int AUX> void launch_rollout_as(const Rol
     if constexpr (MODE != MODE_CONT) rc = l.rc;
     hipLaunchKernelGGL((k_rollout<SH::SRC, SH::EPL, OUT, MODE, SH::UNROLL, SH::PIPE, SH::LB, AUX>), l.grid, l.block, 0, l.st,
                        l.now, l.ever, l.masks, l.reward, l.flags, l.n, l.T, l.ldm, l.ldo, l.c, s, rc, l.ca, l.okbits, l.rollouts,
-                       l.ep_return, l.ep_fail);
+                       l.ep_return, l.ep_fail, l.ld_env);
 }
 
 constexpr int N_OUT = 4, N_MODE = 3, N_AUX = 3, N_FORMS = N_OUT * N_MODE * N_AUX;
@@ -443,6 +445,7 @@ int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     }
     if (a->d_episode_return && ((uintptr_t)a->d_episode_return & 3u) != 0)
         return fail(BPG_ERR_ARG, "d_episode_return must be 4-byte aligned");
+    if (a->ld_rollouts && a->ld_rollouts < b->n) return fail(BPG_ERR_ARG, "ld_rollouts must be 0 or >= n_envs");
     if (a->d_episode_fail_count && a->T > 255) return fail(BPG_ERR_ARG, "d_episode_fail_count is one byte per env: T <= 255");
     if (gmode == G_OKBITS && !b->d_okbits) {
         // the step-ok words are handle-owned scratch, allocated by the first call that asks for d_G: a hipMalloc is not
@@ -464,7 +467,7 @@ int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     if (!episode) {
         const int out = (rw ? OUT_REWARD : 0) | (a->d_flags_tb ? OUT_FLAGS : 0);
         const RolloutGeometry geo = rollout_geometry(b->n, ldm, ldo, a->d_masks, a->d_reward_tb, a->d_flags_tb,
-                                                     a->d_episode_return, a->d_episode_fail_count);
+                                                     a->d_episode_return, a->d_episode_fail_count, a->ld_rollouts);
         const bool per_env = a->d_episode_return || a->d_episode_fail_count;
         const int mode = rollouts > 1 ? MODE_MULTI : (a->reset_first ? MODE_RESET : MODE_CONT);
         // the in-loop counter only where a per-env count is asked for and there is no step-ok word to take it from
@@ -475,6 +478,7 @@ int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
         l.n = b->n; l.ldm = ldm; l.ldo = ldo; l.T = a->T; l.rollouts = rollouts;
         l.c = c; l.s = s; l.rc = rc; l.ca = ca; l.okbits = okbits;
         l.ep_return = reinterpret_cast<uint32_t *>(a->d_episode_return); l.ep_fail = a->d_episode_fail_count;
+        l.ld_env = a->ld_rollouts ? a->ld_rollouts : b->n;
         RolloutLauncher fn = rollout_launcher(geo, a->d_masks == nullptr, out, mode, aux);
         if (!fn) return fail(BPG_ERR_ARG, "rollouts > 1 takes no d_G");
         fn(l);
@@ -493,7 +497,7 @@ int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     if (rcode == BPG_OK && gmode == G_OKBITS) rcode = launch_returns_from_okbits(b->d_okbits, a->d_G, b->n, a->T, a->gamma, st);
     if (rcode == BPG_OK && gmode == G_FROM_REWARD)
         rcode = bpg_discounted_return_ld(a->d_reward_tb, b->n, ldo, a->T, a->gamma, a->d_G, b->device, stream);
-    if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey) {
+    if (rcode == BPG_OK && a->reset_first && b->info.is_variation && !a->d_num_grey && !b->parent) {
         rcode = enqueue_bump_counter(b->d_reset_counter, (uint32_t)rollouts, st);
     }
     return rcode;

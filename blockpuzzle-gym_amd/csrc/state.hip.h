@@ -93,7 +93,12 @@ struct bpg_batch {
     uint64_t *d_okbits;                   // n words: the step-ok bits of the last rollout that asked for G; allocated by
                                           // bpg_reserve_return_scratch or the first bpg_rollout_v2 call with d_G (NULL until then)
     bpg_curriculum cur;                   // difficulty + placement ranges (fetch_env.py:340-348, :404-417, :561-563)
+    bpg_batch *parent;                    // a view (bpg_create_view): the handle whose envs these are; NULL for a batch of its own
 };
+
+// what a view shares with its parent and never copies: seed, id2obj tables, curriculum
+inline const bpg_batch *root_of(const bpg_batch *b) { return b->parent ? b->parent : b; }
+inline bpg_batch *root_of(bpg_batch *b) { return b->parent ? b->parent : b; }
 
 namespace bpgk {   // kernels + launch helpers (named so profiles read bpgk::k_*)
 
@@ -585,7 +590,7 @@ inline PowTable pow_table(double gamma, int T)
 inline SynthConst synth_const(const bpg_batch *b)
 {
     SynthConst s;
-    s.seed0 = b->seed + 1000ull * (uint64_t)b->env_base;        // rollout.py:209-210 on the global env index
+    s.seed0 = root_of(b)->seed + 1000ull * (uint64_t)b->env_base;        // rollout.py:209-210 on the global env index
     for (int n = 0; n < 8; n++) {
         uint32_t valid = 0, forced = 0;
         const int m = n > BPG_MAX_OBJS ? BPG_MAX_OBJS : n;

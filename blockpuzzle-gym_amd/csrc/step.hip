@@ -346,7 +346,7 @@ int bpg_step_contacts(bpg_batch *b, const int16_t *d_contacts, const int32_t *d_
     if (!aligned4(d_contacts) || !aligned4(d_reward)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
     const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
     for (int m = 0; m < models; m++)
-        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+        if (root_of(b)->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
     const dim3 grid(grid_for(b->n, 256, 4096)), block(256);
     if (maxcon % 4 == 0 && aligned16(d_contacts))
@@ -379,7 +379,7 @@ int bpg_contacts_to_masks(bpg_batch *b, const int16_t *d_contacts, const int32_t
     if (!aligned4(d_contacts) || !aligned4(d_masks)) return fail(BPG_ERR_ARG, "pointers must be 4-byte aligned");
     const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
     for (int m = 0; m < models; m++)
-        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+        if (root_of(b)->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
     return launch_contacts_to_masks(b, d_contacts, d_ncon, maxcon, d_masks, 1, b->n, nullptr, (hipStream_t)stream);
 }
@@ -399,7 +399,7 @@ int bpg_contacts_to_masks_tb(bpg_batch *b, const int16_t *d_contacts, const int3
         return fail(BPG_ERR_ARG, "n_envs * T * maxcon is too large");
     const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
     for (int m = 0; m < models; m++)
-        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+        if (root_of(b)->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
     return launch_contacts_to_masks(b, d_contacts, d_ncon, maxcon, d_masks, T, ld, d_num_grey, (hipStream_t)stream);
 }
@@ -413,7 +413,7 @@ int bpg_contacts_csr_to_masks(bpg_batch *b, const int16_t *d_pairs, const int64_
         return fail(BPG_ERR_ARG, "pairs / masks must be 4-byte, offsets 8-byte aligned");
     const int models = b->info.is_variation ? BPG_MAX_MODELS : 1;
     for (int m = 0; m < models; m++)
-        if (b->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
+        if (root_of(b)->ngeom[m] == 0) return fail(BPG_ERR_ARG, "id2obj table not set (bpg_set_id2obj)");
     DeviceGuard guard(b->device);
     hipLaunchKernelGGL(k_contacts_csr_to_masks, dim3(grid_for(b->n, 256)), dim3(256), 0, (hipStream_t)stream, b->ever,
                        reinterpret_cast<const uint32_t *>(d_pairs), d_offsets, total, b->d_id2obj, b->info.is_variation,

@@ -85,6 +85,59 @@ def discounted_return_scan(reward_tb, gamma, out=None):
     return out
 
 
+SHARD_ENVS = 262144           # envs per stream shard of the fused workers: the size whose 256-lane launches share CUs well
+SHARD_FROM = 524288           # batches from this size on are split (below, one launch is as fast or faster)
+MAX_SHARDS = 16
+
+
+def auto_shards(num_envs):
+    """How many stream shards the fused workers split a batch of `num_envs` envs into by default (0.73-0.76 of
+    the HBM peak against 0.67-0.70 for one launch at 1 M envs; nothing to gain below 524 288)."""
+    if num_envs < SHARD_FROM:
+        return 1
+    return max(1, min(MAX_SHARDS, num_envs // SHARD_ENVS))
+
+
+class _ViewShards:
+    """S views of one env batch (bpg_create_view: contiguous env ranges that share the batch's packed state and own their
+    launch scratch), a stream each: the fused workers launch one shard per stream side by side -- the partition that spreads
+    a job over GPUs (distributed.make_sharded), once more inside a GPU.  fork() / join() order the shard streams against the
+    current stream (stream-level waits); nothing else synchronises."""
+
+    def __init__(self, env, S):
+        B, L = env.num_envs, _lib.lib()
+        per = (B // S) // 4 * 4                   # shard boundaries on multiples of 4 envs: 16-byte aligned state slices
+        if per < 4:
+            raise ValueError('%d envs are too few for %d shards' % (B, S))
+        self.env, self.views = env, []
+        for i in range(S):
+            lo = i * per
+            n = (B - lo) if i == S - 1 else per
+            h = C.c_void_p()
+            _lib.check(L.bpg_create_view(C.byref(h), env._h, lo, n))
+            self.views.append((h, torch.cuda.Stream(env.device), lo, n))
+
+    def __len__(self):
+        return len(self.views)
+
+    def fork(self):
+        cur = torch.cuda.current_stream(self.env.device)
+        for _, st, _, _ in self.views:
+            st.wait_stream(cur)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.env.device)
+        for _, st, _, _ in self.views:
+            cur.wait_stream(st)
+
+    def close(self):
+        views, self.views = self.views, []
+        for h, _, _, _ in views:
+            _lib.lib().bpg_destroy(h)
+
+    __del__ = close
+
+
 class _TotalSnapshot:
     """The worker's running total of successful envs as it stands behind everything enqueued so far, copied to pinned host
     memory asynchronously; value() waits for that copy only."""
@@ -205,6 +258,7 @@ class RolloutStudent:
         # fused launch) adds the rollout's count, _finish reads the total once and takes the difference -- no launch of
         # its own for `successful = successes[-1]` (rollout.py:163-167), nothing to zero between rollouts (hipGraph
         # replays included)
+        self._view_shards = {}               # S -> _ViewShards of self.env (created on first use)
         self._succ_total = torch.zeros(1, dtype=torch.int64, device=env.device)
         self._succ_seen = 0                  # the total before the next rollout: an int, or a _TotalSnapshot not read yet
         self._pinned = torch.empty(max(2 * history_len, 64), dtype=torch.int64).pin_memory() if self.async_stats else None
@@ -215,6 +269,15 @@ class RolloutStudent:
         self.initial_ag = torch.empty((B, dims['g']), **f32)
         self.reset_all_rollouts()
         self.clear_history()
+
+    def _shards_for(self, shards):
+        """shards=None: auto_shards(B); an int: that many (1 = one launch on the current stream).  Returns None for 1."""
+        S = auto_shards(self.rollout_batch_size) if shards is None else int(shards)
+        if S <= 1:
+            return None
+        if S not in self._view_shards:
+            self._view_shards[S] = _ViewShards(self.env, S)
+        return self._view_shards[S]
 
     # -- rollout.py:47-64 -------------------------------------------------
     def reset_all_rollouts(self, test=False, num_grey=None, observation_out=None, achieved_goal_out=None):
@@ -535,7 +598,7 @@ class RolloutStudent:
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None,
                                 want_reward=False, materialize_constants=False, gamma=None, episode_return=False,
-                                episode_fail_count=False):
+                                episode_fail_count=False, shards=1):
         """Whole rollout in ONE kernel launch (no policy between steps): contacts
         come from `masks` (T, B) int32/uint32 device tensor, or the synthetic
         source when None.  Same episode dict as generate_rollouts; `o` is the
@@ -551,7 +614,11 @@ class RolloutStudent:
         all-gathers, distributed.all_gather_per_env), from a counter of the same launch.
         episode_fail_count: also `episode_fail_count` (B,) uint8, the same quantity as one byte per env (the number of steps
         whose success condition did not hold; episode_return == -episode_fail_count bit for bit, T <= 255): the form a
-        multi-GPU job puts on the wire (a quarter of the bytes; distributed.episode_return_from_fail_count expands it)."""
+        multi-GPU job puts on the wire (a quarter of the bytes; distributed.episode_return_from_fail_count expands it).
+        shards: S > 1 runs the batch as S contiguous env ranges on S streams (views of the env, one launch each, joined
+        before this returns; None = auto_shards(B)): every output is the same array either way.  Default 1: the launch that
+        writes the episode arrays is bound by its 15 KB of float32 output per env and runs at 0.8 of the HBM peak as one
+        launch -- measured, sharding it gains nothing; evaluate_rollouts_fused, the stream path, shards by default."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
@@ -583,7 +650,30 @@ class RolloutStudent:
             assert masks.shape == (T, B) and masks.stride(1) == 1 and masks.element_size() == 4 \
                 and (T == 1 or masks.stride(0) >= B)
             args.ld_masks = int(masks.stride(0)) if T > 1 else B
-        _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
+        vs = self._shards_for(shards)
+        if vs is None:
+            _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
+        else:
+            # env range [lo, lo + n) of every array: time-major streams are column ranges (same row stride), batch-major
+            # arrays contiguous row ranges
+            dg = self.dims['g']
+            per_env_bytes = dict(d_masks=4, d_reward_tb=4, d_ep_ag=4 * (T + 1) * dg, d_ep_g=4 * T * dg, d_ep_success=4 * T,
+                                 d_G=8 * T, d_episode_return=4, d_episode_fail_count=1)
+            if args.ld_out == 0 and reward is not None:
+                args.ld_out = B
+            if masks is not None and args.ld_masks == 0:
+                args.ld_masks = B
+            vs.fork()
+            for h, st, lo, n in vs.views:
+                a = _lib.RolloutArgs.from_buffer_copy(args)
+                for name, nbytes in per_env_bytes.items():
+                    base = getattr(args, name)
+                    if base:
+                        setattr(a, name, base + lo * nbytes)
+                if G is not None:
+                    _lib.check(_lib.lib().bpg_reserve_return_scratch(h))
+                _lib.check(_lib.lib().bpg_rollout_v2(h, C.byref(a), C.c_void_p(st.cuda_stream)))
+            vs.join()
         out = self._finish(ep, counted=True)
         if want_reward:
             out['reward_tb'] = reward if self.output == 'torch' else reward.cpu().numpy()
@@ -596,7 +686,7 @@ class RolloutStudent:
         return out
 
     def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
-                                flags_tb=None, episode_return=None):
+                                flags_tb=None, episode_return=None, episode_fail_count=None, shards=None):
         """The evaluator's test loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)`
         (train.py:63-64, play.py:59) -- with the contacts of all K rollouts read from one stream, in ONE
         launch: rollout r is reset + T steps on rows r*T .. r*T+T-1 of `masks` ((K*T, B) int32 device
@@ -605,7 +695,13 @@ class RolloutStudent:
         drops it.  num_grey: (K, B) explicit draws for BlocksTouchVariation, or None for the env's
         generator (its next K draws).  reward_tb / flags_tb: optional (K*T, B) float32 / uint8 streams
         the launch fills (step reward; bit 0 is_success, bit 1 done); episode_return: optional (K, B) float32
-        the launch fills with every env's undiscounted return of each rollout.  Returns the K success rates."""
+        the launch fills with every env's undiscounted return of each rollout; episode_fail_count: optional (K, B) uint8, the
+        same as one byte per env (T <= 255).  Returns the K success rates.
+        shards: from 524 288 envs on the batch runs as auto_shards(B) contiguous env ranges of about 262 144 envs, each ONE
+        launch (its K rollouts) on a stream of its own, joined before this returns -- the launches of different shards overlap,
+        so the ramp-up and drain of one are covered by the others (0.73-0.76 of the HBM peak against 0.67-0.70 at 1 M envs,
+        DESIGN.md).  Every array is the caller's own (the shards read and write column ranges of them), every result bit is
+        the one launch's.  shards=1: one launch on the current stream."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         assert masks.dim() == 2 and masks.shape[1] == B and masks.shape[0] % T == 0 and masks.element_size() == 4 \
             and masks.stride(1) == 1 and masks.is_cuda
@@ -630,16 +726,37 @@ class RolloutStudent:
         # (set_test only re-places the cubes, rollout.py:53-55: with the contacts read from the stream the
         # placement has no reader, so nothing is placed here)
         counts = torch.zeros(K, dtype=torch.int64, device=self.device)
-        if episode_return is not None:
-            assert episode_return.shape == (K, B) and episode_return.dtype == torch.float32 \
-                and episode_return.is_contiguous() and episode_return.is_cuda
+        for x, dt in ((episode_return, torch.float32), (episode_fail_count, torch.uint8)):
+            if x is not None:
+                assert x.shape == (K, B) and x.dtype == dt and x.is_contiguous() and x.is_cuda
         args = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld_out,
                                 d_episode_return=None if episode_return is None else episode_return.data_ptr(),
+                                d_episode_fail_count=None if episode_fail_count is None else episode_fail_count.data_ptr(),
                                 d_num_grey=None if ng is None else ng.data_ptr(),
                                 d_reward_tb=None if reward_tb is None else reward_tb.data_ptr(),
                                 d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
                                 d_success_count=counts.data_ptr())
-        _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
+        vs = self._shards_for(shards)
+        if vs is None:
+            _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
+        else:
+            # every shard: its column range of the (K*T, ld) streams and of the (K, B) per-env arrays (row stride B), its K
+            # rollouts in ONE launch on its own stream; the K success counts are shared words (atomic adds)
+            per_env_bytes = dict(d_masks=4, d_reward_tb=4, d_flags_tb=1, d_num_grey=4, d_episode_return=4, d_episode_fail_count=1)
+            args.ld_rollouts = B
+            if ld_out == 0:
+                args.ld_out = B
+            vs.fork()
+            for h, st, lo, n in vs.views:
+                a = _lib.RolloutArgs.from_buffer_copy(args)
+                for name, nbytes in per_env_bytes.items():
+                    base = getattr(args, name)
+                    if base:
+                        setattr(a, name, base + lo * nbytes)
+                _lib.check(_lib.lib().bpg_rollout_v2(h, C.byref(a), C.c_void_p(st.cuda_stream)))
+            vs.join()
+            if env.info.is_variation and ng is None:     # the views drew from the generator: its stream index moves once
+                _lib.check(_lib.lib().bpg_advance_generator(env._h, K, 0, _stream(self.device)))
         if env.info.is_variation:       # the K in-launch resets drew new block counts: the env's observation rows follow
             env._fill_static_observation()
         rates = [float(c) / B for c in counts.tolist()]
@@ -747,13 +864,13 @@ class PGRolloutStudent(RolloutStudent):
         return o_, g_, ag_
 
     def generate_rollouts_fused(self, test=False, masks=None, num_grey=None, actions=None, want_reward=False,
-                                materialize_constants=False, gamma=None, episode_return=False, episode_fail_count=False):
+                                materialize_constants=False, gamma=None, episode_return=False, episode_fail_count=False, shards=1):
         """The whole pg rollout in one call without a policy between the steps: the episode arrays and
         the return `G` for this worker's gamma (policy_gradient/rollout.py:255-258, :283-288)."""
         return super().generate_rollouts_fused(test=test, masks=masks, num_grey=num_grey, actions=actions,
                                                want_reward=want_reward, materialize_constants=materialize_constants,
                                                gamma=self.gamma if gamma is None else gamma, episode_return=episode_return,
-                                               episode_fail_count=episode_fail_count)
+                                               episode_fail_count=episode_fail_count, shards=shards)
 
     def generate_rollouts(self, render=False, test=False, exploit=False, num_grey=None, episode_return=False):
         """policy_gradient/rollout.py:174-290.  A backend failure is fatal here as in the reference

@@ -137,6 +137,19 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id,
                int max_episode_steps, uint64_t seed, int64_t env_id_base);
 int bpg_destroy(bpg_batch *b);
 int64_t bpg_num_envs(const bpg_batch *b);
+/* A handle over envs first_env .. first_env + n_envs - 1 of `parent` -- the same partition of the env index range that spreads a
+ * job over GPUs, applied inside one GPU: launches on views of disjoint ranges are independent and may run side by
+ * side on different streams (while one launch ramps up or drains the others stream).  A view SHARES the parent's
+ * packed state (its launches read and write the parent's arrays in place: whatever the views did is what the parent sees), its
+ * seed, id2obj tables, curriculum and generator stream indices, and OWNS the scratch a launch needs (success-count words,
+ * step-ok words).  Env e of the view is env first_env + e of the parent in every respect (generator keys included).
+ * first_env % 4 == 0.  bpg_seed / bpg_set_id2obj / the curriculum calls go to the parent; a generator-drawn reset through a view
+ * does not advance the generator's stream index -- call bpg_advance_generator on the parent once after the views' launches.
+ * Destroy the views before the parent. */
+int bpg_create_view(bpg_batch **out, bpg_batch *parent, int64_t first_env, int64_t n_envs);
+/* Advances the handle's generator stream indices (device words, stream-ordered): `resets` generator-drawn resets and
+ * `placements` generator-drawn placements have happened.  Only needed after launches through views. */
+int bpg_advance_generator(bpg_batch *b, uint32_t resets, uint32_t placements, void *stream);
 
 /* RobotEnv.seed (robot_env.py:53-55) / RolloutStudent.seed (rollout.py:206-210):
  * re-keys the counter-based generator (synthetic contacts, num_grey draw) and restarts its
@@ -423,6 +436,9 @@ typedef struct {
                                   T <= 255.  The array a multi-GPU job exchanges (all-gather): a quarter of
                                   the float32 form's bytes on the wire, expanded on the receiving side by
                                   bpg_episode_return_from_fail_count.  NULL = not produced */
+    int64_t ld_rollouts;       /* rollouts = K > 1: row stride in elements of the (K, n_envs) arrays d_num_grey, d_episode_return,
+                                  d_episode_fail_count -- 0 = n_envs; larger when the handle is a view (bpg_create_view) of a batch
+                                  whose (K, total) arrays it owns a column range of */
 } bpg_rollout_args;
 #define BPG_ROLLOUT_ARGS_MIN_SIZE 120u   /* everything up to and including gamma (low 16 bits of struct_size) */
 /* `bpg_rollout_args a = BPG_ROLLOUT_ARGS_INIT;` -- struct_size set, every other field zero (C and C++, no warnings under
@@ -435,7 +451,7 @@ static inline bpg_rollout_args bpgh_rollout_args_init(void)
     return a;
 }
 #define BPG_ROLLOUT_ARGS_INIT bpgh_rollout_args_init()
-#define BPG_ROLLOUT_ARGS_INIT_STATIC { BPG_ARGS_TAG(sizeof(bpg_rollout_args)), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0 }
+#define BPG_ROLLOUT_ARGS_INIT_STATIC { BPG_ARGS_TAG(sizeof(bpg_rollout_args)), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0 }
 int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 /* the round-3 entry point of that name took a struct without the size word: kept as a stub that returns BPG_ERR_UNSUPPORTED */
 int bpg_rollout(void);

@@ -133,9 +133,9 @@ def test_row_stride_helper_is_a_pure_host_function():
         assert n <= ld < n + 512 and ld % 256 == 0 and (ld // 256) % 2 == 1
     # the struct the header declares and the ctypes mirror agree on the new trailing fields
     a = _lib.RolloutArgs(T=1, ld_masks=7, ld_out=9)
-    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 16 + 9 * 8 + 16 + 16 + 8 + 8
+    assert (a.ld_masks, a.ld_out) == (7, 9) and C.sizeof(_lib.RolloutArgs) == 16 + 9 * 8 + 16 + 16 + 8 + 8 + 8
     # BPG_ROLLOUT_ARGS_INIT: the mirror fills in BPG_ARGS_TAG(its own size); the minimum the library accepts ends behind gamma
-    assert a.struct_size == _lib.args_tag(C.sizeof(_lib.RolloutArgs)) == 0xB5A90000 | 136
+    assert a.struct_size == _lib.args_tag(C.sizeof(_lib.RolloutArgs)) == 0xB5A90000 | 144
     assert _lib.RolloutArgs.gamma.offset + 8 == _lib.ROLLOUT_ARGS_MIN_SIZE == 120
     # the round-3 names survive as stubs: a stale caller gets an error code whatever it passes
     assert L.bpg_rollout() == _lib.ERR_UNSUPPORTED and b'bpg_rollout_v2' in L.bpg_last_error()

@@ -349,3 +349,85 @@ def test_return_scratch_is_reserved_up_front_and_all_gather_fills_out():
     assert bpg.distributed.all_gather_per_env(x, total_envs=7, out=out) is out and torch.equal(out, x)
     # the round-3 names are stubs now (a stale caller gets an error code, whatever it passes)
     assert L.bpg_step_record() == _lib.ERR_UNSUPPORTED and L.bpg_rollout() == _lib.ERR_UNSUPPORTED
+
+
+# --------------------------------------------------------------------------
+# the fused workers as stream shards (views of the batch) == one launch
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('env_id,B,S,explicit', [('BlocksTouchVariation-v0', 1048576, None, True),
+                                                 ('BlocksTouchVariation-v0', 524288 + 12, None, False),
+                                                 ('BlocksTouch-v0', 40004, 3, True), ('ToppleTower-v0', 1003, 2, True)])
+def test_sharded_evaluator_equals_one_launch(env_id, B, S, explicit):
+    """RolloutStudent.evaluate_rollouts_fused with its default shards (auto_shards: from 524 288 envs on, ranges of about
+    262 144 envs on streams of their own) against shards=1: every stream, every per-env array, every success rate and the
+    state the batch is left in, bit for bit -- explicit num_grey draws and the generator's (whose stream index the
+    sharded form advances once on the parent)."""
+    T, K = 50 if B < 100000 else 10, 3
+    dims = dims_of(env_id)
+    mk = lambda: bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=17), None, dims, None, T,   # noqa: E731
+                                    rollout_batch_size=B, output='torch')
+    one, many = mk(), mk()
+    assert bpg.rollout.auto_shards(1048576) == 4 and bpg.rollout.auto_shards(524288) == 2 and bpg.rollout.auto_shards(400000) == 1
+    gen = torch.Generator(device=DEV).manual_seed(B)
+    masks = bpg.time_major_empty(K * T, B, torch.int32, DEV)
+    masks.copy_(torch.randint(0, 1 << 21, (K * T, B), device=DEV, generator=gen, dtype=torch.int32)
+                & torch.randint(0, 1 << 21, (K * T, B), device=DEV, generator=gen, dtype=torch.int32))
+    ng = torch.randint(0, 3, (K, B), device=DEV, generator=gen, dtype=torch.int32) if explicit else None
+    outs = []
+    for w, sh in ((one, 1), (many, S)):
+        for rep in range(2):                       # twice: the second call starts from the state (and stream index) of the first
+            rw = bpg.time_major_empty(K * T, B, torch.float32, DEV)
+            fl = torch.empty((K * T, int(rw.stride(0))), dtype=torch.uint8, device=DEV)[:, :B]
+            er = torch.empty((K, B), dtype=torch.float32, device=DEV)
+            ef = torch.empty((K, B), dtype=torch.uint8, device=DEV)
+            rates = w.evaluate_rollouts_fused(masks, num_grey=ng, reward_tb=rw, flags_tb=fl, episode_return=er,
+                                              episode_fail_count=ef, shards=sh)
+        torch.cuda.synchronize()
+        outs.append((rates, rw, fl, er, ef, w.env.state_now.clone(), w.env.state_ever.clone(), w.env.state_counters.clone(),
+                     w.env.observation.clone()))
+    if S is None:
+        assert len(many._view_shards) == 1 and len(next(iter(many._view_shards.values()))) == bpg.rollout.auto_shards(B)
+    a, b = outs
+    assert a[0] == b[0]
+    for x, y, name in zip(a[1:], b[1:], ('reward', 'flags', 'episode_return', 'episode_fail_count', 'now', 'ever', 'counters', 'obs')):
+        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), name
+    assert list(one.success_history) == list(many.success_history) and one.n_episodes == many.n_episodes == 2 * K * B
+
+
+@pytest.mark.parametrize('env_id,B,S', [('BlocksTouchVariation-v0', 8192, 4), ('BlocksTouchChoose-v0', 1003, 3)])
+def test_sharded_episode_writer_equals_one_launch(env_id, B, S):
+    """generate_rollouts_fused(shards=S): the episode arrays, reward stream, G, episode return / fail count and the success
+    rate of S view launches on S streams are those of the one launch."""
+    T = 50
+    dims = dims_of(env_id)
+    mk = lambda cls, **kw: cls(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV, seed=3), None, *kw.pop('pre', ()),   # noqa: E731
+                               dims, None, T, rollout_batch_size=B, output='torch', **kw)
+    one, many = mk(bpg.PGRolloutStudent, pre=(None,), gamma=0.98), mk(bpg.PGRolloutStudent, pre=(None,), gamma=0.98)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    for rep in range(2):
+        masks = (torch.randint(0, 1 << 21, (T, B), device=DEV, generator=gen, dtype=torch.int32)
+                 & torch.randint(0, 1 << 21, (T, B), device=DEV, generator=gen, dtype=torch.int32))
+        ng = torch.randint(0, 3, (B,), device=DEV, generator=gen, dtype=torch.int32)
+        kw = dict(masks=masks, num_grey=ng, want_reward=True, episode_return=True, episode_fail_count=True, materialize_constants=rep == 1)
+        e1, e2 = one.generate_rollouts_fused(shards=1, **kw), many.generate_rollouts_fused(shards=S, **kw)
+        assert set(e1) == set(e2)
+        for k in e1:
+            x, y = e1[k], e2[k]
+            assert x.shape == y.shape and x.dtype == y.dtype, k
+            if x.is_floating_point():
+                x, y = x.contiguous().view(torch.int32 if x.dtype == torch.float32 else torch.int64), \
+                    y.contiguous().view(torch.int32 if y.dtype == torch.float32 else torch.int64)
+            assert torch.equal(x, y), k
+        assert one.success_history[-1] == many.success_history[-1]
+    # the C ABI's own checks for views
+    L = _lib.lib()
+    h = C.c_void_p()
+    env = one.env
+    assert L.bpg_create_view(C.byref(h), env._h, 2, 8) == _lib.ERR_ARG                      # not 16-byte aligned
+    assert L.bpg_create_view(C.byref(h), env._h, 0, B + 1) == _lib.ERR_ARG
+    _lib.check(L.bpg_create_view(C.byref(h), env._h, 4, 8))
+    assert L.bpg_num_envs(h) == 8 and L.bpg_seed(h, 1) == _lib.ERR_ARG and L.bpg_advance_generator(h, 1, 0, None) == _lib.ERR_ARG
+    h2 = C.c_void_p()
+    assert L.bpg_create_view(C.byref(h2), h, 0, 4) == _lib.ERR_ARG                          # no views of views
+    assert L.bpg_get_difficulty(h) == env.get_difficulty()
+    _lib.check(L.bpg_destroy(h))
