@@ -20,8 +20,8 @@ on the launch stream (bpg_comm_*, include/bpgym.h) instead of torch.distributed.
 TIMING: `value` = total env-steps of the K timed steps / MAX over ranks of the HIP-event span on the launch stream that covers
 them and the completion of their last exchange, measured inside the barrier + synchronize bracket (see rollout_leg); the wall
 clock of the bracket is reported beside it (`timing`).  N = 1 and N = 8 are measured the same way.
-At N = 1 the line also carries `roofline_sharded`: the same batch run as stream shards (views of the batch on streams of their own),
-which is what the package's fused evaluator does by default from 524 288 envs on.
+At N = 1 the line also carries `roofline_sharded`: the same batch run as stream shards (views of the batch on streams of their
+own, with arrays of their own and on column ranges of the headline's arrays).
 
     python bench.py [--gpus N --steps K --warmup W] [--total-envs E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -98,7 +98,7 @@ def parse():
                    help='time-major streams with rows exactly B elements apart (default: bpg_row_stride(B))')
     p.add_argument('--no-extras', action='store_true', help='skip the secondary kernels (step / episode / synth)')
     p.add_argument('--no-sharded', action='store_true',
-                   help='skip roofline_sharded (the batch as stream shards: views of the headline batch, and the evaluator worker\'s default)')
+                   help='skip roofline_sharded (the batch as stream shards: views of the headline batch on streams of their own)')
     p.add_argument('--stride-pads', default='0,256,768', help='row pads (elements) of the row-stride probe')
     p.add_argument('--no-stride-probe', action='store_true',
                    help='skip the set-up probe of the headline launch at row strides B, B + 256, B + 768')
@@ -209,16 +209,16 @@ def box_state_under_load(cx, h, seconds=0.6):
 
 
 def sharded_roofline(cx, h, steps, warmup):
-    """The headline batch as STREAM SHARDS (untimed part of the run, after the measurement; `value` never uses it).
-    (a) views: S = auto_shards(B) views of the headline env (bpg_create_view: contiguous env ranges that share its packed state),
-        each on a stream of its own, launching the headline's own launch (one rollout per launch, same buffer sets -- every
-        shard reads and writes its column range of them) K times back to back; the shards are forked from / joined into the
-        launch stream ONCE around the K steps.  us per rollout of the WHOLE batch = event span / K.
-    (b) worker: what a user of the package gets by default -- RolloutStudent.evaluate_rollouts_fused (the evaluator's test loop,
-        train.py:63-64: K rollouts per call) splits a batch of this size into the same shards itself, one launch of K rollouts
-        per shard, joined before it returns; timed from outside, everything it does included (the K success counts read back,
-        Variation's observation rows rewritten after the K resets); shards=1 beside it.
-    Algorithmic bytes per rollout as in `roofline`: B * (9 T + 12)."""
+    """The headline batch as STREAM SHARDS (untimed part of the run, after the measurement; `value` never uses it):
+    S = auto_shards(B) views of the headline env (bpg_create_view: contiguous env ranges that share its packed state), each on a
+    stream of its own, launching the headline's own launch (one rollout per launch) K times back to back; the shards are forked
+    from / joined into the launch stream ONCE around the K steps.  us per rollout of the WHOLE batch = event span / K, algorithmic
+    bytes per rollout as in `roofline`: B * (9 T + 12).
+      own_arrays     every shard reads and writes (T, n_shard) arrays of its own (the top-level figure: what a pipeline that
+                     owns its arrays per shard gets, e.g. distributed.StreamShards);
+      shared_arrays  every shard works on its column range of the headline's (T, B) arrays (what a call on the caller's arrays
+                     could be turned into: RolloutStudent.evaluate_rollouts_fused(shards=...), off by default -- it gains nothing).
+    """
     torch, _lib, L, dev, T = cx.torch, cx._lib, cx.L, cx.dev, cx.T
     import blockpuzzle_gym_amd as bpg
     B, LD, NBUF, env = h['B'], h['LD'], h['NBUF'], h['env']
@@ -234,67 +234,52 @@ def sharded_roofline(cx, h, steps, warmup):
         return out
     cur = torch.cuda.current_stream(dev)
     ng = ((torch.arange(B, device=dev, dtype=torch.int32) + env.env_id_base) * 7) % 3
-    # ---- (a) views of the headline env on the headline's arrays
     vs = bpg.rollout._ViewShards(env, S)
     cnt = torch.zeros(2, dtype=torch.int64, device=dev)
-    vargs = []
-    for hv, st, lo, n in vs.views:
-        vargs.append([_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr() + 4 * lo, d_masks=h['masks'][k].data_ptr() + 4 * lo,
-                                       d_reward_tb=h['reward'][k].data_ptr() + 4 * lo, d_flags_tb=h['flags'][k].data_ptr() + lo,
-                                       ld_masks=LD, ld_out=LD, d_success_count=cnt.data_ptr()) for k in range(NBUF)])
+    for layout in ('shared_arrays', 'own_arrays'):
+        vargs, keep = [], []
+        for hv, st, lo, n in vs.views:
+            if layout == 'shared_arrays':
+                sets = [(h['masks'][k].data_ptr() + 4 * lo, h['reward'][k].data_ptr() + 4 * lo, h['flags'][k].data_ptr() + lo, LD)
+                        for k in range(NBUF)]
+            else:
+                ldv = int(L.bpg_row_stride(n))
+                sets = []
+                for k in range(NBUF):
+                    m = torch.empty((T, ldv), dtype=torch.int32, device=dev)[:, :n]
+                    m.copy_(h['masks'][k][:, lo:lo + n])
+                    r = torch.empty((T, ldv), dtype=torch.float32, device=dev)[:, :n]
+                    f = torch.empty((T, ldv), dtype=torch.uint8, device=dev)[:, :n]
+                    keep.append((m, r, f))
+                    sets.append((m.data_ptr(), r.data_ptr(), f.data_ptr(), ldv))
+            vargs.append([_lib.RolloutArgs(T=T, reset_first=1, d_num_grey=ng.data_ptr() + 4 * lo, d_masks=pm, d_reward_tb=pr, d_flags_tb=pf,
+                                           ld_masks=ld, ld_out=ld, d_success_count=cnt.data_ptr()) for pm, pr, pf, ld in sets])
 
-    def train(n_it, first):
-        vs.fork()
-        for i in range(n_it):
-            for (hv, st, lo, n), va in zip(vs.views, vargs):
-                _lib.check(L.bpg_rollout_v2(hv, C.byref(va[(first + i) % NBUF]), C.c_void_p(st.cuda_stream)))
-        vs.join()
-    train(warmup, 0)
-    torch.cuda.synchronize(dev)
-    runs = []
-    for g in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(cur)
-        train(steps, g * steps)
-        e1.record(cur)
-        torch.cuda.synchronize(dev)
-        runs.append(e0.elapsed_time(e1) / steps)
-    out['views_back_to_back'] = dict(figure(min(runs)), runs_ms=runs, launches_per_shard=steps,
-                                     how='%d views x %d launches each on %d streams, forked / joined once around them; HIP events on '
-                                         'the launch stream; min of 3 groups' % (S, steps, S))
-    vs.close()
-    # ---- (b) the evaluator worker's default
-    dims = dict(o=env.dimo, u=4, g=env.dimg, info_is_success=1)
-    w = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=dev, seed=cx.a.seed), None, dims, None, T,
-                           rollout_batch_size=B, output='torch')
-    K = steps
-    masks = torch.empty((K * T, LD), dtype=torch.int32, device=dev)[:, :B]
-    for k in range(K):                              # rollout k reads the rows of buffer set k % NBUF's generator seed
-        w.env.seed(cx.a.seed + k)
-        _lib.check(L.bpg_synth_masks_ld(w.env._h, 0, T, C.c_void_p(masks[k * T].data_ptr()), LD, cx.stream))
-    w.env.seed(cx.a.seed)
-    rw = torch.empty((K * T, LD), dtype=torch.float32, device=dev)[:, :B]
-    fl = torch.empty((K * T, LD), dtype=torch.uint8, device=dev)[:, :B]
-    ngk = ng[None].expand(K, B).contiguous()
-    for label, sh in (('worker_default', None), ('worker_one_launch', 1)):
-        w.evaluate_rollouts_fused(masks, num_grey=ngk, reward_tb=rw, flags_tb=fl, shards=sh)        # warm-up (creates the views)
+        def train(n_it, first):
+            vs.fork()
+            for i in range(n_it):
+                for (hv, st, lo, n), va in zip(vs.views, vargs):
+                    _lib.check(L.bpg_rollout_v2(hv, C.byref(va[(first + i) % NBUF]), C.c_void_p(st.cuda_stream)))
+            vs.join()
+        train(max(warmup, 10), 0)
         torch.cuda.synchronize(dev)
         runs = []
         for g in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)
-            rates = w.evaluate_rollouts_fused(masks, num_grey=ngk, reward_tb=rw, flags_tb=fl, shards=sh)
+            train(steps, g * steps)
             e1.record(cur)
             torch.cuda.synchronize(dev)
-            runs.append(e0.elapsed_time(e1) / K)
-        out[label] = dict(figure(min(runs)), runs_ms=runs, rollouts_per_call=K, success_rate_last=rates[-1],
-                          how='RolloutStudent.evaluate_rollouts_fused(masks of %d rollouts%s): HIP events around the call, min of 3 calls'
-                              % (K, '' if sh is None else ', shards=1'))
-    del w, masks, rw, fl
+            runs.append(e0.elapsed_time(e1) / steps)
+        out[layout] = dict(figure(min(runs)), runs_ms=runs, launches_per_shard=steps)
+        del keep, vargs
+    vs.close()
     torch.cuda.empty_cache()
-    # the top-level figure: the package's default for a batch of this size
-    out.update({k: out['worker_default'][k] for k in ('ms_per_rollout', 'achieved', 'frac')})
-    out['kernel'] = 'k_rollout<masks, 2 envs/lane x 256 lanes, reward+flags, %d rollouts per launch> on %d views / streams' % (K, S)
+    out['how'] = ('%d views x K = %d launches each on %d streams, forked / joined once around them; HIP events on the launch stream; '
+                  'min of 3 groups; the one launch under the same events: roofline.kernel_ms' % (S, steps, S))
+    out.update({k: out['own_arrays'][k] for k in ('ms_per_rollout', 'achieved', 'frac')})
+    out['kernel'] = 'k_rollout<masks, 2 envs/lane x 256 lanes, reward+flags, reset> on %d views / streams, arrays of their own' % S
+    out['one_launch_frac'] = nbytes / (h['kernel_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
 

@@ -91,8 +91,8 @@ MAX_SHARDS = 16
 
 
 def auto_shards(num_envs):
-    """How many stream shards the fused workers split a batch of `num_envs` envs into by default (0.73-0.76 of
-    the HBM peak against 0.67-0.70 for one launch at 1 M envs; nothing to gain below 524 288)."""
+    """How many stream shards `shards='auto'` splits a batch of `num_envs` envs into: ranges of about 262 144 envs from
+    524 288 envs on (nothing to gain below)."""
     if num_envs < SHARD_FROM:
         return 1
     return max(1, min(MAX_SHARDS, num_envs // SHARD_ENVS))
@@ -271,8 +271,8 @@ class RolloutStudent:
         self.clear_history()
 
     def _shards_for(self, shards):
-        """shards=None: auto_shards(B); an int: that many (1 = one launch on the current stream).  Returns None for 1."""
-        S = auto_shards(self.rollout_batch_size) if shards is None else int(shards)
+        """shards='auto': auto_shards(B); an int: that many (1 / None = one launch on the current stream).  Returns None for 1."""
+        S = auto_shards(self.rollout_batch_size) if shards == 'auto' else int(shards or 1)
         if S <= 1:
             return None
         if S not in self._view_shards:
@@ -615,10 +615,9 @@ class RolloutStudent:
         episode_fail_count: also `episode_fail_count` (B,) uint8, the same quantity as one byte per env (the number of steps
         whose success condition did not hold; episode_return == -episode_fail_count bit for bit, T <= 255): the form a
         multi-GPU job puts on the wire (a quarter of the bytes; distributed.episode_return_from_fail_count expands it).
-        shards: S > 1 runs the batch as S contiguous env ranges on S streams (views of the env, one launch each, joined
-        before this returns; None = auto_shards(B)): every output is the same array either way.  Default 1: the launch that
-        writes the episode arrays is bound by its 15 KB of float32 output per env and runs at 0.8 of the HBM peak as one
-        launch -- measured, sharding it gains nothing; evaluate_rollouts_fused, the stream path, shards by default."""
+        shards: S > 1 (or 'auto') runs the batch as S contiguous env ranges on S streams (views of the env, one launch each,
+        joined before this returns): every output is the same array, every bit the one launch's.  Default 1: measured, it
+        does not pay here -- see evaluate_rollouts_fused."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         o0 = torch.empty((B, self.dims['o']), dtype=torch.float32, device=self.device)
         self.reset_all_rollouts(test, num_grey=num_grey, observation_out=o0)      # the episode owns the reset observation
@@ -686,7 +685,7 @@ class RolloutStudent:
         return out
 
     def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
-                                flags_tb=None, episode_return=None, episode_fail_count=None, shards=None):
+                                flags_tb=None, episode_return=None, episode_fail_count=None, shards=1):
         """The evaluator's test loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)`
         (train.py:63-64, play.py:59) -- with the contacts of all K rollouts read from one stream, in ONE
         launch: rollout r is reset + T steps on rows r*T .. r*T+T-1 of `masks` ((K*T, B) int32 device
@@ -697,11 +696,16 @@ class RolloutStudent:
         the launch fills (step reward; bit 0 is_success, bit 1 done); episode_return: optional (K, B) float32
         the launch fills with every env's undiscounted return of each rollout; episode_fail_count: optional (K, B) uint8, the
         same as one byte per env (T <= 255).  Returns the K success rates.
-        shards: from 524 288 envs on the batch runs as auto_shards(B) contiguous env ranges of about 262 144 envs, each ONE
-        launch (its K rollouts) on a stream of its own, joined before this returns -- the launches of different shards overlap,
-        so the ramp-up and drain of one are covered by the others (0.73-0.76 of the HBM peak against 0.67-0.70 at 1 M envs,
-        DESIGN.md).  Every array is the caller's own (the shards read and write column ranges of them), every result bit is
-        the one launch's.  shards=1: one launch on the current stream."""
+        shards: S > 1 (or 'auto': auto_shards(B), ranges of about 262 144 envs) runs the batch as S contiguous env ranges
+        (bpg_create_view), each ONE launch of its K rollouts on a stream of its own, forked from and joined into the current
+        stream -- the launches of different shards overlap, so the ramp-up and drain of one are covered by the others.  Every
+        array stays the caller's own (the shards read and write column ranges of them), every result bit is the one launch's.
+        DEFAULT 1, by measurement (round 5, profiles/r05_shard_probe.log, 1 M envs, two boxes): shards that work on column
+        ranges of the caller's arrays gain nothing over the one launch (89.6-90.1 against 90.1-90.2 us per rollout), and the
+        fork / join of a call costs more than that (K = 5: 145-147 against 133 us per rollout; K = 20: 110 against 106-107).
+        What gains is shards with arrays OF THEIR OWN launched back to back without a join per rollout (4 x 262 144: 83.4-84.9
+        us, 0.71-0.73 of the HBM peak against 0.67): a pipeline that owns its arrays per shard (distributed.StreamShards, or
+        views + its own streams), not something a call on the caller's arrays can be turned into."""
         env, B, T = self.env, self.rollout_batch_size, self.T
         assert masks.dim() == 2 and masks.shape[1] == B and masks.shape[0] % T == 0 and masks.element_size() == 4 \
             and masks.stride(1) == 1 and masks.is_cuda

@@ -354,13 +354,13 @@ def test_return_scratch_is_reserved_up_front_and_all_gather_fills_out():
 # --------------------------------------------------------------------------
 # the fused workers as stream shards (views of the batch) == one launch
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize('env_id,B,S,explicit', [('BlocksTouchVariation-v0', 1048576, None, True),
-                                                 ('BlocksTouchVariation-v0', 524288 + 12, None, False),
+@pytest.mark.parametrize('env_id,B,S,explicit', [('BlocksTouchVariation-v0', 1048576, 'auto', True),
+                                                 ('BlocksTouchVariation-v0', 524288 + 12, 'auto', False),
                                                  ('BlocksTouch-v0', 40004, 3, True), ('ToppleTower-v0', 1003, 2, True)])
 def test_sharded_evaluator_equals_one_launch(env_id, B, S, explicit):
-    """RolloutStudent.evaluate_rollouts_fused with its default shards (auto_shards: from 524 288 envs on, ranges of about
-    262 144 envs on streams of their own) against shards=1: every stream, every per-env array, every success rate and the
-    state the batch is left in, bit for bit -- explicit num_grey draws and the generator's (whose stream index the
+    """RolloutStudent.evaluate_rollouts_fused(shards='auto': from 524 288 envs on, ranges of about 262 144 envs on streams of
+    their own; or an explicit count) against the default one launch: every stream, every per-env array, every success rate
+    and the state the batch is left in, bit for bit -- explicit num_grey draws and the generator's (whose stream index the
     sharded form advances once on the parent)."""
     T, K = 50 if B < 100000 else 10, 3
     dims = dims_of(env_id)
@@ -385,7 +385,7 @@ def test_sharded_evaluator_equals_one_launch(env_id, B, S, explicit):
         torch.cuda.synchronize()
         outs.append((rates, rw, fl, er, ef, w.env.state_now.clone(), w.env.state_ever.clone(), w.env.state_counters.clone(),
                      w.env.observation.clone()))
-    if S is None:
+    if S == 'auto':
         assert len(many._view_shards) == 1 and len(next(iter(many._view_shards.values()))) == bpg.rollout.auto_shards(B)
     a, b = outs
     assert a[0] == b[0]
