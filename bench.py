@@ -772,7 +772,7 @@ def run(a):
     # rocprofv3 --kernel-trace --stats means of the committed profile of this same command
     # (tools/collect_profiles.sh -> profiles/r0N_pmc/kernel_means.json), quoted beside the live HIP-event figures
     prof_means, mf = {}, None
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         mf = os.path.join(ROOT, 'profiles', rnd + '_pmc', 'kernel_means.json')
         if os.path.exists(mf):
             prof_means = json.load(open(mf))

@@ -91,7 +91,7 @@ int main()
     CHECK(bpg_synth_masks(h, 0, T, d_m0, nullptr));
     CHECK(bpg_synth_masks_ld(h, 0, T, d_m1, ld, nullptr));
     unsigned long long *d_c2; HIP(hipMalloc(&d_c2, 16)); HIP(hipMemset(d_c2, 0, 16));
-    bpg_rollout_args ra = BPG_ROLLOUT_ARGS_INIT;      // struct_size = sizeof(bpg_rollout_args), every other field zero
+    bpg_rollout_args ra = BPG_ROLLOUT_ARGS_INIT;      // struct_size = BPG_ARGS_TAG(sizeof(bpg_rollout_args)), every other field zero
     ra.T = T; ra.reset_first = 1; ra.d_masks = d_m0; ra.d_reward_tb = d_r0; ra.d_flags_tb = d_f0; ra.d_success_count = d_c2;
     CHECK(bpg_rollout_v2(h, &ra, nullptr));
     ra.d_masks = d_m1; ra.d_reward_tb = d_r1; ra.d_flags_tb = d_f1; ra.d_success_count = d_c2 + 1;
@@ -178,6 +178,69 @@ int main()
                 ck[3], bad4, K);
     CHECK(bpg_destroy(h2));
     CHECK(bpg_destroy(h3));
+
+    // BASELINE configs[3] in miniature, as a host that is not PyTorch runs it: the job's env range split into contiguous shards
+    // (here two VIEWS of one batch on two streams of one GPU -- the same partition that spreads a job over the GPUs of a node,
+    // where every rank holds one shard as a batch of its own created with env_id_base = its first env), every shard's rollout
+    // launch writes its envs' episode fail counts (one byte per env), the library's own RCCL communicator all-gathers them on
+    // the launch stream (one rank here: the gather is a copy) and the bytes are expanded to the float32 returns on the device.
+    const int64_t Bj = 4096;
+    bpg_batch *job = nullptr, *shard[2] = {nullptr, nullptr};
+    CHECK(bpg_create(&job, bpg_variant_from_id("BlocksTouchVariation-v0"), Bj, 0, 50, 99, 0));
+    CHECK(bpg_create_view(&shard[0], job, 0, Bj / 2));
+    CHECK(bpg_create_view(&shard[1], job, Bj / 2, Bj / 2));
+    hipStream_t st[2];
+    HIP(hipStreamCreate(&st[0])); HIP(hipStreamCreate(&st[1]));
+    uint8_t *d_fail, *d_all; float *d_ret_g, *d_ret_direct;
+    HIP(hipMalloc(&d_fail, Bj)); HIP(hipMalloc(&d_all, Bj)); HIP(hipMalloc(&d_ret_g, Bj * 4)); HIP(hipMalloc(&d_ret_direct, Bj * 4));
+    for (int r = 0; r < 2; r++) {
+        static bpg_rollout_args sa = BPG_ROLLOUT_ARGS_INIT_STATIC;          // the constant initialiser (C statics)
+        bpg_rollout_args a = sa;
+        a.T = 50; a.reset_first = 1;                                         // contacts from the synthetic source, num_grey from the generator
+        a.d_episode_fail_count = d_fail + r * (Bj / 2);
+        a.d_episode_return = d_ret_direct + r * (Bj / 2);
+        CHECK(bpg_rollout_v2(shard[r], &a, st[r]));
+    }
+    HIP(hipStreamSynchronize(st[0])); HIP(hipStreamSynchronize(st[1]));
+    CHECK(bpg_advance_generator(job, 1, 0, nullptr));                        // the views drew from the generator: once, on the parent
+    unsigned char id[BPG_COMM_ID_BYTES];
+    bpg_comm *comm = nullptr;
+    int rc_comm = bpg_comm_unique_id(id);
+    int bad5 = 0;
+    if (rc_comm == BPG_OK) {
+        CHECK(bpg_comm_create(&comm, 0, 1, id, 0));
+        CHECK(bpg_allgather_u8(comm, d_fail, d_all, Bj, nullptr));
+        CHECK(bpg_episode_return_from_fail_count(d_all, d_ret_g, Bj, 0, nullptr));
+        HIP(hipDeviceSynchronize());
+        std::vector<float> ra2((size_t)Bj), rb2((size_t)Bj);
+        HIP(hipMemcpy(ra2.data(), d_ret_g, Bj * 4, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(rb2.data(), d_ret_direct, Bj * 4, hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < Bj; e++) bad5 += std::memcmp(&ra2[e], &rb2[e], 4) != 0;
+        std::printf("sharded rollout + library all-gather (world %d): %d of %lld gathered returns differ from the launch's own\n",
+                    bpg_comm_world_size(comm), bad5, (long long)Bj);
+        CHECK(bpg_comm_destroy(comm));
+    } else {
+        std::printf("librccl.so not available (%s): gather skipped\n", bpg_last_error());
+    }
+    CHECK(bpg_destroy(shard[0])); CHECK(bpg_destroy(shard[1]));
+
+    // the curriculum lives in the handle (fetch_env.py:623-630 for this variant): obj_range 0.08 -> 0.2 in steps of 0.025
+    int level_at_top = -1;
+    for (int i = 0; i < 12; i++) {
+        int top = 0;
+        CHECK(bpg_increase_difficulty(job, &top));
+        if (top && level_at_top < 0) level_at_top = bpg_get_difficulty(job);
+    }
+    bpg_curriculum cur;
+    CHECK(bpg_get_curriculum(job, &cur));
+    std::printf("curriculum: difficulty %d at the maximum level, obj_range %.3f of %.3f\n", level_at_top, cur.obj_range, cur.max_obj_range);
+    const int bad6 = !(level_at_top == 4 && cur.obj_range == cur.max_obj_range && bpg_get_difficulty(job) == 4);
+    bpg_batch *gt = nullptr;
+    CHECK(bpg_create(&gt, bpg_variant_from_id("GripperTouch-v0"), 4, 0, 50, 0, 0));
+    const int rc_gt = bpg_increase_difficulty(gt, nullptr);                  // NotImplementedError in the reference (fetch_env.py:93-94)
+    CHECK(bpg_destroy(gt));
+    CHECK(bpg_destroy(job));
     CHECK(bpg_destroy(h));
-    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0 && bad3 == 0 && bad4 == 0) ? 0 : 2;
+    return (bad == 0 && cnt == (unsigned long long)B && bad2 == 0 && bad3 == 0 && bad4 == 0 && bad5 == 0 && bad6 == 0 &&
+            rc_gt == BPG_ERR_UNSUPPORTED) ? 0 : 2;
 }

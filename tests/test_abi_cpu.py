@@ -189,6 +189,30 @@ def test_no_kernel_uses_scratch_memory():
     assert seen >= 100
 
 
+def test_sgpr_spills_of_the_headline_kernel_stay_outside_its_loops():
+    """The fused rollout keeps ~100 scalars alive (row addresses of the unrolled steps, goal planes, strides) and the compiler
+    parks the kernel arguments that only the epilogue needs (the success-count words) in lanes of a VGPR: "SGPRs Spill: 10" in
+    the resource table.  That is free as long as the spill writes sit in the prologue and the restores behind the loops; inside
+    the step loop they would cost issue slots on every trip.  tools/kernel_resources.py --spill-sites reads the loop depth of
+    every v_writelane / v_readlane out of the device assembly: the headline instantiation (masks, 2 envs per lane, reward +
+    flags, reset, 1024 lanes) must have none at depth > 0, and no instantiation more than a handful in its innermost loop."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kernel_resources', os.path.join(ROOT, 'tools', 'kernel_resources.py'))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    sites = kr.spill_sites(os.path.join(ROOT, 'blockpuzzle-gym_amd', 'csrc', 'rollout.hip'))
+    by_name = {v['name']: v for v in sites.values()}
+    head = [v for k, v in by_name.items() if 'k_rollout<0, 2, 3, 1, 5, false, 1024, 0>' in k]
+    assert len(head) == 1, sorted(by_name)[:5]
+    assert set(head[0]['writes']) <= {0} and set(head[0]['reads']) <= {0}, head[0]
+    for name, v in by_name.items():
+        # MODE_MULTI (4th argument 2) wraps one more loop around everything: its step loop is depth 3, the others' depth 2
+        multi = re.search(r'k_rollout<\d+, \d+, \d+, 2,', name) is not None
+        inner = 3 if multi else 2
+        n_inner = sum(n for d, n in list(v['writes'].items()) + list(v['reads'].items()) if d >= inner)
+        assert n_inner <= 4, (name, v)
+
+
 def test_register_with_gym_against_a_recording_stand_in(monkeypatch):
     """gym is not installable here; a stand-in `gym.envs.registration.register` records what register_with_gym hands
     it: the seven ids of gym_blocks/__init__.py:6-53, max_episode_steps = 50, kwargs {'reward_type': 'sparse'},

@@ -967,6 +967,9 @@ def test_c_abi_from_plain_cpp_host(tmp_path):
     assert 'vs contiguous: 0 mismatches' in out.stdout and 'bpg_row_stride(2^20) = 1048832' in out.stdout
     assert 'return from the rollout call: 0 of 1000 rows differ' in out.stdout
     assert '4 rollouts in one launch' in out.stdout and '; 0 differ from 4 separate launches' in out.stdout
+    # round 5: a sharded rollout (views), the library's own RCCL all-gather of the byte returns, the curriculum in the handle
+    assert 'sharded rollout + library all-gather (world 1): 0 of 4096 gathered returns differ' in out.stdout
+    assert 'curriculum: difficulty 4 at the maximum level, obj_range 0.200 of 0.200' in out.stdout
 
 
 def test_contact_list_input_is_sanitised():

@@ -3,6 +3,7 @@
 `hipcc -Rpass-analysis=kernel-resource-usage` (device-only compiles in parallel, no GPU needed).
 
     python tools/kernel_resources.py [--scratch-only] [--filter k_rollout]
+    python tools/kernel_resources.py --spill-sites [unit ...]      where the SGPR spills of a unit's kernels sit (loop depth)
 """
 import os
 import re
@@ -58,7 +59,57 @@ def resources(sources=None, hipcc='/opt/rocm/bin/hipcc', extra_flags=()):
     return rows
 
 
+def spill_sites(src, hipcc='/opt/rocm/bin/hipcc'):
+    """Where the SGPR spills of every kernel of one translation unit are: {kernel: {'writes': {depth: n}, 'reads': {depth: n}}},
+    depth = loop nesting of the basic block (0 = outside every loop), from the device assembly.  An SGPR spill is a
+    v_writelane_b32 into a constant lane of a VGPR and its restore a v_readlane_b32 from one; at depth 0 -- kernel arguments the
+    epilogue needs, parked in a VGPR lane while the loops run -- they cost a handful of instructions per wave per launch; inside
+    a loop they would cost issue slots on every trip."""
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, 'dev.s')
+        cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '--cuda-device-only', '-S',
+               '-o', asm, src]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-4000:])
+        text = open(asm).read()
+    out, names = {}, []
+    for m in re.finditer(r'^(_Z\w+):\s*; @\1\n(.*?)^\.Lfunc_end', text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        depth, sites = 0, {'writes': {}, 'reads': {}}
+        lines = body.split('\n')
+        for i, ln in enumerate(lines):
+            if re.match(r'\.LBB\d+_\d+:', ln):
+                # the block's loop annotation is on the label line and, for nested loops, the comment lines right behind it
+                note = ln + ' '.join(lines[i + 1:i + 4] if ';' in ln else [])
+                dm = re.findall(r'Depth=(\d+)', ' '.join([ln] + [x for x in lines[i + 1:i + 4] if x.lstrip().startswith(';')]))
+                depth = max(int(x) for x in dm) if dm else 0
+                continue
+            t = ln.strip()
+            if re.match(r'v_writelane_b32 v\d+, s\d+, \d+', t):
+                sites['writes'][depth] = sites['writes'].get(depth, 0) + 1
+            elif re.match(r'v_readlane_b32 s\d+, v\d+, \d+', t):
+                sites['reads'][depth] = sites['reads'].get(depth, 0) + 1
+        if sites['writes'] or sites['reads']:
+            out[name] = sites
+            names.append(name)
+    for name, nm in zip(names, demangle(names)):
+        out[name]['name'] = re.sub(r'\(.*', '', nm)
+    return out
+
+
 def main():
+    if '--spill-sites' in sys.argv:
+        units = [a for a in sys.argv[sys.argv.index('--spill-sites') + 1:] if not a.startswith('-')] or ['rollout']
+        for u in units:
+            sites = spill_sites(os.path.join(CSRC, u + '.hip'))
+            inside = 0
+            for k, v in sorted(sites.items(), key=lambda kv: kv[1]['name']):
+                deep = sum(n for d, n in list(v['writes'].items()) + list(v['reads'].items()) if d > 0)
+                inside += deep
+                print('%-100s spill writes by loop depth %s  restores %s' % (v['name'][:100], v['writes'], v['reads']))
+            print('%s: %d kernels with SGPR spills, %d spill / restore instructions inside a loop' % (u, len(sites), inside))
+        return
     rows = resources()
     flt = sys.argv[sys.argv.index('--filter') + 1] if '--filter' in sys.argv else ''
     for r in rows:

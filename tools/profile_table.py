@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Prints the markdown table of profiles/README.md from profiles/<round>_pmc/kernel_means.json and
-traffic_all_kernels.json (tools/publish_profiles.sh writes both):  python tools/profile_table.py [r04]"""
+traffic_all_kernels.json (tools/publish_profiles.sh writes both):  python tools/profile_table.py [r05]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 ROWS = [
     ('k_rollout_masks_bench', '`k_rollout<masks>` (headline, 2/lane × 1024), as `bench.py` issues it', 'reset + 50 steps + success count, 1 M envs'),
     ('k_rollout_masks', 'same, from `prof_kernels.py` (its own process and buffers)', ''),

@@ -4,7 +4,7 @@
 # counter CSVs and the per-kernel traffic / mean-duration JSONs (tools/summarize_pmc.py).
 set -e
 SRC=gpurun_out/${1:?run directory under gpurun_out/}
-R=${2:-r04}
+R=${2:-r05}
 cd "$(dirname "$0")/.."
 one() {      # exactly one result file per sub-run (gpurun MERGES into an existing local directory: use a fresh name per run)
   n=$(find "$SRC/$1" -name "*$2" | wc -l)

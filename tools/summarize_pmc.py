@@ -44,10 +44,10 @@ def roll(n):
     return n * (4 * T + 4), n * (5 * T + 8)
 
 
-# template arguments: <SRC, NT, EPL, OUT, RESET, UNROLL, PIPE, NTL, LB, OKB, MULTI, RET>
-FAT = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, false, false>'
-FAT_RET = 'k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, false, true>'      # + the per-env episode return
-MID = 'k_rollout<0, true, 2, 3, true, 5, false, true, 256, false, false, false>'
+# template arguments: <SRC, EPL, OUT, MODE (0 continue / 1 reset / 2 several rollouts), UNROLL, PIPE, LB, AUX (0 / 1 step-ok words / 2 per-env counter)>
+FAT = 'k_rollout<0, 2, 3, 1, 5, false, 1024, 0>'
+FAT_RET = 'k_rollout<0, 2, 3, 1, 5, false, 1024, 2>'      # + the per-env episode return
+MID = 'k_rollout<0, 2, 3, 1, 5, false, 256, 0>'
 
 
 def roll_ret(n):
@@ -69,10 +69,10 @@ KERNELS = [
     (FAT_RET, 256 * 1024, 'k_rollout_masks_524288_with_episode_return', 'read8') + roll_ret(524288) + ('2',),
     (MID, 262144 // 2, 'k_rollout_masks_262144', 'read8') + roll(262144) + ('',),
     (MID, 1024 * 256, 'k_rollout_masks_4194304_aliased_rows', 'read8') + roll(4194304) + ('2',),
-    ('k_rollout<0, true, 1, 3, true, 5, true, true, 256, false, false, false>', 131072, 'k_rollout_masks_131072', 'read4') + roll(131072) + ('',),
-    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, false, false>', 65536, 'k_rollout_masks_65536', 'read4') + roll(65536) + ('',),
-    ('k_rollout<1, true, 2, 3, true, 10, false, true, 256, false, false, false>', None, 'k_rollout_synth', 'read8', 0, B * (5 * T + 8), ''),
-    ('k_rollout<0, true, 2, 2, true, 5, false, true, 1024, true, false, false>', None, 'k_rollout_masks_flags_okbits', 'read8',
+    ('k_rollout<0, 1, 3, 1, 5, true, 256, 0>', 131072, 'k_rollout_masks_131072', 'read4') + roll(131072) + ('',),
+    ('k_rollout<0, 1, 3, 1, 10, true, 256, 0>', 65536, 'k_rollout_masks_65536', 'read4') + roll(65536) + ('',),
+    ('k_rollout<1, 2, 3, 1, 10, false, 256, 0>', None, 'k_rollout_synth', 'read8', 0, B * (5 * T + 8), ''),
+    ('k_rollout<0, 2, 2, 1, 5, false, 1024, 1>', None, 'k_rollout_masks_flags_okbits', 'read8',
      B * (4 * T + 4), B * (T + 8 + 8), ''),
     ('k_returns_from_okbits_lane<50', None, 'k_returns_from_okbits_lane50', 'read8', 8 * B, 8 * T * B, ''),
     ('k_step_vec4<0>', None, 'k_step_vec4_masks', 'read16', 12 * B, 13 * B, ''),
@@ -91,8 +91,8 @@ KERNELS = [
     ('k_trim<true>', None, 'k_trim_variation', 'read16', B * 4 * (87 + 2 * 36), B * (8 * 40 + 2 * 4 * 16), ''),
     ('k_step_contacts<4>', None, 'k_step_contacts', 'read16', B * (8 + 4 + 64), 13 * B, ''),
     ('k_contacts_to_masks<4>', None, 'k_contacts_to_masks_tb', 'read16', T * 262144 * (64 + 4) + 4 * 262144, 4 * T * 262144, ''),
-    ('k_rollout<0, true, 1, 3, true, 10, true, true, 256, false, true, false>', 65536, 'k_rollout_masks_65536_x10', 'read4') + roll_k(65536) + ('',),
-    ('k_rollout<0, true, 2, 3, true, 5, false, true, 1024, false, true, false>', 256 * 1024, 'k_rollout_masks_x10', 'read8') + roll_k(B) + ('2',),
+    ('k_rollout<0, 1, 3, 2, 10, true, 256, 0>', 65536, 'k_rollout_masks_65536_x10', 'read4') + roll_k(65536) + ('',),
+    ('k_rollout<0, 2, 3, 2, 5, false, 1024, 0>', 256 * 1024, 'k_rollout_masks_x10', 'read8') + roll_k(B) + ('2',),
 ]
 
 
