@@ -166,7 +166,7 @@ def cpu_baseline(T, seconds):
 def box_state_under_load(cx, h, seconds=0.6):
     """Untimed, after the measurement: the clocks and the power of the card WHILE the headline launch runs back to back (a train
     of launches is enqueued, `rocm-smi` is read once while it drains).  The headline launch takes 82-91 us depending on the box
-    (DESIGN.md 4): this records what the box the bench ran on looked like.  Best effort -- {'error': ...} if rocm-smi is missing."""
+    (docs/HISTORY.md 4): this records what the box the bench ran on looked like.  Best effort -- {'error': ...} if rocm-smi is missing."""
     torch, _lib, L = cx.torch, cx._lib, cx.L
     try:
         env, T, LD, NBUF = h['env'], cx.T, h['LD'], h['NBUF']
@@ -453,7 +453,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     # consecutive uses of one are > 2 x 256 MiB apart)
     NBUF = max(a.buffers, int(2.5 * 256 * 2**20 // (B * T * 9)) + 1)
     # time-major (T, B) streams whose rows are LD = bpg_row_stride(B) elements apart (B + 256 for the power-of-two batch
-    # sizes): rows a power of two apart land on the same HBM channels (DESIGN.md 4).  The pad is never read or written
+    # sizes): rows a power of two apart land on the same HBM channels (DESIGN.md 2).  The pad is never read or written
     # and is not counted in the bytes.  --contiguous-rows: LD = B.
     LD = B if a.contiguous_rows else int(L.bpg_row_stride(B))
 
@@ -568,7 +568,7 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
         torch.cuda.synchronize(dev)
 
     # Row-stride probe (set-up, untimed part of the run; `value` always uses LD above): the headline launch at
-    # rows B, B + 256 and B + 768 elements apart on THIS box -- DESIGN.md 3 derives bpg_row_stride from a handful
+    # rows B, B + 256 and B + 768 elements apart on THIS box -- docs/HISTORY.md 3 derives bpg_row_stride from a handful
     # of boxes, this records what the box the bench ran on says.
     probe = None
     if stride_probe and rank == 0 and not a.no_stride_probe and B >= (1 << 19):
@@ -753,7 +753,7 @@ def run(a):
                     impl=a.collective_impl, gather_dtype=a.gather_dtype)
     dt, kernel_ms, LD, NBUF, R = h['dt'], h['kernel_ms'], h['LD'], h['NBUF'], h['R']
 
-    # algorithmic bytes of the fused rollout launch (DESIGN.md 4): per env-step mask 4 B in,
+    # algorithmic bytes of the fused rollout launch (DESIGN.md 3): per env-step mask 4 B in,
     # reward 4 B + flags 1 B out; per env the packed state 8 B out (the in-launch Variation reset
     # overwrites the whole state, so the old state is not an input) + the explicit num_grey draw 4 B in
     # (+ the episode return 4 B out when the leg all-gathers it)
@@ -906,7 +906,7 @@ def run(a):
         # The same leg with the collectives issued by the OTHER implementation, for the comparison on hardware.  The library's
         # communicator is created here for the first time (ncclCommInitRank over the ranks): should that never return, a
         # watchdog prints the result line without this leg and ends the process -- on every rank alike.
-        if not a.no_cabi_leg and a.collective_impl == 'torch':
+        if not a.no_cabi_leg and a.collective_impl == 'torch' and dist.get_backend() == 'nccl' and not a.single_device:
             import threading
             done = threading.Event()
 

@@ -175,7 +175,7 @@ __device__ __forceinline__ void step_core(uint32_t &now, uint32_t &ever, uint32_
     flags = succ | ((elapsed >= c.max_steps) ? (uint32_t)BPG_FLAG_DONE : 0u) | (ok ? (uint32_t)BPG_FLAG_STEP_OK : 0u);
 }
 
-// build-defined counter-based contact source (DESIGN.md "synthetic contacts"), a pure function
+// build-defined counter-based contact source, a pure function
 // of (seed, global env id, step).  Per env two 32-bit keys from the lowbias32 finaliser (once
 // per launch); per step two well-mixed words a, b: a Weyl step of the key, an xorshift, ONE
 // 32x32->64 multiply each, high half folded onto the low half (v_mad_u64_u32 + v_xor).  On gfx950

@@ -74,7 +74,7 @@ class StreamShards:
     spreads a job over GPUs (contiguous shards keyed by global env index, no data-path exchange), applied once more
     inside a GPU.  The shards' launches are independent, so the hardware runs them side by side: while one shard's
     rollout launch ramps up or drains, the others stream, and the two ends of a launch that a single stream leaves
-    exposed (DESIGN.md) are covered by other shards' work.  Measured (tools/stream_shards.py,
+    exposed (DESIGN.md section 3) are covered by other shards' work.  Measured (tools/stream_shards.py,
     profiles/r04_stream_shards.log, launches back to back, nothing joined between rollouts): 524 288 envs as 2 x 262 144:
     38.6-39.6 us per rollout against 45.2-45.9 us for one handle (0.76-0.79 against 0.66-0.67 of the HBM peak); 1 048 576
     envs as 4 x 262 144: 79.9-80.8 us against 90.7-91.1 us (0.75-0.76 against 0.67); 4 194 304 envs as 16 x 262 144: 315-320 us
@@ -240,7 +240,7 @@ class RcclComm:
     CALLER's stream -- the stream the rollout launch that produced the input ran on, so no event crosses streams -- and
     usable from a host that is not PyTorch (examples/c_abi_demo.cpp).  torch.distributed's nccl backend runs its
     collectives on a stream of its own and orders it against the caller's with events: 12-30 us of serialisation per
-    collective per rollout, which a per-rollout gather pays every time.
+    collective per rollout (docs/HISTORY.md section 8), which a per-rollout gather pays every time.
 
     RcclComm(rank, world, device, id_bytes): every rank passes the same 128 bytes (rank 0's RcclComm.unique_id()).
     RcclComm.from_process_group(device): takes them from rank 0 of the initialised torch.distributed group (any backend:

@@ -132,7 +132,7 @@ class SyntheticContacts:
     """Build-defined physics stand-in (no reference counterpart): contacts are a
     counter-based pseudo-random function of (seed, global env id, step) evaluated
     inside the step kernel; table-block pairs always touch, every other pair is
-    Bernoulli(5/32).  See DESIGN.md."""
+    Bernoulli(5/32).  See DESIGN.md section 5."""
     kind = 'synthetic'
 
     def next(self, env, actions):

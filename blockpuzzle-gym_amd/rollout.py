@@ -49,7 +49,7 @@ def configure_dims(env):
 def time_major_empty(T, B, dtype, device):
     """A (T, B) device tensor for a time-major stream (masks, rewards, flags) whose rows are
     bpg_row_stride(B) elements apart: rows a power of two apart land on the same HBM channels
-    (DESIGN.md section 4).  A view of a (T, ld) allocation; stride(1) == 1."""
+    (DESIGN.md section 2).  A view of a (T, ld) allocation; stride(1) == 1."""
     ld = int(_lib.lib().bpg_row_stride(int(B)))
     return torch.empty((T, ld), dtype=dtype, device=device)[:, :B]
 

@@ -139,7 +139,7 @@ int bpg_destroy(bpg_batch *b);
 int64_t bpg_num_envs(const bpg_batch *b);
 /* A handle over envs first_env .. first_env + n_envs - 1 of `parent` -- the same partition of the env index range that spreads a
  * job over GPUs, applied inside one GPU: launches on views of disjoint ranges are independent and may run side by
- * side on different streams (while one launch ramps up or drains the others stream; DESIGN.md).  A view SHARES the parent's
+ * side on different streams (while one launch ramps up or drains the others stream; DESIGN.md section 3).  A view SHARES the parent's
  * packed state (its launches read and write the parent's arrays in place: whatever the views did is what the parent sees), its
  * seed, id2obj tables, curriculum and generator stream indices, and OWNS the scratch a launch needs (success-count words,
  * step-ok words).  Env e of the view is env first_env + e of the parent in every respect (generator keys included).
@@ -270,7 +270,7 @@ int bpg_synth_masks_ld(bpg_batch *b, int t0, int T, uint32_t *d_masks, int64_t l
  * n-env batch -- masks, rewards, flags (bpg_rollout_args.ld_masks / ld_out).  Build-defined
  * layout choice, no reference counterpart (the reference has no time-major arrays; its episode
  * arrays are batch-major, rollout.py:155-172): rows a power of two apart land on the same HBM
- * channels, rows shifted by ~1 KB each do not (DESIGN.md section 4).  Pure host function. */
+ * channels, rows shifted by ~1 KB each do not (DESIGN.md section 2).  Pure host function. */
 int64_t bpg_row_stride(int64_t n_envs);
 
 /* obs['achieved_goal'] / obs['desired_goal'] of _get_obs (fetch_env.py:219-228,

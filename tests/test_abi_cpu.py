@@ -120,7 +120,7 @@ def test_shard_ranges_cover_the_batch():
 
 
 def test_row_stride_helper_is_a_pure_host_function():
-    """bpg_row_stride (layout of the time-major streams, DESIGN.md section 3) needs no GPU: contiguous rows
+    """bpg_row_stride (layout of the time-major streams, DESIGN.md section 2) needs no GPU: contiguous rows
     below 2^20 envs, above that an odd multiple of 256 elements (rows shifted by 1 KB against each other)."""
     L = _lib.lib()
     assert L.bpg_row_stride(0) == 0 and L.bpg_row_stride(-5) == 0

@@ -141,7 +141,10 @@ def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
     assert line['n_gpus'] == 2 and line['rccl_world_size'] == 2 and line['backend'] == 'gloo'
     assert line['scaling'] == 'strong' and line['config']['total_envs'] == 524288
     assert line['config']['envs_per_gpu'] == 262144
-    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 4 * 524288
+    # one BYTE per env travels (the episode fail count; expanded to the float32 returns on the device behind the gather)
+    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 524288
+    assert line['timing']['span_ms_per_rank'] and len(line['timing']['span_ms_per_rank']) == 2 and len(line['rank_devices']) == 2
+    assert line['ms_per_step'] * line['steps'] == pytest.approx(max(line['timing']['span_ms_per_rank']))
     assert line['collectives_issued'] == 1 + 2                     # end of the warm-up, then every second timed rollout
     km = line['kernel_ms_per_rank']
     assert len(km['all']) == 2 and 0 < km['min'] <= km['max']
@@ -149,9 +152,11 @@ def test_bench_starts_its_own_ranks_and_prints_one_parseable_line():
     assert line['value'] > 0 and 0 <= line['config']['success_rate'] <= 1
     cs = line['gathered_return_checksum']
     assert cs['all_negative_zero_or_below'] and (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(524288, cs['seed'])
+    assert cs['expansion_matches_bytes'] is True and 'u8' in cs['on_the_wire']
     c3 = line['extra']['config3_as_written']
     assert c3['total_envs'] == 1048576 and c3['envs_per_gpu'] == 524288 and c3['collective'] == 'allgather'
-    assert c3['collectives_issued'] == 2 + 4 and c3['gathered_bytes_per_rollout'] == 4 * 1048576
+    assert c3['collectives_issued'] == 2 + 4 and c3['gathered_bytes_per_rollout'] == 1048576
+    assert 'config3_cabi_collectives' not in line['extra']          # one card, gloo: no RCCL communicator over two ranks
 
 
 def test_bench_config3_as_written_on_four_ranks_of_one_card():
@@ -162,9 +167,9 @@ def test_bench_config3_as_written_on_four_ranks_of_one_card():
     returns of ONE 4 194 304-env batch."""
     line = _bench(['--gpus', '4', '--single-device', '--backend', 'gloo', '--total-envs', '4194304', '--steps', '3',
                    '--warmup', '1', '--prewarm', '2', '--collective', 'allgather', '--reduce-every', '1', '--no-extras',
-                   '--no-cpu-baseline', '--launch-timeout', '800'])
+                   '--no-cpu-baseline', '--launch-timeout', '800', '--gather-dtype', 'f32'])
     assert line['n_gpus'] == 4 and line['rccl_world_size'] == 4 and line['config']['envs_per_gpu'] == 1048576
-    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 4 * 4194304
+    assert line['collective'] == 'allgather' and line['gathered_bytes_per_rollout'] == 4 * 4194304       # the float32 form
     assert line['collectives_issued'] == 1 + 3 and 'config3_as_written' not in line.get('extra', {})   # the headline IS that config
     cs = line['gathered_return_checksum']
     assert cs['all_negative_zero_or_below'] and cs['failed_steps'] > 0
@@ -183,10 +188,18 @@ def test_bench_rccl_path_on_one_rank():
     assert line['collectives_issued'] == 4 and line['config']['envs_per_gpu'] == 1048576     # after rollouts 1 (warm-up end), 2, 5, 7
     c3 = line['extra']['config3_as_written']
     assert c3['backend'] == 'nccl' and c3['rccl_world_size'] == 1 and c3['total_envs'] == 4194304
-    assert c3['collectives_issued'] == 2 + 6 and c3['gathered_bytes_per_rollout'] == 4 * 4194304
+    assert c3['collectives_issued'] == 2 + 6 and c3['gathered_bytes_per_rollout'] == 4194304      # u8 on the wire
     cs = c3['gathered_return_checksum']
-    assert (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(4194304, cs['seed'])
+    assert (cs['failed_steps'], cs['weighted']) == _single_batch_checksum(4194304, cs['seed']) and cs['expansion_matches_bytes'] is True
     assert 0 < c3['roofline_kernel_only']['frac'] < 1 and c3['value'] > 0
+    # the same leg with the collectives issued by the library on the launch stream (bpg_comm_*): same gathered returns
+    cc = line['extra']['config3_cabi_collectives']
+    assert 'error' not in cc and cc['collectives_issued_by'].startswith('libbpgym.so') and cc['rccl_world_size'] == 1
+    assert cc['gathered_return_checksum'] == cs and cc['value'] > 0
+    # value is timed by the device-side span; the wall clock of the bracket is beside it and never shorter
+    tm = line['timing']
+    assert line['ms_per_step'] * line['steps'] == pytest.approx(max(tm['span_ms_per_rank'])) and tm['wall_ms_per_step_incl_sync_and_barrier'] >= line['ms_per_step']
+    assert len(line['rank_devices']) == 1 and line['rank_devices'][0]['device'] == 'cuda:0'
     sp = line['kernel_ms_spread']
     assert 0 < sp['min'] <= sp['timed_region'] <= sp['max'] and len(sp['later_groups']) == 3
     assert line['roofline']['traffic_source'] and 'NOT measured by this run' in line['roofline']['traffic_source']

@@ -464,7 +464,7 @@ def test_synthetic_rollout_shapes_vs_oracle_spec(B):
 def test_synthetic_source_rates_and_independence_on_the_gpu():
     """1 048 576 envs x 8 steps of the in-kernel source: every free pair is Bernoulli(5/32) to 4
     sigma, consecutive steps are uncorrelated, pairs of one step correlate by at most the 0.04 the
-    shared low-order digit introduces, table-block pairs are forced, the diagonal
+    shared low-order digit introduces (docs/HISTORY.md 5), table-block pairs are forced, the diagonal
     and absent objects never appear."""
     B, T = 1 << 20, 8
     L = bpg._lib.lib()

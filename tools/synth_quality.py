@@ -51,7 +51,7 @@ def rotl(x, r):
 
 
 def env_key(seed, env):
-    """key(seed + 1000 * env, 0) of DESIGN.md 5a (the reference's per-env seed arithmetic, rollout.py:206-210)"""
+    """key(seed + 1000 * env, 0) of docs/HISTORY.md 5a (the reference's per-env seed arithmetic, rollout.py:206-210)"""
     es = (np.uint64(seed) + np.uint64(1000) * env.astype(np.uint64))
     return lowbias32(u32(es) ^ lowbias32(u32((es >> np.uint64(32)) + np.uint64(0x9E3779B9))))
 
