@@ -240,6 +240,7 @@ class BatchedBlocksEnv:
         self.contact_source = contact_source if contact_source is not None else SyntheticContacts()
         B, dev = self.num_envs, self.device
         self._g = torch.empty(B, self.dimg, dtype=torch.float32, device=dev)
+        self._static_obs_stale = False
         self.observation = torch.zeros(B, self.dimo, dtype=torch.float32, device=dev)
         # cube xy of the current episode (_randomize_objects; filled when a contact source asks for it)
         self.block_xy = torch.full((B, self.num_objs - 2, 2), float('nan'), dtype=torch.float64, device=dev)
@@ -404,7 +405,9 @@ class BatchedBlocksEnv:
             assert observation_out.shape == (self.num_envs, self.dimo) and observation_out.dtype == torch.float32 \
                 and observation_out.stride(1) == 1 and env_mask is None
             self.observation = observation_out
-        obs = self.observation
+        if em is None:
+            self._static_obs_stale = False          # the reset launch rewrites every row
+        obs = self.observation                      # (a partial reset of a stale buffer refreshes the other rows first)
         _lib.check(self._L.bpg_reset_obs(self._h, _ptr(ng), _ptr(em), _ptr(obs), int(obs.stride(0)),
                                          _stream(self.device)))
         self._place(test=False, env_mask=em, variates=variates)
@@ -568,8 +571,27 @@ class BatchedBlocksEnv:
         """The part of Variation's _get_obs that needs no physics (fetch_env.py:579-607):
         obs[0] = num_blocks, colour one-hot of every present block, zero padding -- from the
         state as it stands (reset() does the same inside its own launch)."""
-        obs = self.observation
+        self._static_obs_stale = False
+        obs = self._observation
         _lib.check(self._L.bpg_fill_static_obs(self._h, _ptr(obs), int(obs.stride(0)), _stream(self.device)))
+
+    def _mark_static_observation_stale(self):
+        """The launches just enqueued reset envs without rewriting their observation rows (K rollouts in one launch,
+        RolloutStudent.evaluate_rollouts_fused): the physics-free entries (Variation's num_blocks / colour one-hots) are
+        refreshed when somebody next looks at `env.observation` -- 365 MB at 1 M envs that an evaluator loop which only keeps the
+        success rates never pays."""
+        if self.info.is_variation:
+            self._static_obs_stale = True
+
+    @property
+    def observation(self):
+        if self._static_obs_stale:
+            self._fill_static_observation()
+        return self._observation
+
+    @observation.setter
+    def observation(self, t):
+        self._observation = t
 
     def set_action_vector(self, action):
         """robot_env.py:58 + fetch_env.py:170-185: (B,4) actions -> the (B,9) float64 vector

@@ -761,8 +761,7 @@ class RolloutStudent:
             vs.join()
             if env.info.is_variation and ng is None:     # the views drew from the generator: its stream index moves once
                 _lib.check(_lib.lib().bpg_advance_generator(env._h, K, 0, _stream(self.device)))
-        if env.info.is_variation:       # the K in-launch resets drew new block counts: the env's observation rows follow
-            env._fill_static_observation()
+        env._mark_static_observation_stale()    # the K in-launch resets drew new block counts: the observation rows follow when read
         rates = [float(c) / B for c in counts.tolist()]
         self.success_history.extend(rates)
         self.n_episodes += K * B

@@ -107,6 +107,7 @@ def test_golden_rollout_fused(env_id):
     B, T = int(d['B']), int(d['T'])
     worker = bpg.RolloutStudent(lambda num_envs: bpg.make(env_id, num_envs=num_envs, device=DEV), None,
                                 dims_of(env_id), None, T, rollout_batch_size=B)
+    pinned_by_reference = []
     for r, test in enumerate(d['modes']):
         # the reference's contact lists (geom-id pairs of every step) -> the mask stream, on the device, in one launch
         # (env.contacts_to_masks: the model of each env is the one of the episode about to be drawn); the oracle's
@@ -118,10 +119,25 @@ def test_golden_rollout_fused(env_id):
                                               np.ascontiguousarray(d['r%d_ncon' % r].T), num_grey=num_grey)
         masks = fixture_masks(env_id, d['r%d_contacts' % r], d['r%d_ncon' % r], d['r%d_model_idx' % r])
         np.testing.assert_array_equal(dmasks.cpu().numpy().view(np.uint32), masks)
+        # Variation picks the sim -- and with it the id2obj table -- of an episode by num_objs = 4 + num_grey
+        # (fetch_env.py:647-651), and the conversion runs BEFORE the rollout's reset: it must take the table of the episode
+        # that is ABOUT to be drawn (d_num_grey), not the one of the state.  The reference pins that choice: with the table of
+        # the previous episode's state the masks differ wherever the block count changed and a contact involves a geom
+        # whose id moved, and the episode below would not be the reference's.
+        if env_id.startswith('BlocksTouchVariation'):
+            changed = (worker.env.num_objs_per_env().cpu().numpy() - 4) != num_grey
+            stale = worker.env.contacts_to_masks(np.ascontiguousarray(con.transpose(1, 0, 2, 3)),
+                                                 np.ascontiguousarray(d['r%d_ncon' % r].T), num_grey=None)
+            same = (stale.cpu().numpy().view(np.uint32) == masks).all(0)
+            assert same[~changed].all()                       # same model: same masks
+            if changed.any():
+                pinned_by_reference.append(bool((~same[changed]).any()))
         ep = worker.generate_rollouts_fused(test=bool(test), masks=dmasks, num_grey=num_grey)
         for k in ('ag', 'g', 'info_is_success'):
             np.testing.assert_array_equal(ep[k], d['r%d_%s' % (r, k)], err_msg=k)
         assert worker.success_history[-1] == pytest.approx(float(d['r%d_success_rate' % r]), abs=1e-7)
+    if env_id.startswith('BlocksTouchVariation'):
+        assert any(pinned_by_reference)          # the fixture does exercise a table switch that changes the masks
 
 
 def test_golden_compute_reward():
