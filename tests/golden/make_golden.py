@@ -785,6 +785,10 @@ def main(HERE=HERE):
                         **restart_trace('BlocksTouchVariation-v0', 911, 5, nan_raise))
     np.savez_compressed(os.path.join(HERE, 'restart_ToppleTower.npz'),
                         **restart_trace('ToppleTower-v0', 912, 4, [None, ('nan', 3, 49), ('raise', 1, 0), None]))
+    np.savez_compressed(os.path.join(HERE, 'restart_BlocksTouchChooseCurriculum.npz'),
+                        **restart_trace('BlocksTouchChooseCurriculum-v0', 913, 3, [('raise', 2, 10), None, ('nan', 1, 25), None]))
+    np.savez_compressed(os.path.join(HERE, 'restart_GripperTouch.npz'),
+                        **restart_trace('GripperTouch-v0', 914, 4, [('nan', 3, 3), ('nan', 0, 48), ('raise', 3, 49), None]))
     nan_only = [None, ('nan', 1, 12), None, ('nan', 3, 0), None]
     np.savez_compressed(os.path.join(HERE, 'pg_restart_BlocksTouch.npz'),
                         **restart_trace('BlocksTouch-v0', 920, 4, nan_only, pg=True, exploit_first=True))

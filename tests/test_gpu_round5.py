@@ -133,7 +133,7 @@ def _replay_restarts(name, pg, nan_check='per_step'):
     assert worker.n_episodes == int(d['n_episodes'])
 
 
-@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower'])
+@pytest.mark.parametrize('name', ['BlocksTouch', 'BlocksTouchVariation', 'ToppleTower', 'BlocksTouchChooseCurriculum', 'GripperTouch'])
 def test_golden_restarts_rollout_student(name):
     """RolloutStudent.generate_rollouts around a NaN observation and a MujocoException (rollout.py:136-142), bit for bit
     what the reference returned -- including what the discarded attempt left in the touch matrix (quirk Q1)."""

@@ -323,3 +323,53 @@ def test_trim_raises_as_numpy_does_when_a_row_has_the_wrong_number_of_coloured_b
         O.trim(o, d['variation_g'], d['variation_ag'], 40, 16, True)
     with pytest.raises(AssertionError):              # 3 objects of a 6 x 6 goal are 9 entries, not 16
         O.trim(d['variation_o'], d['variation_g'], d['variation_ag'], 40, 16, True, num_objs=3)
+
+
+@pytest.mark.parametrize('name,pg', [('BlocksTouch', False), ('BlocksTouchVariation', False), ('ToppleTower', False),
+                                     ('BlocksTouchChooseCurriculum', False), ('GripperTouch', False),
+                                     ('BlocksTouch', True), ('BlocksTouchVariation', True)])
+def test_restart_fixtures_replayed_on_the_oracle_envs(name, pg):
+    """rollout.py:136-142 / policy_gradient/rollout.py:243-246 around a scripted NaN or MujocoException, on the oracle's
+    matrix-form envs: every env takes the steps it took in the reference's discarded attempt (all envs k + 1 after a NaN at step
+    k; envs 0 .. j-1 k + 1 and the rest k when env j raised), is reset as often as the reference reset it (three times after a
+    NaN, twice after an exception), then runs the T steps of the attempt the reference returned.  With quirk Q1 the base
+    variants keep what the discarded steps touched, so the returned episode depends on exactly where the attempt ended."""
+    env_id = name + '-v0'
+    v = VARIANTS[env_id]
+    d = np.load(os.path.join(G, ('pg_restart_%s.npz' if pg else 'restart_%s.npz') % name))
+    B, T = int(d['B']), int(d['T'])
+    id2objs = [m['id2obj'] for m in v['models']]
+    envs = [O.OracleEnv(env_id) for _ in range(B)]
+    for e in envs:
+        e.reset(0)                                   # RolloutStudent.__init__ resets every env once (rollout.py:44)
+    for r in range(int(d['n_calls'])):
+        kind, j, k = (int(x) for x in d['faults'][r])
+        nobj = d['r%d_reset_num_objs' % r]           # (n_resets, B)
+        assert nobj.shape[0] == {0: 1, 1: 3, 2: 2}[kind]
+        nd = d['r%d_discard_steps' % r]
+        want_nd = [0] * B if kind == 0 else ([k + 1] * B if kind == 1 else [k + 1 if b < j else k for b in range(B)])
+        assert nd.tolist() == want_nd
+        ag = np.zeros((B, T + 1, envs[0].dimg))
+        succ = np.zeros((B, T, 1), np.float32)
+        rew = np.zeros((T, B), np.float32)
+        for b, e in enumerate(envs):
+            if kind:
+                e.reset(int(nobj[0, b]) - 4)
+                tab = id2objs[int(nobj[0, b]) - 4 if len(id2objs) > 1 else 0]
+                for t in range(int(nd[b])):
+                    e.step(tab, d['r%d_discard_contacts' % r][b, t, :d['r%d_discard_ncon' % r][b, t]])
+                for extra in range(1, nobj.shape[0] - 1):          # reset_all_rollouts before the retry (NaN only)
+                    e.reset(int(nobj[extra, b]) - 4)
+            ag[b, 0] = e.reset(int(nobj[-1, b]) - 4)
+            tab = id2objs[int(d['r%d_model_idx' % r][b])]
+            for t in range(T):
+                a, rr, _, s_ = e.step(tab, d['r%d_contacts' % r][b, t, :d['r%d_ncon' % r][b, t]])
+                ag[b, t + 1], succ[b, t, 0], rew[t, b] = a, s_, rr
+        np.testing.assert_array_equal(ag.astype(np.float32), d['r%d_ag' % r], err_msg='call %d' % r)
+        np.testing.assert_array_equal(succ, d['r%d_info_is_success' % r])
+        assert float(np.mean(succ[:, -1, 0].astype(np.float64))) == float(d['r%d_success_rate' % r])      # np.mean of a float64 array (rollout.py:123,165)
+        np.testing.assert_array_equal(np.stack([e.achieved_goal() for e in envs]), d['r%d_final_ag' % r])
+        if pg:
+            for b in range(B):
+                Gb = O.discounted_return(rew[:, b].astype(np.float64), 1. - 1. / T)
+                np.testing.assert_array_equal(Gb.view(np.uint64), d['r%d_G' % r][b].view(np.uint64))
