@@ -4,33 +4,37 @@
 
 namespace bpgk {
 
-// PIPE: software-pipelined mask requests (see the loop); used for the latency-bound batch sizes.
-// The plain loop (PIPE = false: UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound
-// fat shape runs: with >= 16 waves per CU other waves cover the round trips.
-// RESET: the launch starts with reset_all_rollouts (rollout.py:79).  Compile-time because the
-// elapsed counter is then the same for every lane (step t of the launch), so the time-limit
-// test, the saturation and the generator's Weyl term run on the scalar unit.
-// LB: the largest block the instantiation is ever launched with (the register budget follows from it:
-// 128 VGPRs at 1024 lanes, 512 / waves-per-SIMD below).
-// OKB: the launch also stores every env's step-ok word (bit t = the success condition held at step t, i.e. the
-// step reward was -0.0f; T <= 64) into okbits[n] -- 8 bytes per env instead of a 4 T-byte reward stream -- from
-// which k_returns_from_okbits computes the policy-gradient return.  (Computing G inside this launch, right
-// after a wave's steps, was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs,
-// profiles/r03_tune_pg_path.log -- the memory-bound step phase and the VALU-bound return phase of the same
-// waves do not overlap -- and removed.)
-// MULTI: `rollouts` consecutive rollouts in this ONE launch (each: reset, T steps, success count into its own counter
-// word), rollout r on rows r*T .. r*T+T-1 of the streams -- exactly what `rollouts` launches in a row would do, without
-// their fixed cost (5-6 us per launch, which is all a 65 536-env rollout has left to lose).  Envs are independent and a
-// lane only ever touches its own, so nothing has to be synchronised between the rollouts of a launch; the counts go out
-// as plain atomics that drain behind the next rollout's steps.
-// BPG_TL(slot) / BPG_ROLLOUT_MINB: hooks.hip.h (empty / 1 in the library build).
-// MODE: how the launch starts -- MODE_CONT: from the state as it is; MODE_RESET: with reset_all_rollouts; MODE_MULTI.
-// AUX: AUX_OKB (the step-ok words) or AUX_RET (a per-env counter of held steps in registers, for the episode return /
-// fail count when there is no step-ok word to take it from) or neither.
+// k_rollout<SRC, EPL, OUT, MODE, UNROLL, PIPE, LB, AUX>: T steps in one launch, EPL envs per lane, state in registers.
+// Masks / rewards / flags are time-major (T, ld) so every access is an (EPL * 4)-byte-per-lane coalesced stream.
+// SRC: SRC_MASKS (contacts read from the mask stream) or SRC_SYNTH (generated in-kernel, build-defined).
+// OUT: which per-step streams are written (bit 0 reward, bit 1 flags) -- compile-time, because a store behind a run-time
+//   `if (pointer)` makes the compiler assume "maybe not issued" when it counts outstanding memory operations, and every wait
+//   then also drains the stores.
+// MODE: how the launch starts.  MODE_CONT: from the state as it is.  MODE_RESET: with reset_all_rollouts (rollout.py:79) --
+//   compile-time because the elapsed counter is then the same for every lane (step t of the launch), so the time-limit test,
+//   the saturation and the generator's Weyl term run on the scalar unit.  MODE_MULTI: `rollouts` consecutive rollouts in this
+//   ONE launch (each: reset, T steps, success count into its own counter word), rollout r on rows r*T .. r*T+T-1 of the
+//   streams -- exactly what `rollouts` launches in a row would do, without their fixed cost (5-6 us per launch, which is all a
+//   65 536-env rollout has left to lose).  Envs are independent and a lane only ever touches its own, so nothing has to be
+//   synchronised between the rollouts of a launch; the counts go out as plain atomics that drain behind the next rollout's steps.
+// UNROLL, PIPE: steps per batch; PIPE = software-pipelined mask requests (see the loop), for the latency-bound batch sizes.  The
+//   plain loop (UNROLL requests, UNROLL steps, repeat) is what the bandwidth-bound fat shape runs: with >= 16 waves per CU
+//   other waves cover the round trips.
+// LB: the largest block the instantiation is ever launched with (the register budget follows from it: 128 VGPRs at 1024
+//   lanes, 512 / waves-per-SIMD below).
+// AUX: AUX_OKB -- the launch also stores every env's step-ok word (bit t = the success condition held at step t, i.e. the step
+//   reward was -0.0f; T <= 64) into okbits[n], 8 bytes per env instead of a 4 T-byte reward stream, from which
+//   k_returns_from_okbits computes the policy-gradient return.  (Computing G inside this launch, right after a wave's steps,
+//   was built and measured: 141-150 us against 52 + 83 us for the two launches at 1 M envs, profiles/r03_tune_pg_path.log --
+//   the memory-bound step phase and the VALU-bound return phase of the same waves do not overlap -- and removed.)
+//   AUX_RET -- a per-env counter of held steps in registers, for the episode return / fail count when there is no step-ok
+//   word to take it from (compile-time: the contacts-in-kernel form lives on occupancy and loses a wave per SIMD to the extra
+//   registers).  AUX_NONE -- neither.
 // The by-value constants a form does not use are not parameters of its instantiations (NoConst): the kernarg segment of the
-// masks forms carries no SynthConst, that of MODE_CONT no ResetConst.
-// (plain ints, not enumerators of an unnamed enum: such a type in a kernel's template-dependent signature is mangled with a
-// per-pass counter -- `$_0` on the host, `$_1` on the device -- and the launch then dies with "Cannot find Symbol")
+// masks forms carries no SynthConst, that of MODE_CONT no ResetConst.  BPG_TL(slot) / BPG_ROLLOUT_MINB: hooks.hip.h.
+// (MODE_* / AUX_* / SRC_* / OUT_* are plain ints, not enumerators of an unnamed enum: such a type in a kernel's
+// template-dependent signature is mangled with a per-pass counter -- `$_0` on the host, `$_1` on the device -- and the launch
+// then dies with "Cannot find Symbol".)
 constexpr int MODE_CONT = 0, MODE_RESET = 1, MODE_MULTI = 2;
 constexpr int AUX_NONE = 0, AUX_OKB = 1, AUX_RET = 2;
 struct NoConst {};
@@ -262,7 +266,7 @@ k_rollout(uint32_t *__restrict__ now, uint32_t *__restrict__ ever, const uint32_
     BPG_TL(13);
 }
 
-// Launch shape of the fused rollout, chosen from the batch size (tools/tune_round3.hip mode A,
+// Launch shape of the fused rollout, chosen from the batch size (round 3's tools/tune_round3.hip mode A,
 // profiles/r03_tune_mid_shapes.log; round 2: profiles/r02_tune_geometry.log; MI355X, T = 50, masks read cold
 // from HBM).  The kernel is a pure stream with T independent requests per lane, so what matters is (a) enough
 // resident waves on every CU to cover the HBM latency and (b), when there are not, that no wave waits for a

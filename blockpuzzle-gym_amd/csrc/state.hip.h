@@ -289,7 +289,7 @@ template <bool NT> __device__ __forceinline__ void st_d2(double2 *p, double2 v)
 // loads, computes, stores once and ends): nontemporal.  A plain store allocates in the L2 and is written back when the
 // kernel ends, behind its last wave and before the next launch of the stream may start (MI355X_MICROARCH.md
 // "boundary": + B / 6 TB/s for B dirty bytes); a nontemporal one streams out while the kernel runs.  Measured on the step
-// launch (tools/tune_round4.hip, profiles/r04_tune_step_train.log) and per kernel with -DBPG_OUT_NT=0 against the
+// launch (round 4's tools/tune_round4.hip, profiles/r04_tune_step_train.log) and per kernel with -DBPG_OUT_NT=0 against the
 // default on the same box (tools/ab_output_stores.py, profiles/r04_ab_output_stores.log).  The multi-GB episode writer
 // and the reset's observation rows are the exceptions (plain stores: profiles/r04_tune_episode_nontemporal.log; reset
 // + rows 8.4 us plain against 9.6 us at 65 536 envs), and so is everything a later step of the same launch train re-reads
@@ -435,13 +435,7 @@ __device__ __forceinline__ void block_count_add(uint32_t lane_count, const Count
     }
 }
 
-// T steps in one launch, EPL envs per lane, state in registers.  Masks / rewards are
-// time-major (T, n) so every access is an (EPL*4)-byte-per-lane coalesced stream.
-// Optionally resets first (rollout.py:79) and counts the final successes.
-// EPL, the block size and the loop form are picked from n by rollout_geometry().
-// OUT: which per-step streams are written (bit 0 reward, bit 1 flags) -- a compile-time choice,
-// because a store behind a run-time `if (pointer)` makes the compiler assume "maybe not issued"
-// when it counts outstanding memory operations, and every wait then also drains the stores.
+// which per-step streams a fused rollout writes (k_rollout's OUT template argument: rollout.hip)
 constexpr int OUT_REWARD = 1, OUT_FLAGS = 2;
 
 __device__ __forceinline__ void wave_lds_sync()

@@ -165,7 +165,7 @@ k_synth_masks(const uint32_t *__restrict__ ever, int64_t n, int t0, int T, uint3
 // stores.  Plain stores allocate in the L2 and are written back when the kernel ends, behind the last wave: in a
 // graph-replayed train of step launches at 65 536 envs that put 1.4 us of store drain inside every launch and 0.8 us
 // of write-back behind it (5.9 -> 4.1 us per step; 35.0 -> 33.3 us at 1 M envs, 152 -> 115 us at 4 M;
-// tools/tune_round4.hip, profiles/r04_tune_step_train.log).  The packed state, re-read by the next step, stays plain.
+// round 4's tools/tune_round4.hip, profiles/r04_tune_step_train.log).  The packed state, re-read by the next step, stays plain.
 // BPG_TL_STEP(slot, agp): hooks.hip.h (empty in the library build).
 template <int SIDE, int SRC, bool VEC4, int WPB = 1, bool NT = false>
 __global__ void __launch_bounds__(64 * WPB)
