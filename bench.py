@@ -15,8 +15,9 @@ With N>1 the run has a SECOND timed leg, reported under `extra.config3_as_writte
 episode fail count (1 B/env, bpg_rollout_args.d_episode_fail_count: the episode return is its negative; `--gather-dtype f32`
 moves the float32 return, 4 B/env, instead), the ranks all-gather those bytes over RCCL once per rollout and expand them to the
 float32 returns on the device (`--gpus 8 --total-envs 4194304 --collective allgather --reduce-every 1` makes that leg the
-headline instead).  A THIRD leg, `extra.config3_cabi_collectives`, repeats it with the collectives issued by the library itself
-on the launch stream (bpg_comm_*, include/bpgym.h) instead of torch.distributed.
+headline instead).  A THIRD and a FOURTH leg, `extra.config3_cabi_collectives[_side_stream]`, repeat it with the collectives issued by
+the library itself (bpg_comm_*, include/bpgym.h) instead of torch.distributed: on the launch stream, and on a second stream ordered
+by events so that the exchange runs beside the next launch; a watchdog gives them up after --cabi-leg-timeout seconds.
 TIMING: `value` = total env-steps of the K timed steps / MAX over ranks of the HIP-event span on the launch stream that covers
 them and the completion of their last exchange, measured inside the barrier + synchronize bracket (see rollout_leg); the wall
 clock of the bracket is reported beside it (`timing`).  N = 1 and N = 8 are measured the same way.
@@ -71,7 +72,7 @@ def parse():
     p.add_argument('--gather-dtype', choices=['u8', 'f32'], default='u8',
                    help='all-gather legs: what travels per env -- u8 = the episode fail count (bpg_rollout_args.d_episode_fail_count, '
                         '1 B/env, expanded to the float32 return on the device after the gather), f32 = the float32 return itself')
-    p.add_argument('--collective-impl', choices=['torch', 'cabi'], default='torch',
+    p.add_argument('--collective-impl', choices=['torch', 'cabi', 'cabi_side'], default='torch',
                    help='who issues the collectives: torch.distributed (its nccl backend runs them on a stream of its own, ordered '
                         'against the launch stream with events) or the library (bpg_comm_*: ncclAllGather / ncclAllReduce on the '
                         'launch stream itself)')
@@ -485,7 +486,16 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
     gathered = [torch.zeros(total, dtype=wire, device=dev) for _ in range(2)] if gather else None  # what the gather delivers
     # the float32 returns of all envs, global env order: the gathered array itself, or its expansion on the device
     returns_f32 = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)] if u8 else gathered
-    comm = cx.comm() if (multi and impl == 'cabi') else None
+    comm = cx.comm() if (multi and impl in ('cabi', 'cabi_side')) else None
+    side = torch.cuda.Stream(dev) if (comm is not None and impl == 'cabi_side') else None
+    overlapped = impl in ('torch', 'cabi_side')      # the exchange of rollout i runs beside the kernel of rollout i + 1
+
+    class _EventWork:              # what torch's Work is for its collectives: wait() = the current stream waits for the event
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream(dev).wait_event(self.ev)
 
     def per_env_arg(buf):
         return dict(d_episode_fail_count=buf.data_ptr()) if u8 else dict(d_episode_return=buf.data_ptr())
@@ -510,14 +520,16 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
             D.episode_return_from_fail_count(gathered[g % 2], out=returns_f32[g % 2])
 
     def settle(g):
-        """The launch stream waits for the gather of group g (a stream-level wait, no host block) and expands its bytes."""
+        """The launch stream waits for the gather of group g (a stream-level wait, no host block) and expands its bytes (the
+        side-stream form has expanded them there already)."""
         w = gworks.pop(g, None)
         if w is not None:
             w.wait()
-            expand(g)
+            if side is None:
+                expand(g)
 
     def one_rollout(i, k=None):
-        group_start = gather and impl == 'torch' and (i == 0 or coll_after[i - 1])
+        group_start = gather and overlapped and (i == 0 or coll_after[i - 1])
         if group_start:
             settle(grp[i] - 2)     # this group's buffers were read by the gather two groups ago (settled already, normally)
         if k == 0:
@@ -533,9 +545,20 @@ def rollout_leg(cx, total, B, collective, R, steps, warmup, prewarm, stride_prob
                 # one collective per R rollouts: the [successes, envs] rows not yet reduced
                 lo, pending[0] = pending[0], i + 1
                 if comm is not None:
-                    comm.all_reduce_sum_(stats[lo:i + 1])
+                    comm.all_reduce_sum_(stats[lo:i + 1])      # on the launch stream (16 R bytes: nothing to overlap)
                 else:
                     works.append(dist.all_reduce(stats[lo:i + 1], async_op=True))
+            elif side is not None:     # the library's ncclAllGather + the expansion on a second stream of the caller's,
+                g = grp[i]             # ordered by two events: beside the next rollout's kernel, as torch's collectives run
+                after_launch = torch.cuda.Event()
+                after_launch.record()
+                side.wait_event(after_launch)
+                with torch.cuda.stream(side):
+                    comm.all_gather(ret[g % 2], out=gathered[g % 2], stream=side)
+                    expand(g)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                gworks[g] = _EventWork(done)
             elif comm is not None:     # the library's ncclAllGather on the launch stream: stream order is all there is
                 g = grp[i]
                 comm.all_gather(ret[g % 2], out=gathered[g % 2])
@@ -900,8 +923,8 @@ def run(a):
         c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50),
                         impl=a.collective_impl, gather_dtype=a.gather_dtype)
         out.setdefault('extra', {})['config3_as_written'] = config3_record(
-            c, 'torch.distributed (RCCL on its own stream, asynchronous)' if a.collective_impl == 'torch'
-            else 'libbpgym.so (ncclAllGather on the launch stream)')
+            c, {'torch': 'torch.distributed (RCCL on its own stream, asynchronous)', 'cabi': 'libbpgym.so (ncclAllGather on the launch stream)',
+                'cabi_side': 'libbpgym.so (ncclAllGather + expansion on a second stream, event-ordered)'}[a.collective_impl])
         del c
         # The same leg with the collectives issued by the OTHER implementation, for the comparison on hardware.  The library's
         # communicator is created here for the first time (ncclCommInitRank over the ranks): should that never return, a
@@ -922,6 +945,12 @@ def run(a):
                 c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50),
                                 impl='cabi', gather_dtype=a.gather_dtype)
                 out['extra']['config3_cabi_collectives'] = config3_record(c, 'libbpgym.so (ncclAllGather on the launch stream)')
+                del c
+                torch.cuda.empty_cache()
+                c = rollout_leg(cx, a.config3_total, c_hi - c_lo, 'allgather', 1, a.steps, a.warmup, min(a.prewarm, 50),
+                                impl='cabi_side', gather_dtype=a.gather_dtype)
+                out['extra']['config3_cabi_collectives_side_stream'] = config3_record(
+                    c, 'libbpgym.so (ncclAllGather + expansion on a second stream, event-ordered: beside the next launch)')
                 del c
             except Exception as e:  # noqa: BLE001
                 out['extra']['config3_cabi_collectives'] = {'error': repr(e)[:300]}

@@ -196,6 +196,8 @@ def test_bench_rccl_path_on_one_rank():
     cc = line['extra']['config3_cabi_collectives']
     assert 'error' not in cc and cc['collectives_issued_by'].startswith('libbpgym.so') and cc['rccl_world_size'] == 1
     assert cc['gathered_return_checksum'] == cs and cc['value'] > 0
+    cs2 = line['extra']['config3_cabi_collectives_side_stream']          # ... and on a second stream, beside the next launch
+    assert 'error' not in cs2 and cs2['gathered_return_checksum'] == cs and cs2['value'] > 0
     # value is timed by the device-side span; the wall clock of the bracket is beside it and never shorter
     tm = line['timing']
     assert line['ms_per_step'] * line['steps'] == pytest.approx(max(tm['span_ms_per_rank'])) and tm['wall_ms_per_step_incl_sync_and_barrier'] >= line['ms_per_step']
