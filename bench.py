@@ -276,6 +276,45 @@ def sharded_roofline(cx, h, steps, warmup):
         del keep, vargs
     vs.close()
     torch.cuda.empty_cache()
+    # ---- the same through the package's worker: RolloutStudent.evaluate_rollouts_fused (the evaluator's test loop, train.py:63-64:
+    # K rollouts per call) on per-shard arrays of the shards' own (worker.shard_streams), one launch of K rollouts per shard, forked /
+    # joined per call; timed from outside with everything the call does (the K success counts read back); the one launch beside it
+    try:
+        dims = dict(o=env.dimo, u=4, g=env.dimg, info_is_success=1)
+        w = bpg.RolloutStudent(lambda num_envs: bpg.make(ENV_ID, num_envs=num_envs, device=dev, seed=cx.a.seed), None, dims, None, T,
+                               rollout_batch_size=B, output='torch')
+        K = min(steps, 20)
+        ngk = ng[None].expand(K, B).contiguous()
+        one_m = torch.empty((K * T, LD), dtype=torch.int32, device=dev)[:, :B]
+        for k in range(K):
+            w.env.seed(cx.a.seed + k)
+            _lib.check(L.bpg_synth_masks_ld(w.env._h, 0, T, C.c_void_p(one_m[k * T].data_ptr()), LD, cx.stream))
+        w.env.seed(cx.a.seed)
+        one_r = torch.empty((K * T, LD), dtype=torch.float32, device=dev)[:, :B]
+        one_f = torch.empty((K * T, LD), dtype=torch.uint8, device=dev)[:, :B]
+        own_m = w.shard_streams(K * T, torch.int32, S)
+        for t, (lo, n) in zip(own_m, w.shard_ranges(S)):
+            t.copy_(one_m[:, lo:lo + n])
+        own_r = w.shard_streams(K * T, torch.float32, S)
+        own_f = [torch.empty((K * T, int(r.stride(0))), dtype=torch.uint8, device=dev)[:, :r.shape[1]] for r in own_r]
+        for label, call in (('worker_own_arrays', lambda: w.evaluate_rollouts_fused(own_m, num_grey=ngk, reward_tb=own_r, flags_tb=own_f)),
+                            ('worker_one_launch', lambda: w.evaluate_rollouts_fused(one_m, num_grey=ngk, reward_tb=one_r, flags_tb=one_f))):
+            call()
+            torch.cuda.synchronize(dev)
+            runs = []
+            for g in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                call()
+                e1.record(cur)
+                torch.cuda.synchronize(dev)
+                runs.append(e0.elapsed_time(e1) / K)
+            out[label] = dict(figure(min(runs)), runs_ms=runs, rollouts_per_call=K,
+                              how='RolloutStudent.evaluate_rollouts_fused, %d rollouts per call, HIP events around the call, min of 3 calls' % K)
+        del w, one_m, one_r, one_f, own_m, own_r, own_f
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out['worker_own_arrays'] = {'error': repr(e)[:300]}
     out['how'] = ('%d views x K = %d launches each on %d streams, forked / joined once around them; HIP events on the launch stream; '
                   'min of 3 groups; the one launch under the same events: roofline.kernel_ms' % (S, steps, S))
     out.update({k: out['own_arrays'][k] for k in ('ms_per_rollout', 'achieved', 'frac')})

@@ -684,6 +684,19 @@ class RolloutStudent:
             out['episode_fail_count'] = nfail if self.output == 'torch' else nfail.cpu().numpy()
         return out
 
+    def shard_ranges(self, shards='auto'):
+        """[(first_env, n_envs)] of the stream shards the fused workers split this worker's batch into (`shards` as in
+        evaluate_rollouts_fused): contiguous, boundaries on multiples of 4 envs, the last shard takes the remainder."""
+        vs = self._shards_for(shards)
+        return [(0, self.rollout_batch_size)] if vs is None else [(lo, n) for _, _, lo, n in vs.views]
+
+    def shard_streams(self, rows, dtype, shards='auto'):
+        """One time-major (rows, n_shard) device array PER SHARD -- arrays of the shards' own, each with its own
+        bpg_row_stride -- for the masks / reward_tb / flags_tb of evaluate_rollouts_fused: a physics backend that fills the
+        contact masks shard by shard, or a consumer that reads the streams shard by shard, loses nothing by it, and launches on
+        such arrays stream at 0.78 of the HBM peak instead of 0.67-0.72 when many are in flight per join."""
+        return [time_major_empty(rows, n, dtype, self.device) for _, n in self.shard_ranges(shards)]
+
     def evaluate_rollouts_fused(self, masks, n_rollouts=None, test=False, num_grey=None, reward_tb=None,
                                 flags_tb=None, episode_return=None, episode_fail_count=None, shards=1):
         """The evaluator's test loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts(...)`
@@ -696,31 +709,63 @@ class RolloutStudent:
         the launch fills (step reward; bit 0 is_success, bit 1 done); episode_return: optional (K, B) float32
         the launch fills with every env's undiscounted return of each rollout; episode_fail_count: optional (K, B) uint8, the
         same as one byte per env (T <= 255).  Returns the K success rates.
-        shards: S > 1 (or 'auto': auto_shards(B), ranges of about 262 144 envs) runs the batch as S contiguous env ranges
-        (bpg_create_view), each ONE launch of its K rollouts on a stream of its own, forked from and joined into the current
-        stream -- the launches of different shards overlap, so the ramp-up and drain of one are covered by the others.  Every
-        array stays the caller's own (the shards read and write column ranges of them), every result bit is the one launch's.
-        DEFAULT 1, by measurement (round 5, profiles/r05_shard_probe.log, 1 M envs, two boxes): shards that work on column
-        ranges of the caller's arrays gain nothing over the one launch (89.6-90.1 against 90.1-90.2 us per rollout), and the
-        fork / join of a call costs more than that (K = 5: 145-147 against 133 us per rollout; K = 20: 110 against 106-107).
-        What gains is shards with arrays OF THEIR OWN launched back to back without a join per rollout (4 x 262 144: 83.4-84.9
-        us, 0.71-0.73 of the HBM peak against 0.67): a pipeline that owns its arrays per shard (distributed.StreamShards, or
-        views + its own streams), not something a call on the caller's arrays can be turned into."""
+
+        STREAM SHARDS.  The batch can run as S contiguous env ranges (views of the env, bpg_create_view), each launching its
+        rollouts back to back on a stream of its own, forked from and joined into the current stream once per call: the
+        launches of different shards overlap, so the ramp-up and drain of one are covered by the others.  Every result bit is
+        the one launch's.  Two forms:
+          * `masks` (and `reward_tb` / `flags_tb` when given) as a LIST of per-shard arrays -- arrays of the shards' own, one per
+            range of shard_ranges(len(masks)); shard_streams() allocates them;
+          * `shards=S` (or 'auto') with ONE (K*T, B) array per stream: the shards work on column ranges of the caller's arrays.
+        What was measured (bench.py roofline_sharded, profiles/r05_shard_probe.log; 1 M envs as 4 shards): launched back to
+        back and joined rarely, shards with arrays of their own stream at 0.78 of the HBM peak on every box against 0.67-0.72
+        for the one launch; on column ranges 0.67-0.77 depending on the box.  A CALL of this method has a fixed cost of about
+        250 us (validation, fork / join, the read-back of the K counts) that the one launch pays too in part: at the
+        evaluator's K = 10-20 rollouts per call the two forms come out even (89.7 against 90.2 us per rollout at K = 20), the
+        sharded form wins from about 50 rollouts per call.  Hence the default shards=1 -- one launch on the current stream --
+        and the per-shard-arrays form for pipelines that keep many rollouts in flight per join."""
         env, B, T = self.env, self.rollout_batch_size, self.T
-        assert masks.dim() == 2 and masks.shape[1] == B and masks.shape[0] % T == 0 and masks.element_size() == 4 \
-            and masks.stride(1) == 1 and masks.is_cuda
-        K = masks.shape[0] // T
+        per_shard = isinstance(masks, (list, tuple))
+        if per_shard:
+            shards = len(masks)
+        vs = self._shards_for(shards)
+        ranges = [(0, B)] if vs is None else [(lo, n) for _, _, lo, n in vs.views]
+        if per_shard and len(ranges) != len(masks):
+            raise ValueError('%d per-shard mask arrays for %d shards' % (len(masks), len(ranges)))
+
+        def per_range(x, dt, what):
+            """x: None, one (rows, B) array (every shard gets its column range) or a list of per-shard (rows, n) arrays ->
+            [(data pointer, row stride in elements)] per shard."""
+            if x is None:
+                return [(None, 0)] * len(ranges)
+            xs = list(x) if isinstance(x, (list, tuple)) else None
+            def ok(t, n):
+                return torch.is_tensor(t) and t.dim() == 2 and t.shape[1] == n and t.stride(1) == 1 and t.is_cuda and t.dtype in dt
+            if xs is None:
+                if not ok(x, B):
+                    raise ValueError('%s must be a (rows, %d) %s device array with unit inner stride' % (what, B, dt[0]))
+                ldx = int(x.stride(0)) if x.shape[0] > 1 else B
+                return [(x.data_ptr() + lo * x.element_size(), ldx) for lo, n in ranges]
+            if len(xs) != len(ranges) or not all(ok(t, n) for t, (lo, n) in zip(xs, ranges)):
+                raise ValueError('%s: per-shard arrays must be (rows, n) %s device arrays for the ranges %s (shard_ranges)'
+                                 % (what, dt[0], ranges))
+            return [(t.data_ptr(), int(t.stride(0)) if t.shape[0] > 1 else n) for t, (lo, n) in zip(xs, ranges)]
+
+        first = masks[0] if per_shard else masks
+        assert first.dim() == 2 and first.shape[0] % T == 0 and first.element_size() == 4
+        rows = first.shape[0]
+        K = rows // T
         if n_rollouts is not None and int(n_rollouts) != K:
             raise ValueError('masks hold %d rollouts of T = %d rows, n_rollouts = %d' % (K, T, n_rollouts))
-        ld = int(masks.stride(0)) if masks.shape[0] > 1 else B
-        ld_out = 0
-        for s, dt in ((reward_tb, torch.float32), (flags_tb, torch.uint8)):
-            if s is not None:
-                assert s.shape == masks.shape and s.dtype == dt and s.stride(1) == 1 and s.is_cuda
-                lo = int(s.stride(0)) if s.shape[0] > 1 else B
-                if ld_out not in (0, lo):
-                    raise ValueError('reward_tb and flags_tb must share one row stride')
-                ld_out = lo
+        m_ptrs = per_range(masks, (torch.int32, torch.uint32), 'masks')
+        r_ptrs = per_range(reward_tb, (torch.float32,), 'reward_tb')
+        f_ptrs = per_range(flags_tb, (torch.uint8,), 'flags_tb')
+        for x in (masks, reward_tb, flags_tb):
+            for t in (x if isinstance(x, (list, tuple)) else ([] if x is None else [x])):
+                assert t.shape[0] == rows
+        for (rp, rl), (fp, fl) in zip(r_ptrs, f_ptrs):
+            if rp and fp and rl != fl:
+                raise ValueError('reward_tb and flags_tb must share one row stride')
         ng = None
         if num_grey is not None:
             ng = torch.as_tensor(num_grey).to(self.device, torch.int32).contiguous()
@@ -733,31 +778,49 @@ class RolloutStudent:
         for x, dt in ((episode_return, torch.float32), (episode_fail_count, torch.uint8)):
             if x is not None:
                 assert x.shape == (K, B) and x.dtype == dt and x.is_contiguous() and x.is_cuda
-        args = _lib.RolloutArgs(T=T, reset_first=1, rollouts=K, d_masks=masks.data_ptr(), ld_masks=ld, ld_out=ld_out,
-                                d_episode_return=None if episode_return is None else episode_return.data_ptr(),
-                                d_episode_fail_count=None if episode_fail_count is None else episode_fail_count.data_ptr(),
-                                d_num_grey=None if ng is None else ng.data_ptr(),
-                                d_reward_tb=None if reward_tb is None else reward_tb.data_ptr(),
-                                d_flags_tb=None if flags_tb is None else flags_tb.data_ptr(),
-                                d_success_count=counts.data_ptr())
-        vs = self._shards_for(shards)
+
+        def args_of(i, lo, k0=0, nk=K):
+            """Rollouts k0 .. k0+nk-1 of shard i (first env lo) as one launch: its rows of its streams, its column range of the
+            (K, B) per-env arrays (row stride B); the K success counts are shared words (atomic adds)."""
+            off = lambda p, nbytes, ld: (p + nbytes * k0 * T * ld) if p else None        # noqa: E731  (row k0*T of a (K*T, ld) stream)
+            ldo = r_ptrs[i][1] or f_ptrs[i][1]
+            return _lib.RolloutArgs(
+                T=T, reset_first=1, rollouts=nk, d_masks=off(m_ptrs[i][0], 4, m_ptrs[i][1]), ld_masks=m_ptrs[i][1],
+                d_reward_tb=off(r_ptrs[i][0], 4, ldo), d_flags_tb=off(f_ptrs[i][0], 1, ldo), ld_out=ldo,
+                d_episode_return=None if episode_return is None else episode_return.data_ptr() + 4 * (lo + k0 * B),
+                d_episode_fail_count=None if episode_fail_count is None else episode_fail_count.data_ptr() + (lo + k0 * B),
+                d_num_grey=None if ng is None else ng.data_ptr() + 4 * (lo + k0 * B), ld_rollouts=B,
+                d_success_count=counts.data_ptr() + 8 * k0)
         if vs is None:
-            _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(args), _stream(self.device)))
+            a = args_of(0, 0)
+            _lib.check(_lib.lib().bpg_rollout_v2(env._h, C.byref(a), _stream(self.device)))
         else:
-            # every shard: its column range of the (K*T, ld) streams and of the (K, B) per-env arrays (row stride B), its K
-            # rollouts in ONE launch on its own stream; the K success counts are shared words (atomic adds)
-            per_env_bytes = dict(d_masks=4, d_reward_tb=4, d_flags_tb=1, d_num_grey=4, d_episode_return=4, d_episode_fail_count=1)
-            args.ld_rollouts = B
-            if ld_out == 0:
-                args.ld_out = B
+            # One launch PER ROLLOUT per shard, back to back on the shard's stream: what overlaps between the shards is the ends of
+            # their launches, and a launch that runs all K rollouts of a shard has none inside it (measured: K = 20 in one launch
+            # per shard is slower than the one launch of the whole batch; K launches per shard are not).  Generator-drawn num_grey
+            # needs the one launch: a view's resets do not advance the generator's stream index.
+            per_rollout = not (env.info.is_variation and ng is None)
+            # the K x S argument structs depend on the arrays' addresses only: an evaluator that reuses its buffers from call
+            # to call (they all do) pays for building them once -- at 20 us of Python per struct the enqueue of 80 launches
+            # would otherwise take as long as the launches themselves
+            key = (K, per_rollout, len(vs), tuple(m_ptrs), tuple(r_ptrs), tuple(f_ptrs),
+                   *(None if x is None else x.data_ptr() for x in (ng, episode_return, episode_fail_count)))
+            cache = self.__dict__.setdefault('_eval_launches', {})
+            plan = cache.get(key)
+            if plan is None:
+                if len(cache) >= 8:
+                    cache.clear()
+                rolls = [(k, 1) for k in range(K)] if per_rollout else [(0, K)]
+                plan = cache[key] = [(h, C.c_void_p(st.cuda_stream), args_of(i, lo, k0, nk))
+                                     for k0, nk in rolls for i, (h, st, lo, n) in enumerate(vs.views)]
+            count_ptr = counts.data_ptr()
+            L, byref = _lib.lib().bpg_rollout_v2, C.byref
             vs.fork()
-            for h, st, lo, n in vs.views:
-                a = _lib.RolloutArgs.from_buffer_copy(args)
-                for name, nbytes in per_env_bytes.items():
-                    base = getattr(args, name)
-                    if base:
-                        setattr(a, name, base + lo * nbytes)
-                _lib.check(_lib.lib().bpg_rollout_v2(h, C.byref(a), C.c_void_p(st.cuda_stream)))
+            for idx, (h, st_ptr, a) in enumerate(plan):
+                a.d_success_count = count_ptr + 8 * ((idx // len(vs)) if per_rollout else 0)   # the one field that is new every call
+                rc = L(h, byref(a), st_ptr)
+                if rc:
+                    _lib.check(rc)
             vs.join()
             if env.info.is_variation and ng is None:     # the views drew from the generator: its stream index moves once
                 _lib.check(_lib.lib().bpg_advance_generator(env._h, K, 0, _stream(self.device)))

@@ -387,8 +387,29 @@ def test_sharded_evaluator_equals_one_launch(env_id, B, S, explicit):
                      w.env.observation.clone()))
     if S == 'auto':
         assert len(many._view_shards) == 1 and len(next(iter(many._view_shards.values()))) == bpg.rollout.auto_shards(B)
-    a, b = outs
-    assert a[0] == b[0]
+    # the form that pays: arrays of the shards' own (shard_streams), one per range of shard_ranges
+    own = mk()
+    S_own = len(many.shard_ranges(S))
+    ranges = own.shard_ranges(S_own)
+    assert ranges == many.shard_ranges(S) and sum(n for _, n in ranges) == B and all(lo % 4 == 0 for lo, _ in ranges)
+    m_own = own.shard_streams(K * T, torch.int32, S_own)
+    for t, (lo, n) in zip(m_own, ranges):
+        t.copy_(masks[:, lo:lo + n])
+    for rep in range(2):
+        rw_own, fl_own = own.shard_streams(K * T, torch.float32, S_own), own.shard_streams(K * T, torch.float32, S_own)
+        fl_own = [torch.empty((K * T, int(r.stride(0))), dtype=torch.uint8, device=DEV)[:, :r.shape[1]] for r in rw_own]
+        er = torch.empty((K, B), dtype=torch.float32, device=DEV)
+        ef = torch.empty((K, B), dtype=torch.uint8, device=DEV)
+        rates = own.evaluate_rollouts_fused(m_own, num_grey=ng, reward_tb=rw_own, flags_tb=fl_own, episode_return=er, episode_fail_count=ef)
+    torch.cuda.synchronize()
+    outs.append((rates, torch.cat(rw_own, 1), torch.cat(fl_own, 1), er, ef, own.env.state_now.clone(), own.env.state_ever.clone(),
+                 own.env.state_counters.clone(), own.env.observation.clone()))
+    a, b, c = outs
+    assert a[0] == b[0] == c[0]
+    for x, y, name in zip(a[1:], c[1:], ('reward', 'flags', 'episode_return', 'episode_fail_count', 'now', 'ever', 'counters', 'obs')):
+        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), 'own arrays: ' + name
+    with pytest.raises(ValueError):
+        own.evaluate_rollouts_fused(m_own[:-1] + [m_own[-1], m_own[-1]])          # one array too many for the shards there are
     for x, y, name in zip(a[1:], b[1:], ('reward', 'flags', 'episode_return', 'episode_fail_count', 'now', 'ever', 'counters', 'obs')):
         assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), name
     assert list(one.success_history) == list(many.success_history) and one.n_episodes == many.n_episodes == 2 * K * B
