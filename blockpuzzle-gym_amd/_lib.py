@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libbpgym.so')
+# BPGYM_LIB: another build of the same sources (an A/B variant made with build.build(extra_flags=..., out=...)); tools only
+LIB_PATH = os.environ.get('BPGYM_LIB') or os.path.join(_HERE, 'lib', 'libbpgym.so')
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ATTRIBUTE = 0, -1, -2, -3, -4
 MAX_OBJS, NUM_PAIRS, MAX_GEOMS, MAX_MODELS = 6, 21, 64, 3
