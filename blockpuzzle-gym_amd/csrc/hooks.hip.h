@@ -16,6 +16,14 @@
 #ifndef BPG_ROLLOUT_MINB
 #define BPG_ROLLOUT_MINB 1
 #endif
+// rollout_geometry(): the batch size from which the fused rollout runs in 1024-lane blocks, and the lanes' worth of blocks per CU a
+// grid is capped at (A/B experiments of the launch shape)
+#ifndef BPG_ROLLOUT_FAT_FROM
+#define BPG_ROLLOUT_FAT_FROM 524288
+#endif
+#ifndef BPG_ROLLOUT_CU_LANES
+#define BPG_ROLLOUT_CU_LANES 1024
+#endif
 // write-once outputs of the one-shot kernels leave as nontemporal stores (state.hip.h, OUT_NT)
 #ifndef BPG_OUT_NT
 #define BPG_OUT_NT 1

@@ -313,7 +313,7 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
         // needs 200 VGPRs and is no faster than the plain loop: profiles/r03_tune_mid_shapes.log.)
         g.epl = 2;
         const bool aliased = ld_masks % 4096 == 0 || ld_out % 4096 == 0;
-        const bool fat = n >= 524288 && (n < 4194304 || !aliased);
+        const bool fat = n >= BPG_ROLLOUT_FAT_FROM && (n < 4194304 || !aliased);
         g.block = fat ? 1024 : 256;
         g.pipe = false;
     } else {
@@ -327,7 +327,7 @@ RolloutGeometry rollout_geometry(int64_t n, int64_t ld_masks, int64_t ld_out, co
     const int64_t lanes = n / g.epl;
     int64_t grid = (lanes + g.block - 1) / g.block;
     if (grid < 1) grid = 1;
-    const int64_t cap = 256 * (1024 / g.block);           // at most 1024 lanes' worth of blocks per CU
+    const int64_t cap = 256 * (g.block >= BPG_ROLLOUT_CU_LANES ? 1 : BPG_ROLLOUT_CU_LANES / g.block);   // at most 1024 lanes' worth of blocks per CU
     g.grid = (int)(grid > cap ? cap : grid);
     return g;
 }
