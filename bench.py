@@ -1000,6 +1000,8 @@ def run(a):
         dist.barrier()
     if rank == 0:
         emit(out)
+    if cx._comm is not None:             # the library's communicator goes before the process group that carried its id
+        cx._comm.close()
     if multi:
         dist.destroy_process_group()
 
