@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One process per GPU: every rank rolls out its contiguous shard of the env batch, the rollout launch writes the shard's
-per-env episode returns, ONE all-gather assembles them in global env order (BASELINE configs[3]).
+per-env episode fail counts (one byte per env: the episode return is its negative), ONE all-gather assembles them in global
+env order and they are expanded to the float32 returns on the device (BASELINE configs[3]).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/sharded_returns.py
     python examples/sharded_returns.py            # one process, no process group: the same code path, nothing gathered
@@ -32,8 +33,9 @@ def main():
                                 None, T, rollout_batch_size=hi - lo, output='torch', async_stats=True)
     for it in range(3):
         # contacts from the built-in synthetic source here; a physics backend passes masks=(T, B) or a contact_source
-        ep = worker.generate_rollouts_fused(episode_return=True)
-        returns = D.all_gather_per_env(ep['episode_return'], total_envs=TOTAL)        # (TOTAL,) on every rank
+        ep = worker.generate_rollouts_fused(episode_fail_count=True)
+        counts = D.all_gather_per_env(ep['episode_fail_count'], total_envs=TOTAL)     # (TOTAL,) uint8 on every rank: 1 B/env on the wire
+        returns = D.episode_return_from_fail_count(counts)                             # (TOTAL,) float32, bit for bit d_episode_return
         rate = D.global_success_rate(worker.env.success_count()[0], hi - lo, as_tensor=True)     # one 16-byte all-reduce
         if rank == 0:
             print('rollout %d: %d envs over %d rank(s), mean episode return %.3f, global success rate %.4f'
