@@ -147,6 +147,7 @@ SIGNATURES = {
                                             C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     'bpg_rollout_v2': (C.c_int, [C.c_void_p, C.POINTER(RolloutArgs), C.c_void_p]),
     'bpg_rollout': (C.c_int, []),
+    'bpg_rollout_train': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(RolloutArgs), C.c_int64, C.c_int, C.c_void_p]),
     'bpg_reserve_return_scratch': (C.c_int, [C.c_void_p]),
     'bpg_episode_return_from_fail_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'bpg_success_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -207,6 +207,7 @@ int bpg_create(bpg_batch **out, int variant, int64_t n_envs, int device_id, int 
     b->d_okbits = nullptr;
     b->cur = initial_curriculum(variant);
     b->parent = nullptr;
+    b->ev_fork = b->ev_join = nullptr;
     std::memset(b->ngeom, 0, sizeof(b->ngeom));
     const size_t bytes = (size_t)((n_envs + 3) & ~(int64_t)3) * sizeof(uint32_t);
     hipError_t e1 = hipMalloc(&b->now, bytes), e2 = hipMalloc(&b->ever, bytes);
@@ -244,6 +245,7 @@ int bpg_create_view(bpg_batch **out, bpg_batch *parent, int64_t first_env, int64
     bpg_batch *b = new (std::nothrow) bpg_batch(*parent);
     if (!b) return fail(BPG_ERR_ARG, "out of host memory");
     b->parent = parent;
+    b->ev_fork = b->ev_join = nullptr;
     b->n = n_envs;
     b->env_base = parent->env_base + first_env;
     b->now = parent->now + first_env;
@@ -277,6 +279,8 @@ int bpg_destroy(bpg_batch *b)
 {
     if (!b) return BPG_OK;
     DeviceGuard guard(b->device);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     if (b->parent) {                       // a view owns its scratch only
         if (b->d_count_shards) (void)hipFree(b->d_count_shards);
         if (b->d_okbits) (void)hipFree(b->d_okbits);

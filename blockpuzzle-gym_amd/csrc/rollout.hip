@@ -507,4 +507,43 @@ int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream)
     return rcode;
 }
 
+int bpg_rollout_train(bpg_batch *const *handles, void *const *streams, int n_shards, const bpg_rollout_args *args,
+                      int64_t args_stride_bytes, int n_launches, void *caller_stream)
+{
+    if (!handles || !streams || !args) return fail(BPG_ERR_ARG, "NULL argument");
+    if (n_shards < 1 || n_shards > 64 || n_launches < 1) return fail(BPG_ERR_ARG, "n_shards must be in 1..64 and n_launches >= 1");
+    if (args_stride_bytes < (int64_t)BPG_ROLLOUT_ARGS_MIN_SIZE || args_stride_bytes % 8 != 0)
+        return fail(BPG_ERR_ARG, "args_stride_bytes must be the size of the caller's bpg_rollout_args");
+    for (int s = 0; s < n_shards; s++) {
+        if (!handles[s]) return fail(BPG_ERR_ARG, "a handle is NULL");
+        if (handles[s]->device != handles[0]->device) return fail(BPG_ERR_ARG, "the shards of a train live on one device");
+        for (int q = 0; q < s; q++)
+            if (handles[q] == handles[s] || streams[q] == streams[s])
+                return fail(BPG_ERR_ARG, "every shard needs a handle and a stream of its own");
+    }
+    DeviceGuard guard(handles[0]->device);
+    hipStream_t cs = (hipStream_t)caller_stream;
+    auto event_of = [](hipEvent_t &e) -> hipError_t { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); };
+    // fork: the shards' streams start behind everything enqueued on the caller's stream so far (one event, n_shards waits)
+    HIP_TRY(event_of(handles[0]->ev_fork));
+    HIP_TRY(hipEventRecord(handles[0]->ev_fork, cs));
+    for (int s = 0; s < n_shards; s++)
+        if ((hipStream_t)streams[s] != cs) HIP_TRY(hipStreamWaitEvent((hipStream_t)streams[s], handles[0]->ev_fork, 0));
+    // launch-major: launch l of every shard before launch l + 1 of any, so that no stream runs dry while the host is enqueuing
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(args);
+    for (int l = 0; l < n_launches; l++)
+        for (int s = 0; s < n_shards; s++) {
+            const bpg_rollout_args *a = reinterpret_cast<const bpg_rollout_args *>(base + ((int64_t)l * n_shards + s) * args_stride_bytes);
+            if (int rc = bpg_rollout_v2(handles[s], a, streams[s])) return rc;
+        }
+    // join: the caller's stream continues behind the last launch of every shard
+    for (int s = 0; s < n_shards; s++) {
+        if ((hipStream_t)streams[s] == cs) continue;
+        HIP_TRY(event_of(handles[s]->ev_join));
+        HIP_TRY(hipEventRecord(handles[s]->ev_join, (hipStream_t)streams[s]));
+        HIP_TRY(hipStreamWaitEvent(cs, handles[s]->ev_join, 0));
+    }
+    return BPG_OK;
+}
+
 }  // extern "C"

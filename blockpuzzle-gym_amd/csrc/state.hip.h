@@ -94,6 +94,7 @@ struct bpg_batch {
                                           // bpg_reserve_return_scratch or the first bpg_rollout_v2 call with d_G (NULL until then)
     bpg_curriculum cur;                   // difficulty + placement ranges (fetch_env.py:340-348, :404-417, :561-563)
     bpg_batch *parent;                    // a view (bpg_create_view): the handle whose envs these are; NULL for a batch of its own
+    hipEvent_t ev_fork, ev_join;          // bpg_rollout_train: created on first use (timing disabled), owned by the handle
 };
 
 // what a view shares with its parent and never copies: seed, id2obj tables, curriculum

@@ -811,17 +811,21 @@ class RolloutStudent:
                 if len(cache) >= 8:
                     cache.clear()
                 rolls = [(k, 1) for k in range(K)] if per_rollout else [(0, K)]
-                plan = cache[key] = [(h, C.c_void_p(st.cuda_stream), args_of(i, lo, k0, nk))
-                                     for k0, nk in rolls for i, (h, st, lo, n) in enumerate(vs.views)]
-            count_ptr = counts.data_ptr()
-            L, byref = _lib.lib().bpg_rollout_v2, C.byref
-            vs.fork()
-            for idx, (h, st_ptr, a) in enumerate(plan):
-                a.d_success_count = count_ptr + 8 * ((idx // len(vs)) if per_rollout else 0)   # the one field that is new every call
-                rc = L(h, byref(a), st_ptr)
-                if rc:
-                    _lib.check(rc)
-            vs.join()
+                S = len(vs)
+                arr = (_lib.RolloutArgs * (len(rolls) * S))()                      # launch-major, as bpg_rollout_train reads it
+                for l, (k0, nk) in enumerate(rolls):
+                    for i, (h, st, lo, n) in enumerate(vs.views):
+                        arr[l * S + i] = args_of(i, lo, k0, nk)
+                plan = cache[key] = (arr, len(rolls), (C.c_void_p * S)(*[h.value for h, _, _, _ in vs.views]),
+                                     (C.c_void_p * S)(*[st.cuda_stream for _, st, _, _ in vs.views]))
+            arr, n_launches, handles, streams = plan
+            count_ptr, S = counts.data_ptr(), len(vs)
+            for idx in range(n_launches * S):          # the one field that is new every call
+                arr[idx].d_success_count = count_ptr + 8 * ((idx // S) if per_rollout else 0)
+            # ONE call enqueues the fork, the n_launches x S launches and the join (bpg_rollout_train): the host cost of a launch is
+            # that of the kernel launch itself, not a trip through the interpreter
+            _lib.check(_lib.lib().bpg_rollout_train(handles, streams, S, arr, C.sizeof(_lib.RolloutArgs), n_launches,
+                                                    _stream(self.device)))
             if env.info.is_variation and ng is None:     # the views drew from the generator: its stream index moves once
                 _lib.check(_lib.lib().bpg_advance_generator(env._h, K, 0, _stream(self.device)))
         env._mark_static_observation_stale()    # the K in-launch resets drew new block counts: the observation rows follow when read

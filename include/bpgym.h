@@ -455,6 +455,16 @@ static inline bpg_rollout_args bpgh_rollout_args_init(void)
 int bpg_rollout_v2(bpg_batch *b, const bpg_rollout_args *args, void *stream);
 /* the round-3 entry point of that name took a struct without the size word: kept as a stub that returns BPG_ERR_UNSUPPORTED */
 int bpg_rollout(void);
+/* A TRAIN of fused rollouts over stream shards in one call: launch l (l < n_launches) of shard s (s < n_shards) is
+ * bpg_rollout_v2(handles[s], &args[l * n_shards + s], streams[s]) -- args is an array of n_launches * n_shards structs,
+ * args_stride_bytes apart (the caller's sizeof(bpg_rollout_args)), launch-major.  The shards' streams are forked from
+ * caller_stream in front of the train and joined into it behind it (one event and n_shards waits each way; the events are the
+ * handles' own, created on first use), and nothing else is synchronised: the launches of different shards run side by side.  The
+ * handles are views of one batch (bpg_create_view) or batches of their own, one stream each, all on one device.  This is the
+ * evaluator's loop -- `for _ in range(n_test_rollouts): evaluator.generate_rollouts()` (train.py:63-64) -- for a batch split into
+ * shards, without a host round trip per launch: the host cost of a launch is that of the kernel launch itself. */
+int bpg_rollout_train(bpg_batch *const *handles, void *const *streams, int n_shards, const bpg_rollout_args *args,
+                      int64_t args_stride_bytes, int n_launches, void *caller_stream);
 /* The step-ok words behind bpg_rollout_args.d_G (8 bytes per env) are handle-owned scratch that the first call asking for d_G
  * would otherwise allocate with a device-synchronising hipMalloc in the middle of the stream (and could not at all inside a
  * stream capture): allocate them up front, once, from set-up code.  Idempotent. */

@@ -452,3 +452,21 @@ def test_sharded_episode_writer_equals_one_launch(env_id, B, S):
     assert L.bpg_create_view(C.byref(h2), h, 0, 4) == _lib.ERR_ARG                          # no views of views
     assert L.bpg_get_difficulty(h) == env.get_difficulty()
     _lib.check(L.bpg_destroy(h))
+
+
+def test_rollout_train_argument_checks():
+    """bpg_rollout_train: one handle and one stream per shard, all on one device, the caller's struct size as the stride."""
+    L = _lib.lib()
+    env = bpg.make('BlocksTouch-v0', num_envs=64, device=DEV)
+    h = (C.c_void_p * 2)(env._h.value, env._h.value)
+    s0, s1 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    st = (C.c_void_p * 2)(s0.cuda_stream, s1.cuda_stream)
+    a = (_lib.RolloutArgs * 2)(_lib.RolloutArgs(T=3, reset_first=1), _lib.RolloutArgs(T=3, reset_first=1))
+    size = C.sizeof(_lib.RolloutArgs)
+    assert L.bpg_rollout_train(h, st, 2, a, size, 1, None) == _lib.ERR_ARG and b'of its own' in L.bpg_last_error()
+    assert L.bpg_rollout_train(h, st, 0, a, size, 1, None) == _lib.ERR_ARG
+    assert L.bpg_rollout_train(h, st, 1, a, 12, 1, None) == _lib.ERR_ARG
+    assert L.bpg_rollout_train(None, st, 1, a, size, 1, None) == _lib.ERR_ARG
+    assert L.bpg_rollout_train(h, st, 1, a, size, 2, None) == 0          # one shard, two launches: a plain train on its stream
+    torch.cuda.synchronize()
+    assert int((env.state_now >> 21).max()) == 3
