@@ -193,15 +193,16 @@ int main()
     HIP(hipStreamCreate(&st[0])); HIP(hipStreamCreate(&st[1]));
     uint8_t *d_fail, *d_all; float *d_ret_g, *d_ret_direct;
     HIP(hipMalloc(&d_fail, Bj)); HIP(hipMalloc(&d_all, Bj)); HIP(hipMalloc(&d_ret_g, Bj * 4)); HIP(hipMalloc(&d_ret_direct, Bj * 4));
+    static bpg_rollout_args sa = BPG_ROLLOUT_ARGS_INIT_STATIC;              // the constant initialiser (C statics)
+    bpg_rollout_args train[2] = {sa, sa};
+    void *shard_streams[2] = {st[0], st[1]};
     for (int r = 0; r < 2; r++) {
-        static bpg_rollout_args sa = BPG_ROLLOUT_ARGS_INIT_STATIC;          // the constant initialiser (C statics)
-        bpg_rollout_args a = sa;
-        a.T = 50; a.reset_first = 1;                                         // contacts from the synthetic source, num_grey from the generator
-        a.d_episode_fail_count = d_fail + r * (Bj / 2);
-        a.d_episode_return = d_ret_direct + r * (Bj / 2);
-        CHECK(bpg_rollout_v2(shard[r], &a, st[r]));
+        train[r].T = 50; train[r].reset_first = 1;                           // contacts from the synthetic source, num_grey from the generator
+        train[r].d_episode_fail_count = d_fail + r * (Bj / 2);
+        train[r].d_episode_return = d_ret_direct + r * (Bj / 2);
     }
-    HIP(hipStreamSynchronize(st[0])); HIP(hipStreamSynchronize(st[1]));
+    // fork from the default stream, one launch per shard on its own stream, join: ONE call
+    CHECK(bpg_rollout_train(shard, shard_streams, 2, train, (int64_t)sizeof(bpg_rollout_args), 1, nullptr));
     CHECK(bpg_advance_generator(job, 1, 0, nullptr));                        // the views drew from the generator: once, on the parent
     unsigned char id[BPG_COMM_ID_BYTES];
     bpg_comm *comm = nullptr;
